@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- CG iterations/sec and SpMV achieved HBM GB/s on the 7-point Poisson 512^3 matrix.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" is one CG iteration of the hot path (halo exchange, SpMV fused with p.Ap, x/r update fused
+with r.r, stop-test scalars, p update) on the synthetic 7-point 512^3 system (config of BASELINE.json's
+metric; it fits one GPU: 11.8 GB CSR + 5.4 GB vectors).  With N GPUs the SAME matrix is row-partitioned
+into N z-slabs (strong scaling, the north star's ">= 6x at 8 GPUs"), one process per GPU, RCCL inside
+libMgcgGpu.so for the two scalar all-reduces and the halo exchange; torch.distributed only bootstraps
+(unique id, barriers, max over ranks).  The matrix is generated directly in HBM by the library's device
+generator; no reference data set exists or is needed ("data": "synthetic").
+
+Output: ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel = CSR SpMV: algorithmic bytes / launch (12*nnz + 4*(N+1) + 16*N,
+                  SURVEY.md section 8d) divided by its average duration measured with HIP events on the
+                  library's stream inside the timed region; peak = 8.0 TB/s HBM3E.
+  cpu_baseline -- the CPU oracle (single thread, the reference CPU path's behaviour) timed on a bounded
+                  sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--grid", type=int, default=512, help="n for the n^3 7-point Poisson grid (BASELINE config: 512)")
+    ap.add_argument("--solver", choices=["cg", "mgcg"], default="cg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=4, help="CG iterations of the CPU oracle sample")
+    ap.add_argument("--spmv-kernel", type=int, default=None)
+    ap.add_argument("--spmv-rows", type=int, default=None)
+    ap.add_argument("--spmv-flags", type=int, default=None)
+    ap.add_argument("--spmv-grid", type=int, default=None)
+    return ap.parse_args()
+
+
+def cpu_baseline(n: int, iters: int):
+    """The CPU oracle (oracle/cg_oracle.c, single thread like the reference's serial C# loops) on the same
+    7-point n^3 system; falls back to a smaller grid if host memory is short."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    L = O.lib()
+    avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    grid = n
+    while grid > 64 and (12 * 7 + 8 * 6) * grid**3 * 1.15 > avail:
+        grid //= 2
+    N = grid**3
+    nnz = L.oracle_poisson_nnz(grid, grid, grid)
+    e = np.empty(nnz)
+    c = np.empty(nnz, dtype=np.int32)
+    r = np.empty(N + 1, dtype=np.int32)
+    L.oracle_poisson_fill(grid, grid, grid, e, c, r)
+    x, b, work = np.zeros(N), np.ones(N), np.empty(3 * N)
+    res = C.c_double(0)
+    # init (r = b - A x, p = r, rr) is outside the per-iteration figure, as on the GPU side
+    t0 = time.perf_counter()
+    L.oracle_cg_steps(e, c, r, N, x, b, 0, C.byref(res), work)
+    t_init = time.perf_counter() - t0
+    x[:] = 0
+    t0 = time.perf_counter()
+    L.oracle_cg_steps(e, c, r, N, x, b, iters, C.byref(res), work)
+    dt = time.perf_counter() - t0 - t_init
+    its = iters / max(dt, 1e-9)
+    scale = (grid / n) ** 3     # report in units of the full-size workload
+    return {
+        "value": its * scale,
+        "unit": "iterations/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{iters} CG iterations of the CPU oracle (C restatement of ConjugateGradientCpu.cs, 1 thread) on 7-pt Poisson {grid}^3"
+                  + ("" if grid == n else f", rate scaled by ({grid}/{n})^3 to the {n}^3 workload"),
+        "seconds_per_iteration": dt / iters,
+        "residual": res.value,
+    }
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+
+    dist = None
+    if world > 1:
+        # torch first: its bundled HIP runtime and RCCL then serve the whole process (one HIP, one RCCL).
+        import torch  # noqa: F401
+        import torch.distributed as dist_mod
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("gloo")
+        dist = dist_mod
+
+    from conjugategradient_amd import _lib
+    from conjugategradient_amd.parallel import ConjugateGradientRankGpu
+
+    L = _lib.lib()
+    _lib.require_gpu()
+    n = a.grid
+    N = n**3
+    if world > 1 and n % world:
+        raise SystemExit("grid extent must be divisible by the number of GPUs (z-slab partition)")
+
+    cg = ConjugateGradientRankGpu(N, 7, 0, 10**9, 1e-8, rank=rank, world=world, device=local_rank)
+    if a.spmv_kernel is not None:
+        L.MgcgSetSpmvKernel(cg.cusparse, a.spmv_kernel)
+    if a.spmv_rows is not None or a.spmv_flags is not None or a.spmv_grid is not None:
+        L.MgcgSetSpmvTuning(cg.cusparse, a.spmv_rows or 256, a.spmv_flags or 0, a.spmv_grid or 0)
+    cg.InitializePoisson(n, n, n)
+    L.MgcgDeviceSynchronize()
+    _lib.check("setup")
+    nnz_local = cg.part.elementCount
+    rows_local = cg.part.count
+
+    mg_info = None
+    if a.solver == "mgcg":
+        raise SystemExit("--solver mgcg is reported by tools/bench_mgcg.py in this round; bench.py's metric is the CG iteration")
+
+    # warm-up (also builds the RCCL communicator and the halo plan)
+    cg.Steps(max(a.warmup, 1), restart=True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    L.MgcgProfileSpmv(cg.cusparse, 1)
+    barrier()
+    L.MgcgDeviceSynchronize()
+    t0 = time.perf_counter()
+    res = cg.Steps(a.steps, restart=False)      # synchronises the stream before returning
+    L.MgcgDeviceSynchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    launches = C.c_int(0)
+    spmv_ms_total = L.MgcgProfileSpmvMs(cg.cusparse, C.byref(launches))
+    L.MgcgProfileSpmv(cg.cusparse, 0)
+
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([dt, spmv_ms_total / max(launches.value, 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, spmv_ms = float(t[0]), float(t[1])
+    else:
+        spmv_ms = spmv_ms_total / max(launches.value, 1)
+
+    if rank == 0:
+        spmv_bytes = 12 * nnz_local + 4 * (rows_local + 1) + 16 * rows_local     # per launch, per GPU
+        achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+        nnz_total = 7 * N - 6 * n * n
+        iter_bytes = 12 * nnz_total + 4 * (N + 1) + 16 * N + 72 * N
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+        if os.path.exists(pmc_file) and world == 1:
+            try:
+                pj = json.load(open(pmc_file))
+                if pj.get("grid") == n:
+                    traffic = pj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "CG iterations/sec (7-pt Poisson 512^3); SpMV achieved HBM GB/s in roofline",
+            "value": a.steps / dt,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"unpreconditioned CG iteration, 7-point Poisson {n}^3 CSR (fp64 values, int32 indices), "
+                                   f"b=1, x0=0, {world} z-slab partition(s)",
+                       "rows": N, "nnz": nnz_total, "parallelism": f"row-range dp{world}"},
+            "iteration_algorithmic_gbps": iter_bytes / (dt / a.steps) / 1e9,
+            "residual_after_steps": res,
+            "roofline": {"bound": "hbm", "kernel": "spmv_stream_kernel (CSR SpMV fused with p.Ap)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms, "launches_timed": launches.value},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, a.cpu_iters)
+        print(json.dumps(out), flush=True)
+
+    cg.Dispose()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

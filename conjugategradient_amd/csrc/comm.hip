@@ -1,0 +1,202 @@
+// One process per GPU: RCCL over xGMI, bound at run time (dlopen) so that libMgcgGpu.so loads on
+// hosts without RCCL and a single-GPU caller never touches it.
+// Replaces the reference's host-staged "collectives": resultsDot.Sum() and SyncP/P2Host/P2Device
+// (Mgcg/cuBlas/Mgcg/ConjugateGradientParallelGpu.cs:384-419,463,499,525).
+#include "common.hpp"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace mgcg {
+
+// Types and enums come from rccl.h; the functions are bound at run time.
+typedef ncclUniqueId NcclUniqueId;
+typedef ncclComm_t NcclComm;
+static const ncclDataType_t NCCL_DOUBLE = ncclDouble;
+static const ncclDataType_t NCCL_INT32 = ncclInt32;
+static const ncclRedOp_t NCCL_SUM = ncclSum;
+
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+static Rccl* rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // Prefer a copy already in the process (e.g. the one torch loaded) so there is one RCCL per process.
+        const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+        for (const char* n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (r.lib) break; }
+        if (!r.lib) for (const char* n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.lib) break; }
+        if (!r.lib) return;
+#define SYM(field, name) r.field = (decltype(r.field))dlsym(r.lib, name)
+        SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+        SYM(AllReduce, "ncclAllReduce"); SYM(AllGather, "ncclAllGather"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
+        SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    });
+    if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd || !r.AllGather) {
+        set_error("RCCL is not available (dlopen librccl.so.1 failed: %s)", dlerror() ? dlerror() : "missing symbols");
+        return nullptr;
+    }
+    return &r;
+}
+
+static bool nccl_ok(ncclResult_t rc, const char* what)
+{
+    if (rc == ncclSuccess) return true;
+    Rccl* r = rccl();
+    set_error("%s failed: %s", what, (r && r->GetErrorString) ? r->GetErrorString(rc) : "rccl error");
+    return false;
+}
+
+} // namespace mgcg
+
+struct MgcgComm {
+    mgcg::NcclComm comm = nullptr;
+    int nranks = 1, rank = 0;
+    hipStream_t stream = nullptr;
+    double* scratch = nullptr;       // device, 8 doubles
+    long long* gathered = nullptr;   // host copy of every rank's (offset, count, minJ, maxJ)
+};
+
+namespace mgcg {
+
+bool comm_allreduce_sum(MgcgComm* c, double* devPtr, int count, hipStream_t s)
+{
+    if (!c || c->nranks == 1) return true;
+    Rccl* r = rccl();
+    if (!r) return false;
+    return nccl_ok(r->AllReduce(devPtr, devPtr, (size_t)count, NCCL_DOUBLE, NCCL_SUM, c->comm, s), "ncclAllReduce");
+}
+
+// For every peer: the contiguous range of p this rank must send (its own rows that the peer's
+// matrix slice references) and receive (the peer's rows this rank's slice references).
+struct HaloPlan {
+    int nranks = 1;
+    std::vector<long long> sendBegin, sendCount, recvBegin, recvCount;
+};
+
+HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long long countLocal, int minJ, int maxJ)
+{
+    HaloPlan* h = new HaloPlan();
+    if (!c || c->nranks == 1) return h;
+    Rccl* r = rccl();
+    if (!r) { delete h; return nullptr; }
+    const int n = c->nranks;
+    h->nranks = n;
+    // all-gather (offset, count, minJ, maxJ) of every rank
+    long long mine[4] = { offset, countLocal, (long long)minJ, (long long)maxJ };
+    long long* dAll = nullptr;
+    if (!MGCG_HIP(hipMalloc((void**)&dAll, sizeof(long long) * 4 * (size_t)n))) { delete h; return nullptr; }
+    bool ok = MGCG_HIP(hipMemcpyAsync(dAll + 4 * c->rank, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
+    ok = ok && MGCG_HIP(hipStreamSynchronize(c->stream));
+    // 4 int64 = 8 int32 per rank
+    ok = ok && nccl_ok(r->AllGather(dAll + 4 * c->rank, dAll, 8, NCCL_INT32, c->comm, c->stream), "ncclAllGather");
+    std::vector<long long> all(4 * (size_t)n);
+    ok = ok && MGCG_HIP(hipMemcpyAsync(all.data(), dAll, sizeof(long long) * 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    ok = ok && MGCG_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(dAll);
+    if (!ok) { delete h; return nullptr; }
+    h->sendBegin.assign(n, 0); h->sendCount.assign(n, 0); h->recvBegin.assign(n, 0); h->recvCount.assign(n, 0);
+    auto clip = [](long long lo, long long hi, long long a, long long b, long long& begin, long long& cnt) {
+        const long long s = lo > a ? lo : a, e = hi < b ? hi : b;
+        begin = s; cnt = e > s ? e - s : 0;
+    };
+    for (int q = 0; q < n; ++q) {
+        if (q == c->rank) continue;
+        const long long qOff = all[4 * q], qCnt = all[4 * q + 1], qMin = all[4 * q + 2], qMax = all[4 * q + 3];
+        // what I need from q: q's rows inside [minJ, maxJ]
+        if (countLocal > 0 && maxJ >= minJ) clip(minJ, (long long)maxJ + 1, qOff, qOff + qCnt, h->recvBegin[q], h->recvCount[q]);
+        // what q needs from me: my rows inside [qMin, qMax]
+        if (qCnt > 0 && qMax >= qMin) clip(qMin, qMax + 1, offset, offset + countLocal, h->sendBegin[q], h->sendCount[q]);
+    }
+    (void)count;
+    return h;
+}
+
+void halo_plan_destroy(HaloPlan* h) { delete h; }
+
+bool halo_exchange(MgcgComm* c, HaloPlan* h, double* p, hipStream_t s)
+{
+    if (!c || c->nranks == 1 || !h) return true;
+    Rccl* r = rccl();
+    if (!r) return false;
+    bool ok = nccl_ok(r->GroupStart(), "ncclGroupStart");
+    for (int q = 0; ok && q < h->nranks; ++q) {
+        if (h->sendCount[q] > 0) ok = ok && nccl_ok(r->Send(p + h->sendBegin[q], (size_t)h->sendCount[q], NCCL_DOUBLE, q, c->comm, s), "ncclSend");
+        if (h->recvCount[q] > 0) ok = ok && nccl_ok(r->Recv(p + h->recvBegin[q], (size_t)h->recvCount[q], NCCL_DOUBLE, q, c->comm, s), "ncclRecv");
+    }
+    ok = nccl_ok(r->GroupEnd(), "ncclGroupEnd") && ok;
+    return ok;
+}
+
+} // namespace mgcg
+
+using namespace mgcg;
+
+extern "C" {
+
+int MgcgCommGetUniqueId(void* id128)
+{
+    Rccl* r = rccl();
+    if (!r || !id128) return -1;
+    NcclUniqueId id;
+    if (!nccl_ok(r->GetUniqueId(&id), "ncclGetUniqueId")) return -1;
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+MgcgComm* MgcgCommInitRank(const void* id128, int nranks, int rank)
+{
+    DeviceState* d = device_state();
+    if (!d) return nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) { set_error("MgcgCommInitRank: bad rank %d of %d", rank, nranks); return nullptr; }
+    MgcgComm* c = new MgcgComm();
+    c->nranks = nranks; c->rank = rank; c->stream = d->stream;
+    if (!MGCG_HIP(hipMalloc((void**)&c->scratch, 8 * sizeof(double)))) { delete c; return nullptr; }
+    if (nranks > 1) {
+        Rccl* r = rccl();
+        if (!r || !id128) { if (r) set_error("MgcgCommInitRank: null unique id"); (void)hipFree(c->scratch); delete c; return nullptr; }
+        NcclUniqueId id;
+        memcpy(&id, id128, sizeof(id));
+        if (!nccl_ok(r->CommInitRank(&c->comm, nranks, id, rank), "ncclCommInitRank")) { (void)hipFree(c->scratch); delete c; return nullptr; }
+    }
+    return c;
+}
+
+void MgcgCommDestroy(MgcgComm* c)
+{
+    if (!c) return;
+    if (c->comm) { Rccl* r = rccl(); if (r && r->CommDestroy) (void)r->CommDestroy(c->comm); }
+    if (c->scratch) (void)hipFree(c->scratch);
+    delete c;
+}
+
+int MgcgCommRank(const MgcgComm* c) { return c ? c->rank : 0; }
+int MgcgCommSize(const MgcgComm* c) { return c ? c->nranks : 1; }
+
+double MgcgCommAllReduceSum(MgcgComm* c, double value)
+{
+    if (!c) return value;
+    if (!device_state()) return NAN;
+    bool ok = MGCG_HIP(hipMemcpyAsync(c->scratch, &value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    ok = ok && MGCG_HIP(hipStreamSynchronize(c->stream));
+    ok = ok && comm_allreduce_sum(c, c->scratch, 1, c->stream);
+    double out = NAN;
+    ok = ok && MGCG_HIP(hipMemcpyAsync(&out, c->scratch, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    ok = ok && MGCG_HIP(hipStreamSynchronize(c->stream));
+    return ok ? out : NAN;
+}
+
+} // extern "C"

@@ -1,0 +1,197 @@
+// Internal declarations shared by the translation units of libMgcgGpu.so.
+// gfx950 (MI355X, CDNA4) only: 64-wide wavefronts, 256 CUs in 8 XCDs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include <cmath>
+#include <mutex>
+#include <string>
+#include <vector>
+
+// Only the C ABI is exported from the shared object (-fvisibility=hidden for everything else).
+#pragma GCC visibility push(default)
+#include "../../include/MgcgGpu.h"
+#pragma GCC visibility pop
+
+namespace mgcg {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;          // threads per workgroup for every streaming kernel
+constexpr int kNumXcd = 8;
+constexpr int kNumCu = 256;
+constexpr int kMaxGrid = kNumCu * 8; // 8 resident 256-thread workgroups per CU (32 waves/CU)
+constexpr int kMaxDevices = 64;
+
+// ---------------------------------------------------------------- errors
+void set_error(const char* fmt, ...);
+bool hip_ok(hipError_t e, const char* what, const char* file, int line);
+#define MGCG_HIP(call) ::mgcg::hip_ok((call), #call, __FILE__, __LINE__)
+
+// ---------------------------------------------------------------- per-device state
+// One stream per device, shared by every handle created on that device, so calls made through
+// different handles stay ordered exactly as they are on the reference's default stream.
+struct DeviceState {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    int numCu = kNumCu;
+};
+DeviceState* device_state();   // for the calling thread's current device (lazily created)
+int current_device();
+
+// Device scalars of one CG run (lives in the handle's workspace).
+struct CgScalars {
+    double rr;        // r.r  (or r.z for the preconditioned loop) of the previous iteration
+    double pAp;
+    double rrNew;     // r.r of this iteration (stop test)
+    double rzNew;     // r.z of this iteration (preconditioned loop)
+    double residual;
+    double rr0;
+    double nrmInf;
+    double beta;
+    double alpha;
+    int iteration;    // index of the iteration being executed
+    int done;         // set by the finalisation kernel; every later kernel exits at once
+    int status;
+    int pad;
+};
+
+// What the host polls (pinned, device-written).
+struct HostMirror {
+    volatile double residual;
+    volatile int iteration;
+    volatile int done;
+    volatile int status;
+    volatile int pad;
+};
+
+// ---------------------------------------------------------------- handles
+struct Workspace {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    double* partials = nullptr;      // kMaxGrid * 2 doubles: per-workgroup partial sums
+    CgScalars* scalars = nullptr;    // device
+    HostMirror* mirror = nullptr;    // pinned host, device-visible
+    double* hostScalar = nullptr;    // pinned host, 4 doubles (Dot results)
+    double* trace = nullptr;         // device residual trace
+    int traceCap = 0;
+    bool init();
+    void destroy();
+    bool ensure_trace(int cap);
+};
+
+} // namespace mgcg
+
+struct MgcgBlas   { mgcg::Workspace ws; };
+namespace mgcg {
+// Optional per-launch timing of the SpMV inside the CG loop (bench.py's roofline figure).
+struct SpmvProfile {
+    bool enabled = false;
+    std::vector<hipEvent_t> start, stop;
+    int used = 0;
+};
+}
+struct MgcgSparse {
+    mgcg::Workspace ws;
+    mgcg::SpmvProfile prof;
+    int kernel = 0;          // 0 auto
+    int rowsPerBlock = 256;
+    int flags = 0;           // bit0 nt loads, bit1 xcd-contiguous mapping
+    int gridBlocks = 0;
+};
+struct MgcgMatDescr { int type = 0; int base = 0; };
+struct Vector    { double* data = nullptr; long long size = 0; int device = -1; };
+struct VectorInt { int* data = nullptr;    long long size = 0; int device = -1; };
+
+namespace mgcg {
+
+// ---------------------------------------------------------------- SpMV
+enum SpmvEpilogue {
+    EPI_AXPBY = 0,   // y = alpha*(A x) + beta*y
+    EPI_DOT = 1,     // y = A x ; partial += w_i * y_i
+    EPI_RESIDUAL = 2,// y = b - A x
+    EPI_JACOBI = 3,  // y = xo + omega*(dinv*(b - A x))
+    EPI_RESIDUAL_DOT = 4 // y = b - A x ; partial += y_i*y_i
+};
+
+struct SpmvArgs {
+    const double* elements;
+    const int* rowOffsets;
+    const int* columnIndeces;
+    const double* x;
+    double* y;
+    int elementsCount;
+    int rowCount;
+    int columnCount;
+    double alpha, beta;      // EPI_AXPBY
+    const double* w;         // EPI_DOT: weights (own slice of x); EPI_JACOBI: xo (own slice of x)
+    const double* b;         // EPI_RESIDUAL / EPI_JACOBI
+    const double* dinv;      // EPI_JACOBI
+    double omega;            // EPI_JACOBI
+    double* partials;        // EPI_DOT / EPI_RESIDUAL_DOT: one double per workgroup
+    const int* doneFlag;     // optional: exit at once when *doneFlag != 0
+};
+
+struct SpmvConfig { int kernel = 0; int rowsPerBlock = 256; int flags = 0; int gridBlocks = 0; };
+
+// Launches the SpMV; returns the number of partials written (grid size) for dot epilogues.
+int launch_spmv(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg);
+
+// ---------------------------------------------------------------- BLAS-1 and fused CG updates
+void launch_axpy(hipStream_t s, double* y, const double* x, long long n, double alpha);
+void launch_scal(hipStream_t s, double* x, double alpha, long long n);
+void launch_xpay(hipStream_t s, double* y, const double* x, long long n, double beta);
+void launch_copy(hipStream_t s, double* y, const double* x, long long n);
+void launch_fill(hipStream_t s, double* y, double v, long long n);
+// partials[0..grid) = per-workgroup partial of sum x_i*y_i ; returns grid
+int  launch_dot_partials(hipStream_t s, const double* x, const double* y, long long n, double* partials);
+int  launch_nrminf_partials(hipStream_t s, const double* x, long long n, double* partials);
+// out[0] = sum(partials[0..n)) in a fixed order (mode 0) or max (mode 1)
+void launch_reduce(hipStream_t s, const double* partials, int n, double* out, int mode);
+
+// p = r ; partial r.r      (CG init)
+int  launch_copy_dot(hipStream_t s, double* p, const double* r, long long n, double* partials, const int* done);
+// alpha = sc->rr / sc->pAp ; x += alpha p ; r -= alpha Ap ; partial r.r (and max|r| in partials2 when wantInf)
+int  launch_update_xr(hipStream_t s, const CgScalars* sc, double* x, double* r, const double* p, const double* Ap,
+                      long long n, double* partials, double* partialsInf);
+// p = z + beta p with beta = sc->beta ; skipped when sc->done
+void launch_update_p(hipStream_t s, const CgScalars* sc, double* p, const double* z, long long n);
+
+struct FinalizeArgs {
+    CgScalars* sc;
+    HostMirror* mirror;
+    double* trace; int traceCap;
+    double tol; int minIt; int maxIt; int rule;
+    int preconditioned;     // beta = rzNew/rr(rz) computed by finalize_precond instead
+};
+// Single-workgroup kernels that turn partial sums into the loop's scalars.
+void launch_reduce_to(hipStream_t s, const double* partials, int n, double* dst, const int* done);          // dst = sum
+void launch_finalize(hipStream_t s, const double* partials, const double* partialsInf, int n, bool reduceFirst, const FinalizeArgs& f);
+void launch_finalize_precond(hipStream_t s, const double* partials, int n, bool reduceFirst, CgScalars* sc);  // rzNew -> beta, rr
+void launch_init_scalars(hipStream_t s, const double* partials, int n, bool reduceFirst, CgScalars* sc, HostMirror* mirror, int rule);
+
+// ---------------------------------------------------------------- multigrid kernels
+void launch_jacobi_first(hipStream_t s, long long n, double omega, const double* dinv, const double* b, double* x, const int* done);
+void launch_restrict(hipStream_t s, int nx, int ny, int nz, const double* r, double* bc, const int* done);
+void launch_prolong_add(hipStream_t s, int nx, int ny, int nz, double* x, const double* e, const int* done);
+void launch_extract_dinv(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces,
+                         long long n, long long rowBase, double* dinv);
+// Galerkin: count pass (elementsC == nullptr) writes per-row counts to countsC[I]; fill pass writes entries.
+void launch_galerkin(hipStream_t s, int nx, int ny, int nz, const double* elements, const int* rowOffsets, const int* columnIndeces,
+                     double sigma, const int* rowOffsetsC, int* countsC, double* elementsC, int* columnIndecesC, int* errFlag);
+void launch_poisson(hipStream_t s, int nx, int ny, int nz, int zBegin, int zEnd, double* elements, int* rowOffsets, int* columnIndeces);
+void launch_rebase(hipStream_t s, int* rowOffsets, long long n, int base);
+long long poisson_nnz_host(int nx, int ny, int nz, int zBegin, int zEnd);
+void launch_minmax_int(hipStream_t s, const int* v, long long n, int* out2 /* device int[2] */);
+
+// ---------------------------------------------------------------- RCCL (dlopen'ed)
+struct CommImpl;
+bool comm_allreduce_sum(MgcgComm* c, double* devPtr, int count, hipStream_t s);
+struct HaloPlan;  // per-peer contiguous send/recv ranges of p
+HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long long countLocal, int minJ, int maxJ);
+void halo_plan_destroy(HaloPlan* h);
+bool halo_exchange(MgcgComm* c, HaloPlan* h, double* p, hipStream_t s);
+
+} // namespace mgcg

@@ -1,0 +1,370 @@
+// BLAS-1 and fused CG vector updates for gfx950.
+// Replaces cublasD{axpy,dot,scal,copy}_v2 (Mgcg/cuBlas/MgcgGpu/Mgcg.cu:22-54) and the OpenCL
+// AddVectorVector / MultiplyVectorVector / ReductionSum / ReductionMaxAbsolute kernels
+// (Mgcg/HandmadeCL/MgcgCL/Mgcg.cl:15-159).
+//
+// All kernels are grid-stride over a fixed grid (<= 8 workgroups of 256 threads per CU) with
+// 16-byte loads when the operands allow it.  Element-wise arithmetic keeps the reference CPU
+// twin's operation order (Mgcg/cuBlas/Mgcg/LongVector.cs:41-51: answer = left + a*right, product
+// rounded first; the library is built with -ffp-contract=off), so x, r and p updates are
+// bit-identical to it.  Reductions: per-lane partial -> __shfl_down over the 64-lane wavefront ->
+// LDS across the 4 waves -> one partial per workgroup -> a single-workgroup second stage that adds
+// the partials in a fixed order.  No atomics: results are run-to-run reproducible.
+#include "common.hpp"
+
+namespace mgcg {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double wave_sum_b(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max_b(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { double o = __shfl_down(v, off, 64); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ double block_sum(double v, double* s_red)
+{
+    v = wave_sum_b(v);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+__device__ __forceinline__ double block_max(double v, double* s_red)
+{
+    v = wave_max_b(v);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double a = s_red[0] > s_red[1] ? s_red[0] : s_red[1];
+    double b = s_red[2] > s_red[3] ? s_red[2] : s_red[3];
+    return a > b ? a : b;
+}
+
+static inline int grid_for(long long n, int perThread)
+{
+    long long blocks = (n + (long long)kBlock * perThread - 1) / ((long long)kBlock * perThread);
+    if (blocks > kMaxGrid) blocks = kMaxGrid;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// Element-wise grid-stride driver.  V2: f2(i) handles elements i, i+1 with 16-byte accesses and the
+// odd tail goes to f1 on one thread; otherwise f1(i) per element.
+template <bool V2, typename F2, typename F1>
+__device__ __forceinline__ void grid_stride(long long n, F2 f2, F1 f1)
+{
+    const long long stride = (long long)gridDim.x * kBlock;
+    if constexpr (V2) {
+        const long long n2 = n >> 1;
+        for (long long i2 = (long long)blockIdx.x * kBlock + threadIdx.x; i2 < n2; i2 += stride) f2(i2 * 2);
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) f1(n - 1);
+    } else {
+        for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) f1(i);
+    }
+}
+
+// ------------------------------------------------------------------ axpy: y = y + alpha*x
+template <bool V2>
+__global__ __launch_bounds__(kBlock) void axpy_kernel(double* __restrict__ y, const double* __restrict__ x, long long n, double alpha)
+{
+    grid_stride<V2>(n,
+        [&](long long i) { d2 xv = *(const d2*)(x + i); d2 yv = *(d2*)(y + i); d2 t; t.x = alpha * xv.x; t.y = alpha * xv.y; yv.x = yv.x + t.x; yv.y = yv.y + t.y; *(d2*)(y + i) = yv; },
+        [&](long long i) { double t = alpha * x[i]; y[i] = y[i] + t; });
+}
+void launch_axpy(hipStream_t s, double* y, const double* x, long long n, double alpha)
+{
+    if (n <= 0) return;
+    if (al16(y) && al16(x)) hipLaunchKernelGGL(axpy_kernel<true>, dim3(grid_for(n, 2)), dim3(kBlock), 0, s, y, x, n, alpha);
+    else hipLaunchKernelGGL(axpy_kernel<false>, dim3(grid_for(n, 1)), dim3(kBlock), 0, s, y, x, n, alpha);
+}
+
+// ------------------------------------------------------------------ scal: x = alpha*x
+template <bool V2>
+__global__ __launch_bounds__(kBlock) void scal_kernel(double* __restrict__ x, long long n, double alpha)
+{
+    grid_stride<V2>(n,
+        [&](long long i) { d2 v = *(d2*)(x + i); v.x = alpha * v.x; v.y = alpha * v.y; *(d2*)(x + i) = v; },
+        [&](long long i) { x[i] = alpha * x[i]; });
+}
+void launch_scal(hipStream_t s, double* x, double alpha, long long n)
+{
+    if (n <= 0) return;
+    if (al16(x)) hipLaunchKernelGGL(scal_kernel<true>, dim3(grid_for(n, 2)), dim3(kBlock), 0, s, x, n, alpha);
+    else hipLaunchKernelGGL(scal_kernel<false>, dim3(grid_for(n, 1)), dim3(kBlock), 0, s, x, n, alpha);
+}
+
+// ------------------------------------------------------------------ xpay: y = x + beta*y   (Scal+Axpy of Mgcg.cu:197,265 fused)
+template <bool V2>
+__global__ __launch_bounds__(kBlock) void xpay_kernel(double* __restrict__ y, const double* __restrict__ x, long long n, double beta)
+{
+    grid_stride<V2>(n,
+        [&](long long i) { d2 xv = *(const d2*)(x + i); d2 yv = *(d2*)(y + i); d2 t; t.x = beta * yv.x; t.y = beta * yv.y; yv.x = xv.x + t.x; yv.y = xv.y + t.y; *(d2*)(y + i) = yv; },
+        [&](long long i) { double t = beta * y[i]; y[i] = x[i] + t; });
+}
+void launch_xpay(hipStream_t s, double* y, const double* x, long long n, double beta)
+{
+    if (n <= 0) return;
+    if (al16(y) && al16(x)) hipLaunchKernelGGL(xpay_kernel<true>, dim3(grid_for(n, 2)), dim3(kBlock), 0, s, y, x, n, beta);
+    else hipLaunchKernelGGL(xpay_kernel<false>, dim3(grid_for(n, 1)), dim3(kBlock), 0, s, y, x, n, beta);
+}
+
+// ------------------------------------------------------------------ copy / fill
+__global__ __launch_bounds__(kBlock) void fill_kernel(double* __restrict__ y, double v, long long n)
+{
+    grid_stride<false>(n, [&](long long) {}, [&](long long i) { y[i] = v; });
+}
+void launch_copy(hipStream_t s, double* y, const double* x, long long n)
+{
+    if (n <= 0) return;
+    (void)hipMemcpyAsync(y, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s);
+}
+void launch_fill(hipStream_t s, double* y, double v, long long n)
+{
+    if (n <= 0) return;
+    if (v == 0.0) { (void)hipMemsetAsync(y, 0, (size_t)n * sizeof(double), s); return; }
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 1)), dim3(kBlock), 0, s, y, v, n);
+}
+
+// ------------------------------------------------------------------ dot partials
+template <bool V2>
+__global__ __launch_bounds__(kBlock) void dot_kernel(const double* __restrict__ x, const double* __restrict__ y, long long n, double* __restrict__ partials)
+{
+    __shared__ double s_red[4];
+    double acc = 0.0;
+    grid_stride<V2>(n,
+        [&](long long i) { d2 xv = *(const d2*)(x + i); d2 yv = *(const d2*)(y + i); double t0 = xv.x * yv.x; double t1 = xv.y * yv.y; acc += t0; acc += t1; },
+        [&](long long i) { double t = x[i] * y[i]; acc += t; });
+    const double t = block_sum(acc, s_red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+int launch_dot_partials(hipStream_t s, const double* x, const double* y, long long n, double* partials)
+{
+    const bool v2 = al16(x) && al16(y);
+    const int grid = grid_for(n, v2 ? 4 : 2);
+    if (v2) hipLaunchKernelGGL(dot_kernel<true>, dim3(grid), dim3(kBlock), 0, s, x, y, n, partials);
+    else hipLaunchKernelGGL(dot_kernel<false>, dim3(grid), dim3(kBlock), 0, s, x, y, n, partials);
+    return grid;
+}
+
+__global__ __launch_bounds__(kBlock) void nrminf_kernel(const double* __restrict__ x, long long n, double* __restrict__ partials)
+{
+    __shared__ double s_red[4];
+    double m = 0.0;
+    grid_stride<false>(n, [&](long long) {}, [&](long long i) { double a = fabs(x[i]); m = a > m ? a : m; });
+    const double t = block_max(m, s_red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+int launch_nrminf_partials(hipStream_t s, const double* x, long long n, double* partials)
+{
+    const int grid = grid_for(n, 2);
+    hipLaunchKernelGGL(nrminf_kernel, dim3(grid), dim3(kBlock), 0, s, x, n, partials);
+    return grid;
+}
+
+// ------------------------------------------------------------------ second stage (one workgroup)
+// Fixed-order sum (or max) of n partials; result valid in thread 0.
+__device__ __forceinline__ double reduce_partials_block(const double* __restrict__ partials, int n, double* s_red, int mode)
+{
+    double acc = 0.0;
+    if (mode == 0) { for (int i = threadIdx.x; i < n; i += kBlock) acc += partials[i]; return block_sum(acc, s_red); }
+    for (int i = threadIdx.x; i < n; i += kBlock) { double a = partials[i]; acc = a > acc ? a : acc; }
+    return block_max(acc, s_red);
+}
+
+__global__ __launch_bounds__(kBlock) void reduce_kernel(const double* __restrict__ partials, int n, double* __restrict__ out, int mode, const int* done)
+{
+    __shared__ double s_red[4];
+    if (done != nullptr && *done != 0) return;
+    const double t = reduce_partials_block(partials, n, s_red, mode);
+    if (threadIdx.x == 0) out[0] = t;
+}
+void launch_reduce(hipStream_t s, const double* partials, int n, double* out, int mode)
+{
+    hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(kBlock), 0, s, partials, n, out, mode, (const int*)nullptr);
+}
+void launch_reduce_to(hipStream_t s, const double* partials, int n, double* dst, const int* done)
+{
+    hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(kBlock), 0, s, partials, n, dst, 0, done);
+}
+
+// ------------------------------------------------------------------ fused CG pieces
+// p = r ; partial r.r
+template <bool V2>
+__global__ __launch_bounds__(kBlock) void copy_dot_kernel(double* __restrict__ p, const double* __restrict__ r, long long n, double* __restrict__ partials, const int* done)
+{
+    __shared__ double s_red[4];
+    if (done != nullptr && *done != 0) return;
+    double acc = 0.0;
+    grid_stride<V2>(n,
+        [&](long long i) { d2 rv = *(const d2*)(r + i); *(d2*)(p + i) = rv; double t0 = rv.x * rv.x; double t1 = rv.y * rv.y; acc += t0; acc += t1; },
+        [&](long long i) { double rv = r[i]; p[i] = rv; double t = rv * rv; acc += t; });
+    const double t = block_sum(acc, s_red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+int launch_copy_dot(hipStream_t s, double* p, const double* r, long long n, double* partials, const int* done)
+{
+    const bool v2 = al16(p) && al16(r);
+    const int grid = grid_for(n, v2 ? 4 : 2);
+    if (v2) hipLaunchKernelGGL(copy_dot_kernel<true>, dim3(grid), dim3(kBlock), 0, s, p, r, n, partials, done);
+    else hipLaunchKernelGGL(copy_dot_kernel<false>, dim3(grid), dim3(kBlock), 0, s, p, r, n, partials, done);
+    return grid;
+}
+
+// alpha = rr / pAp ; x = x + alpha*p ; r = r + (-alpha)*Ap ; partial r.r [, partial max|r|]
+// (ConjugateGradientCpu.cs:71-74 in one pass over x, p, r, Ap)
+template <bool V2, bool INF>
+__global__ __launch_bounds__(kBlock) void update_xr_kernel(const CgScalars* __restrict__ sc, double* __restrict__ x, double* __restrict__ r,
+                                                           const double* __restrict__ p, const double* __restrict__ Ap, long long n,
+                                                           double* __restrict__ partials, double* __restrict__ partialsInf)
+{
+    __shared__ double s_red[4];
+    __shared__ double s_red2[4];
+    if (sc->done != 0) return;
+    const double alpha = sc->rr / sc->pAp;
+    const double malpha = -alpha;
+    double acc = 0.0, mx = 0.0;
+    grid_stride<V2>(n,
+        [&](long long i) {
+            d2 pv = *(const d2*)(p + i); d2 xv = *(d2*)(x + i); d2 av = *(const d2*)(Ap + i); d2 rv = *(d2*)(r + i);
+            double t0 = alpha * pv.x; double t1 = alpha * pv.y; xv.x = xv.x + t0; xv.y = xv.y + t1; *(d2*)(x + i) = xv;
+            double u0 = malpha * av.x; double u1 = malpha * av.y; rv.x = rv.x + u0; rv.y = rv.y + u1; *(d2*)(r + i) = rv;
+            double q0 = rv.x * rv.x; double q1 = rv.y * rv.y; acc += q0; acc += q1;
+            if (INF) { double a0 = fabs(rv.x); double a1 = fabs(rv.y); mx = a0 > mx ? a0 : mx; mx = a1 > mx ? a1 : mx; }
+        },
+        [&](long long i) {
+            double t = alpha * p[i]; x[i] = x[i] + t;
+            double u = malpha * Ap[i]; double rv = r[i] + u; r[i] = rv;
+            double q = rv * rv; acc += q;
+            if (INF) { double a0 = fabs(rv); mx = a0 > mx ? a0 : mx; }
+        });
+    const double t = block_sum(acc, s_red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    if (INF) {
+        const double m = block_max(mx, s_red2);
+        if (threadIdx.x == 0) partialsInf[blockIdx.x] = m;
+    }
+}
+int launch_update_xr(hipStream_t s, const CgScalars* sc, double* x, double* r, const double* p, const double* Ap,
+                     long long n, double* partials, double* partialsInf)
+{
+    const bool v2 = al16(x) && al16(r) && al16(p) && al16(Ap);
+    const int grid = grid_for(n, v2 ? 4 : 2);
+    const bool inf = partialsInf != nullptr;
+#define GO(V, I) hipLaunchKernelGGL((update_xr_kernel<V, I>), dim3(grid), dim3(kBlock), 0, s, sc, x, r, p, Ap, n, partials, partialsInf)
+    if (v2) { if (inf) GO(true, true); else GO(true, false); }
+    else { if (inf) GO(false, true); else GO(false, false); }
+#undef GO
+    return grid;
+}
+
+// p = z + beta*p   (ConjugateGradientCpu.cs:94 with z = r; the preconditioned loop passes z = M^-1 r)
+template <bool V2>
+__global__ __launch_bounds__(kBlock) void update_p_kernel(const CgScalars* __restrict__ sc, double* __restrict__ p, const double* __restrict__ z, long long n)
+{
+    if (sc->done != 0) return;
+    const double beta = sc->beta;
+    grid_stride<V2>(n,
+        [&](long long i) { d2 zv = *(const d2*)(z + i); d2 pv = *(d2*)(p + i); double t0 = beta * pv.x; double t1 = beta * pv.y; pv.x = zv.x + t0; pv.y = zv.y + t1; *(d2*)(p + i) = pv; },
+        [&](long long i) { double t = beta * p[i]; p[i] = z[i] + t; });
+}
+void launch_update_p(hipStream_t s, const CgScalars* sc, double* p, const double* z, long long n)
+{
+    if (n <= 0) return;
+    const bool v2 = al16(p) && al16(z);
+    if (v2) hipLaunchKernelGGL(update_p_kernel<true>, dim3(grid_for(n, 2)), dim3(kBlock), 0, s, sc, p, z, n);
+    else hipLaunchKernelGGL(update_p_kernel<false>, dim3(grid_for(n, 1)), dim3(kBlock), 0, s, sc, p, z, n);
+}
+
+// ------------------------------------------------------------------ scalar bookkeeping (one workgroup)
+__global__ __launch_bounds__(kBlock) void init_scalars_kernel(const double* __restrict__ partials, int n, int reduceFirst,
+                                                              CgScalars* sc, HostMirror* mirror, int rule)
+{
+    __shared__ double s_red[4];
+    double rr = 0.0;
+    if (reduceFirst) rr = reduce_partials_block(partials, n, s_red, 0);
+    if (threadIdx.x == 0) {
+        if (!reduceFirst) rr = sc->rr;
+        sc->rr = rr; sc->rr0 = rr; sc->pAp = 0; sc->rrNew = 0; sc->rzNew = 0; sc->residual = 0; sc->nrmInf = 0;
+        sc->beta = 0; sc->alpha = 0; sc->iteration = 0; sc->done = 0; sc->status = 0;
+        (void)rule;
+        mirror->residual = 0; mirror->iteration = 0; mirror->status = 0; mirror->done = 0;
+    }
+}
+void launch_init_scalars(hipStream_t s, const double* partials, int n, bool reduceFirst, CgScalars* sc, HostMirror* mirror, int rule)
+{
+    hipLaunchKernelGGL(init_scalars_kernel, dim3(1), dim3(kBlock), 0, s, partials, n, reduceFirst ? 1 : 0, sc, mirror, rule);
+}
+
+// Residual, stop test (the five rules of SURVEY.md 3.5), beta and the rr hand-over.
+__global__ __launch_bounds__(kBlock) void finalize_kernel(const double* __restrict__ partials, const double* __restrict__ partialsInf, int n,
+                                                          int reduceFirst, FinalizeArgs f)
+{
+    __shared__ double s_red[4];
+    __shared__ double s_red2[4];
+    CgScalars* sc = f.sc;
+    if (sc->done != 0) return;
+    double rrNew = 0.0, inf = 0.0;
+    if (reduceFirst) {
+        rrNew = reduce_partials_block(partials, n, s_red, 0);
+        if (partialsInf != nullptr) inf = reduce_partials_block(partialsInf, n, s_red2, 1);
+    }
+    if (threadIdx.x != 0) return;
+    if (!reduceFirst) { rrNew = sc->rrNew; inf = sc->nrmInf; }
+    const int it = sc->iteration;
+    double res = sqrt(rrNew);
+    if (f.rule == MGCG_RULE_HANDMADECL) res = inf;
+    double shown = res;
+    bool converged;
+    switch (f.rule) {
+    case MGCG_RULE_NATIVE:   converged = (f.minIt <= it) && (res < f.tol); break;
+    case MGCG_RULE_SIMPLE:   converged = (f.minIt < it) && (res < f.tol); break;
+    case MGCG_RULE_VIENNACL: shown = sqrt(rrNew / sc->rr0); converged = (f.minIt < it) && (rrNew / sc->rr0 < f.tol * f.tol); break;
+    default:                 converged = (it >= f.minIt) && (it <= f.maxIt) && (res < f.tol); break;  // ConjugateGradient.cs:56-79
+    }
+    int status = MGCG_OK;
+    bool stop = converged;
+    if (!stop && it >= f.minIt && it > f.maxIt) { stop = true; status = MGCG_MAXIT_EXCEEDED; }
+    if (!stop && !(res == res && fabs(res) <= 1.79e308)) { stop = true; status = MGCG_NONFINITE; }
+    if (f.trace != nullptr && it < f.traceCap) f.trace[it] = shown;
+    sc->rrNew = rrNew; sc->residual = res; sc->nrmInf = inf;
+    if (stop) {
+        sc->done = 1; sc->status = status;
+        f.mirror->residual = res; f.mirror->iteration = it; f.mirror->status = status;
+        __threadfence_system();
+        f.mirror->done = 1;
+    } else {
+        if (!f.preconditioned) { sc->beta = rrNew / sc->rr; sc->rr = rrNew; }
+        sc->iteration = it + 1;
+        f.mirror->residual = res; f.mirror->iteration = it + 1;
+    }
+}
+void launch_finalize(hipStream_t s, const double* partials, const double* partialsInf, int n, bool reduceFirst, const FinalizeArgs& f)
+{
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, s, partials, partialsInf, n, reduceFirst ? 1 : 0, f);
+}
+
+// Preconditioned loop: rzNew = r.z ; beta = rzNew / rz ; rz = rzNew   (rz lives in sc->rr)
+__global__ __launch_bounds__(kBlock) void finalize_precond_kernel(const double* __restrict__ partials, int n, int reduceFirst, CgScalars* sc)
+{
+    __shared__ double s_red[4];
+    if (sc->done != 0) return;
+    double rz = 0.0;
+    if (reduceFirst) rz = reduce_partials_block(partials, n, s_red, 0);
+    if (threadIdx.x != 0) return;
+    if (!reduceFirst) rz = sc->rzNew;
+    sc->rzNew = rz;
+    sc->beta = rz / sc->rr;
+    sc->rr = rz;
+}
+void launch_finalize_precond(hipStream_t s, const double* partials, int n, bool reduceFirst, CgScalars* sc)
+{
+    hipLaunchKernelGGL(finalize_precond_kernel, dim3(1), dim3(kBlock), 0, s, partials, n, reduceFirst ? 1 : 0, sc);
+}
+
+} // namespace mgcg

@@ -1,0 +1,247 @@
+// Multigrid transfer / set-up kernels and the device problem generator (gfx950).
+// The reference's "Mgcg" never implemented its multigrid; the algorithm is
+// defined in DESIGN.md section 5 and stated on the CPU in oracle/mg_oracle.c, whose arithmetic
+// order every kernel here reproduces (restriction adds the children in (z,y,x) order, etc.).
+// The smoother and residual passes are SpMV epilogues (kernels_spmv.hip: EPI_JACOBI, EPI_RESIDUAL).
+#include "common.hpp"
+
+namespace mgcg {
+
+static inline int grid1(long long n)
+{
+    long long b = (n + kBlock - 1) / kBlock;
+    if (b > kMaxGrid) b = kMaxGrid;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// x = omega * (dinv * b): a Jacobi sweep from a zero guess needs no SpMV.
+__global__ __launch_bounds__(kBlock) void jacobi_first_kernel(long long n, double omega, const double* __restrict__ dinv,
+                                                              const double* __restrict__ b, double* __restrict__ x, const int* done)
+{
+    if (done != nullptr && *done != 0) return;
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        double t = dinv[i] * b[i];
+        x[i] = omega * t;
+    }
+}
+void launch_jacobi_first(hipStream_t s, long long n, double omega, const double* dinv, const double* b, double* x, const int* done)
+{
+    hipLaunchKernelGGL(jacobi_first_kernel, dim3(grid1(n)), dim3(kBlock), 0, s, n, omega, dinv, b, x, done);
+}
+
+// bc[I] = sum of r over the children of I in (z,y,x) order.  One lane per coarse cell; the two
+// x-children are adjacent, so a wavefront reads whole 1 KiB spans of each fine line.
+__global__ __launch_bounds__(kBlock) void restrict_kernel(int nx, int ny, int nz, const double* __restrict__ r, double* __restrict__ bc, const int* done)
+{
+    if (done != nullptr && *done != 0) return;
+    const int cx = nx > 1 ? 2 : 1, cy = ny > 1 ? 2 : 1, cz = nz > 1 ? 2 : 1;
+    const int NX = nx / cx, NY = ny / cy, NZ = nz / cz;
+    const long long NC = (long long)NX * NY * NZ;
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long I = (long long)blockIdx.x * kBlock + threadIdx.x; I < NC; I += stride) {
+        const int X = (int)(I % NX), Y = (int)((I / NX) % NY), Z = (int)(I / ((long long)NX * NY));
+        double sum = 0.0;
+        for (int dz = 0; dz < cz; ++dz)
+            for (int dy = 0; dy < cy; ++dy) {
+                const long long base = ((long long)(Z * cz + dz) * ny + (Y * cy + dy)) * nx + (long long)X * cx;
+                for (int dx = 0; dx < cx; ++dx) sum += r[base + dx];
+            }
+        bc[I] = sum;
+    }
+}
+void launch_restrict(hipStream_t s, int nx, int ny, int nz, const double* r, double* bc, const int* done)
+{
+    const long long NC = (long long)(nx > 1 ? nx / 2 : 1) * (ny > 1 ? ny / 2 : 1) * (nz > 1 ? nz / 2 : 1);
+    hipLaunchKernelGGL(restrict_kernel, dim3(grid1(NC)), dim3(kBlock), 0, s, nx, ny, nz, r, bc, done);
+}
+
+// x[i] += e[parent(i)]
+__global__ __launch_bounds__(kBlock) void prolong_add_kernel(int nx, int ny, int nz, double* __restrict__ x, const double* __restrict__ e, const int* done)
+{
+    if (done != nullptr && *done != 0) return;
+    const int cx = nx > 1 ? 2 : 1, cy = ny > 1 ? 2 : 1, cz = nz > 1 ? 2 : 1;
+    const int NX = nx / cx, NY = ny / cy;
+    const long long N = (long long)nx * ny * nz;
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < N; i += stride) {
+        const int xx = (int)(i % nx), yy = (int)((i / nx) % ny), zz = (int)(i / ((long long)nx * ny));
+        x[i] += e[((long long)(zz / cz) * NY + (yy / cy)) * NX + (xx / cx)];
+    }
+}
+void launch_prolong_add(hipStream_t s, int nx, int ny, int nz, double* x, const double* e, const int* done)
+{
+    hipLaunchKernelGGL(prolong_add_kernel, dim3(grid1((long long)nx * ny * nz)), dim3(kBlock), 0, s, nx, ny, nz, x, e, done);
+}
+
+// dinv[i] = 1 / (first stored entry of local row i whose column is rowBase + i)
+__global__ __launch_bounds__(kBlock) void extract_dinv_kernel(const double* __restrict__ elements, const int* __restrict__ rowOffsets,
+                                                              const int* __restrict__ columnIndeces, long long n, long long rowBase, double* __restrict__ dinv)
+{
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        double d = 0.0;
+        for (int k = rowOffsets[i]; k < rowOffsets[i + 1]; ++k)
+            if (columnIndeces[k] == rowBase + i) { d = elements[k]; break; }
+        dinv[i] = 1.0 / d;
+    }
+}
+void launch_extract_dinv(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces,
+                         long long n, long long rowBase, double* dinv)
+{
+    hipLaunchKernelGGL(extract_dinv_kernel, dim3(grid1(n)), dim3(kBlock), 0, s, elements, rowOffsets, columnIndeces, n, rowBase, dinv);
+}
+
+// sigma * P^T A P on the 27-slot neighbourhood, one lane per coarse row, same accumulation order as
+// oracle_mg_galerkin.  elementsC == nullptr: count pass (countsC[I] = touched slots).
+__global__ __launch_bounds__(kBlock) void galerkin_kernel(int nx, int ny, int nz, const double* __restrict__ elements, const int* __restrict__ rowOffsets,
+                                                          const int* __restrict__ columnIndeces, double sigma, const int* __restrict__ rowOffsetsC,
+                                                          int* __restrict__ countsC, double* __restrict__ elementsC, int* __restrict__ columnIndecesC, int* errFlag)
+{
+    const int cx = nx > 1 ? 2 : 1, cy = ny > 1 ? 2 : 1, cz = nz > 1 ? 2 : 1;
+    const int NX = nx / cx, NY = ny / cy, NZ = nz / cz;
+    const long long NC = (long long)NX * NY * NZ;
+    const long long sxy = (long long)nx * ny;
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long I = (long long)blockIdx.x * kBlock + threadIdx.x; I < NC; I += stride) {
+        const int X = (int)(I % NX), Y = (int)((I / NX) % NY), Z = (int)(I / ((long long)NX * NY));
+        double acc[27];
+        unsigned touched = 0u;
+#pragma unroll
+        for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+        for (int dz = 0; dz < cz; ++dz)
+            for (int dy = 0; dy < cy; ++dy)
+                for (int dx = 0; dx < cx; ++dx) {
+                    const long long i = ((long long)(Z * cz + dz) * ny + (Y * cy + dy)) * nx + (X * cx + dx);
+                    for (int k = rowOffsets[i]; k < rowOffsets[i + 1]; ++k) {
+                        const long long j = columnIndeces[k];
+                        const int jx = (int)(j % nx), jy = (int)((j / nx) % ny), jz = (int)(j / sxy);
+                        const int ox = jx / cx - X, oy = jy / cy - Y, oz = jz / cz - Z;
+                        if (ox < -1 || ox > 1 || oy < -1 || oy > 1 || oz < -1 || oz > 1) { *errFlag = 1; continue; }
+                        const int q = (oz + 1) * 9 + (oy + 1) * 3 + (ox + 1);
+                        const double v = elements[k];
+                        // static indexing keeps acc[] in registers
+#pragma unroll
+                        for (int t = 0; t < 27; ++t) if (t == q) acc[t] += v;
+                        touched |= 1u << q;
+                    }
+                }
+        if (elementsC == nullptr) { countsC[I] = __popc(touched); continue; }
+        int kout = rowOffsetsC[I];
+#pragma unroll
+        for (int q = 0; q < 27; ++q) {
+            if (!(touched & (1u << q))) continue;
+            const int ox = q % 3 - 1, oy = (q / 3) % 3 - 1, oz = q / 9 - 1;
+            elementsC[kout] = sigma * acc[q];
+            columnIndecesC[kout] = (int)(((long long)(Z + oz) * NY + (Y + oy)) * NX + (X + ox));
+            ++kout;
+        }
+    }
+}
+void launch_galerkin(hipStream_t s, int nx, int ny, int nz, const double* elements, const int* rowOffsets, const int* columnIndeces,
+                     double sigma, const int* rowOffsetsC, int* countsC, double* elementsC, int* columnIndecesC, int* errFlag)
+{
+    const long long NC = (long long)(nx > 1 ? nx / 2 : 1) * (ny > 1 ? ny / 2 : 1) * (nz > 1 ? nz / 2 : 1);
+    hipLaunchKernelGGL(galerkin_kernel, dim3(grid1(NC)), dim3(kBlock), 0, s, nx, ny, nz, elements, rowOffsets, columnIndeces,
+                       sigma, rowOffsetsC, countsC, elementsC, columnIndecesC, errFlag);
+}
+
+// ---------------------------------------------------------------- device problem generator
+// Entries stored before global row i = (x,y,z) of the 5/7-point Dirichlet Poisson matrix
+// (closed form: 7i minus the neighbours that fall off the grid in rows < i).
+__device__ __host__ inline long long poisson_row_offset(long long i, int nx, int ny, int nz)
+{
+    const long long sxy = (long long)nx * ny;
+    const int x = (int)(i % nx), y = (int)((i / nx) % ny), z = (int)(i / sxy);
+    const long long L = i / nx;                                   // complete x-lines before this row
+    long long missing = 0;
+    missing += L + (x > 0 ? 1 : 0);                               // rows with x == 0      (no -x neighbour)
+    missing += L;                                                 // rows with x == nx-1   (no +x neighbour)
+    missing += (long long)z * nx + (y > 0 ? nx : x);              // rows with y == 0
+    missing += (long long)z * nx + (y == ny - 1 ? x : 0);         // rows with y == ny-1
+    if (nz > 1) {
+        missing += (z > 0) ? sxy : ((long long)y * nx + x);       // rows with z == 0
+        missing += (z == nz - 1) ? ((long long)y * nx + x) : 0;   // rows with z == nz-1
+        return 7 * i - missing;
+    }
+    return 5 * i - missing;
+}
+
+__global__ __launch_bounds__(kBlock) void poisson_kernel(int nx, int ny, int nz, int zBegin, int zEnd,
+                                                         double* __restrict__ elements, int* __restrict__ rowOffsets, int* __restrict__ columnIndeces)
+{
+    const long long sxy = (long long)nx * ny;
+    const long long rowBegin = (long long)zBegin * sxy, rowEnd = (long long)zEnd * sxy;
+    const long long nLocal = rowEnd - rowBegin;
+    const long long base = poisson_row_offset(rowBegin, nx, ny, nz);
+    const double diag = nz > 1 ? 6.0 : 4.0;
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long li = (long long)blockIdx.x * kBlock + threadIdx.x; li <= nLocal; li += stride) {
+        const long long i = rowBegin + li;
+        if (li == nLocal) {
+            const long long total = (long long)nx * ny * nz;
+            const long long endOff = (i == total) ? ((nz > 1 ? 7 : 5) * total - 2 * ((long long)ny * nz + (long long)nx * nz + (nz > 1 ? sxy : 0)))
+                                                  : poisson_row_offset(i, nx, ny, nz);
+            rowOffsets[li] = (int)(endOff - base);
+            continue;
+        }
+        long long k = poisson_row_offset(i, nx, ny, nz) - base;
+        rowOffsets[li] = (int)k;
+        const int x = (int)(i % nx), y = (int)((i / nx) % ny), z = (int)(i / sxy);
+        if (nz > 1 && z > 0)  { elements[k] = -1.0; columnIndeces[k++] = (int)(i - sxy); }
+        if (y > 0)            { elements[k] = -1.0; columnIndeces[k++] = (int)(i - nx); }
+        if (x > 0)            { elements[k] = -1.0; columnIndeces[k++] = (int)(i - 1); }
+        elements[k] = diag;   columnIndeces[k++] = (int)i;
+        if (x < nx - 1)       { elements[k] = -1.0; columnIndeces[k++] = (int)(i + 1); }
+        if (y < ny - 1)       { elements[k] = -1.0; columnIndeces[k++] = (int)(i + nx); }
+        if (nz > 1 && z < nz - 1) { elements[k] = -1.0; columnIndeces[k++] = (int)(i + sxy); }
+    }
+}
+void launch_poisson(hipStream_t s, int nx, int ny, int nz, int zBegin, int zEnd, double* elements, int* rowOffsets, int* columnIndeces)
+{
+    const long long nLocal = (long long)(zEnd - zBegin) * nx * ny;
+    hipLaunchKernelGGL(poisson_kernel, dim3(grid1(nLocal + 1)), dim3(kBlock), 0, s, nx, ny, nz, zBegin, zEnd, elements, rowOffsets, columnIndeces);
+}
+
+long long poisson_nnz_host(int nx, int ny, int nz, int zBegin, int zEnd)
+{
+    const long long sxy = (long long)nx * ny;
+    const long long total = sxy * nz;
+    auto off = [&](long long i) -> long long {
+        if (i == total) return (nz > 1 ? 7 : 5) * total - 2 * ((long long)ny * nz + (long long)nx * nz + (nz > 1 ? sxy : 0));
+        return poisson_row_offset(i, nx, ny, nz);
+    };
+    return off((long long)zEnd * sxy) - off((long long)zBegin * sxy);
+}
+
+__global__ __launch_bounds__(kBlock) void rebase_kernel(int* __restrict__ rowOffsets, long long n, int base)
+{
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) rowOffsets[i] -= base;
+}
+void launch_rebase(hipStream_t s, int* rowOffsets, long long n, int base)
+{
+    if (n <= 0 || base == 0) return;
+    hipLaunchKernelGGL(rebase_kernel, dim3(grid1(n)), dim3(kBlock), 0, s, rowOffsets, n, base);
+}
+
+// out2[0] = min, out2[1] = max (out2 pre-set to INT_MAX / INT_MIN by the caller)
+__global__ __launch_bounds__(kBlock) void minmax_kernel(const int* __restrict__ v, long long n, int* out2)
+{
+    int lo = 0x7fffffff, hi = (int)0x80000000;
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) { int a = v[i]; lo = a < lo ? a : lo; hi = a > hi ? a : hi; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        int l2 = __shfl_down(lo, off, 64), h2 = __shfl_down(hi, off, 64);
+        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&out2[0], lo); atomicMax(&out2[1], hi); }
+}
+void launch_minmax_int(hipStream_t s, const int* v, long long n, int* out2)
+{
+    hipLaunchKernelGGL(minmax_kernel, dim3(grid1(n)), dim3(kBlock), 0, s, v, n, out2);
+}
+
+} // namespace mgcg

@@ -1,0 +1,280 @@
+// Runtime half of the C ABI: devices, handles, device vectors, errors.
+// Replaces Mgcg/cuBlas/MgcgGpu/Runtime.cu, Vector_Double.cu and Vector_Int.cu.
+#include "common.hpp"
+
+namespace mgcg {
+
+// ---------------------------------------------------------------- errors (thread-local, never abort)
+static thread_local std::string t_lastError;
+
+void set_error(const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    t_lastError = buf;
+    if (getenv("MGCG_VERBOSE")) fprintf(stderr, "[MgcgGpu] %s\n", buf);
+}
+
+bool hip_ok(hipError_t e, const char* what, const char* file, int line)
+{
+    if (e == hipSuccess) return true;
+    set_error("%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    return false;
+}
+
+// ---------------------------------------------------------------- devices
+// MGCG_VIRTUAL_DEVICES=n makes GetDeviceCount() report n devices mapped round-robin onto the
+// physical ones, so the reference's multi-device host logic (ConjugateGradientParallelGpu) can be
+// exercised on a one-GPU box.
+static int physical_count()
+{
+    static int n = -2;
+    if (n == -2) { int c = 0; if (hipGetDeviceCount(&c) != hipSuccess) c = 0; n = c; }
+    return n;
+}
+static int virtual_count()
+{
+    const char* v = getenv("MGCG_VIRTUAL_DEVICES");
+    if (v && atoi(v) > 0 && physical_count() > 0) return atoi(v);
+    return physical_count();
+}
+
+static thread_local int t_device = 0;   // virtual id
+static std::mutex g_devMutex;
+static DeviceState g_dev[kMaxDevices];
+
+int current_device() { return t_device; }
+
+DeviceState* device_state()
+{
+    const int phys = physical_count();
+    if (phys <= 0) { set_error("no HIP device available (hipGetDeviceCount = %d): the HIP path cannot run", phys); return nullptr; }
+    const int vd = t_device;
+    if (vd < 0 || vd >= kMaxDevices) { set_error("device id %d out of range", vd); return nullptr; }
+    const int pd = vd % phys;
+    if (!MGCG_HIP(hipSetDevice(pd))) return nullptr;
+    std::lock_guard<std::mutex> lock(g_devMutex);
+    DeviceState* d = &g_dev[pd];                       // virtual devices on one physical GPU share its stream
+    if (d->stream == nullptr) {
+        d->device = pd;
+        if (!MGCG_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking))) return nullptr;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, pd) == hipSuccess) d->numCu = prop.multiProcessorCount;
+    }
+    return d;
+}
+
+// ---------------------------------------------------------------- workspace
+bool Workspace::init()
+{
+    DeviceState* d = device_state();
+    if (!d) return false;
+    device = current_device();
+    stream = d->stream;
+    if (!MGCG_HIP(hipMalloc((void**)&partials, sizeof(double) * kMaxGrid * 2))) return false;
+    if (!MGCG_HIP(hipMalloc((void**)&scalars, sizeof(CgScalars)))) return false;
+    if (!MGCG_HIP(hipMemset(scalars, 0, sizeof(CgScalars)))) return false;
+    if (!MGCG_HIP(hipHostMalloc((void**)&mirror, sizeof(HostMirror), hipHostMallocMapped))) return false;
+    memset((void*)mirror, 0, sizeof(HostMirror));
+    if (!MGCG_HIP(hipHostMalloc((void**)&hostScalar, sizeof(double) * 4, hipHostMallocMapped))) return false;
+    return true;
+}
+void Workspace::destroy()
+{
+    if (partials) (void)hipFree(partials);
+    if (scalars) (void)hipFree(scalars);
+    if (mirror) (void)hipHostFree((void*)mirror);
+    if (hostScalar) (void)hipHostFree(hostScalar);
+    if (trace) (void)hipFree(trace);
+    partials = nullptr; scalars = nullptr; mirror = nullptr; hostScalar = nullptr; trace = nullptr; traceCap = 0;
+}
+bool Workspace::ensure_trace(int cap)
+{
+    if (cap <= traceCap) return true;
+    if (trace) (void)hipFree(trace);
+    trace = nullptr; traceCap = 0;
+    if (!MGCG_HIP(hipMalloc((void**)&trace, sizeof(double) * (size_t)cap))) return false;
+    traceCap = cap;
+    return true;
+}
+
+} // namespace mgcg
+
+using namespace mgcg;
+
+// ---------------------------------------------------------------- device vectors
+template <typename V, typename T>
+static V* create_vec(long long size)
+{
+    DeviceState* d = device_state();
+    if (!d) return nullptr;
+    if (size < 0) { set_error("negative vector size %lld", size); return nullptr; }
+    V* v = new V();
+    v->size = size; v->device = current_device();
+    if (size > 0) {
+        if (!MGCG_HIP(hipMalloc((void**)&v->data, sizeof(T) * (size_t)size))) { delete v; return nullptr; }
+        // thrust::device_vector<T>(size) value-initialises (Vector_Double.cu:9)
+        if (!MGCG_HIP(hipMemsetAsync(v->data, 0, sizeof(T) * (size_t)size, d->stream))) { (void)hipFree(v->data); delete v; return nullptr; }
+    }
+    return v;
+}
+
+template <typename V, typename T>
+static void copy_to_array(const V* src, T* dst, int count, int srcOff, int dstOff, const char* name)
+{
+    DeviceState* d = device_state();
+    if (!d) return;
+    if (!src || !dst) { set_error("%s: null argument", name); return; }
+    if (count < 0 || srcOff < 0 || (long long)srcOff + count > src->size) { set_error("%s: range [%d,+%d) outside vector of %lld", name, srcOff, count, src->size); return; }
+    if (count == 0) return;
+    if (!MGCG_HIP(hipMemcpyAsync(dst + dstOff, src->data + srcOff, sizeof(T) * (size_t)count, hipMemcpyDeviceToHost, d->stream))) return;
+    (void)MGCG_HIP(hipStreamSynchronize(d->stream));
+}
+
+template <typename V, typename T>
+static void copy_from_array(V* dst, const T* src, int count, int srcOff, int dstOff, const char* name)
+{
+    DeviceState* d = device_state();
+    if (!d) return;
+    if (!src || !dst) { set_error("%s: null argument", name); return; }
+    if (count < 0 || dstOff < 0 || (long long)dstOff + count > dst->size) { set_error("%s: range [%d,+%d) outside vector of %lld", name, dstOff, count, dst->size); return; }
+    if (count == 0) return;
+    if (!MGCG_HIP(hipMemcpyAsync(dst->data + dstOff, src + srcOff, sizeof(T) * (size_t)count, hipMemcpyHostToDevice, d->stream))) return;
+    (void)MGCG_HIP(hipStreamSynchronize(d->stream));   // pageable source must stay valid: complete before returning
+}
+
+extern "C" {
+
+const char* MgcgGetLastError(void) { return mgcg::t_lastError.c_str(); }
+void MgcgClearLastError(void) { mgcg::t_lastError.clear(); }
+int MgcgAbiVersion(void) { return 1; }
+
+int GetDeviceCount(void) { return virtual_count(); }
+
+void SetDevice(int deviceID)
+{
+    const int n = virtual_count();
+    if (deviceID < 0 || deviceID >= (n > 0 ? n : 1)) { set_error("SetDevice(%d): only %d device(s)", deviceID, n); return; }
+    t_device = deviceID;
+    const int phys = physical_count();
+    if (phys > 0) (void)MGCG_HIP(hipSetDevice(deviceID % phys));
+}
+
+MgcgBlas* CreateBlas(void)
+{
+    MgcgBlas* h = new MgcgBlas();
+    if (!h->ws.init()) { h->ws.destroy(); delete h; return nullptr; }
+    return h;
+}
+void DestroyBlas(MgcgBlas* h) { if (!h) return; h->ws.destroy(); delete h; }
+
+MgcgSparse* CreateSparse(void)
+{
+    MgcgSparse* h = new MgcgSparse();
+    if (!h->ws.init()) { h->ws.destroy(); delete h; return nullptr; }
+    const char* k = getenv("MGCG_SPMV_KERNEL");       if (k) h->kernel = atoi(k);
+    const char* r = getenv("MGCG_SPMV_ROWS");         if (r) h->rowsPerBlock = atoi(r);
+    const char* f = getenv("MGCG_SPMV_FLAGS");        if (f) h->flags = atoi(f);
+    const char* g = getenv("MGCG_SPMV_GRID");         if (g) h->gridBlocks = atoi(g);
+    return h;
+}
+void DestroySparse(MgcgSparse* h) { if (!h) return; h->ws.destroy(); delete h; }
+
+MgcgMatDescr* CreateMatDescr(void) { return new MgcgMatDescr(); }
+void DestroyMatDescr(MgcgMatDescr* d) { delete d; }
+
+void MgcgSetSpmvKernel(MgcgSparse* h, int kernel) { if (h) h->kernel = kernel; }
+void MgcgSetSpmvTuning(MgcgSparse* h, int rowsPerBlock, int flags, int gridBlocks)
+{
+    if (!h) return;
+    h->rowsPerBlock = rowsPerBlock; h->flags = flags; h->gridBlocks = gridBlocks;
+}
+
+int MgcgDeviceSynchronize(void)
+{
+    DeviceState* d = device_state();
+    if (!d) return -1;
+    return MGCG_HIP(hipStreamSynchronize(d->stream)) ? 0 : -1;
+}
+
+void* MgcgEventCreate(void)
+{
+    if (!device_state()) return nullptr;
+    hipEvent_t e;
+    if (!MGCG_HIP(hipEventCreate(&e))) return nullptr;
+    return (void*)e;
+}
+void MgcgEventRecord(void* ev)
+{
+    DeviceState* d = device_state();
+    if (!d || !ev) return;
+    (void)MGCG_HIP(hipEventRecord((hipEvent_t)ev, d->stream));
+}
+float MgcgEventElapsedMs(void* start, void* stop)
+{
+    float ms = -1.0f;
+    if (!start || !stop) return ms;
+    if (!MGCG_HIP(hipEventSynchronize((hipEvent_t)stop))) return -1.0f;
+    if (!MGCG_HIP(hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop))) return -1.0f;
+    return ms;
+}
+void MgcgEventDestroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+
+int MgcgMemGetInfo(long long* freeBytes, long long* totalBytes)
+{
+    if (!device_state()) return -1;
+    size_t f = 0, t = 0;
+    if (!MGCG_HIP(hipMemGetInfo(&f, &t))) return -1;
+    if (freeBytes) *freeBytes = (long long)f;
+    if (totalBytes) *totalBytes = (long long)t;
+    return 0;
+}
+
+Vector* Create_Double(int size) { return create_vec<Vector, double>(size); }
+Vector* MgcgCreateDouble64(long long size) { return create_vec<Vector, double>(size); }
+VectorInt* Create_Int(int size) { return create_vec<VectorInt, int>(size); }
+VectorInt* MgcgCreateInt64(long long size) { return create_vec<VectorInt, int>(size); }
+long long MgcgVectorSize(const Vector* v) { return v ? v->size : 0; }
+
+void CopyToArray_Double(const Vector* s, double d[], int count, int so, int dofs) { copy_to_array<Vector, double>(s, d, count, so, dofs, "CopyToArray_Double"); }
+void CopyFromArray_Double(Vector* d, const double s[], int count, int so, int dofs) { copy_from_array<Vector, double>(d, s, count, so, dofs, "CopyFromArray_Double"); }
+void CopyToArray_Int(const VectorInt* s, int d[], int count, int so, int dofs) { copy_to_array<VectorInt, int>(s, d, count, so, dofs, "CopyToArray_Int"); }
+void CopyFromArray_Int(VectorInt* d, int s[], int count, int so, int dofs) { copy_from_array<VectorInt, int>(d, s, count, so, dofs, "CopyFromArray_Int"); }
+
+void Delete_Double(Vector* v)
+{
+    if (!v) return;
+    if (v->data) { DeviceState* d = device_state(); if (d) (void)hipStreamSynchronize(d->stream); (void)hipFree(v->data); }
+    delete v;
+}
+void Delete_Int(VectorInt* v)
+{
+    if (!v) return;
+    if (v->data) { DeviceState* d = device_state(); if (d) (void)hipStreamSynchronize(d->stream); (void)hipFree(v->data); }
+    delete v;
+}
+double* ToRawPtr_Double(Vector* v) { return v ? v->data : nullptr; }
+int* ToRawPtr_Int(VectorInt* v) { return v ? v->data : nullptr; }
+
+void CopyFromDevice_Double(const double* source, double* destination, int count, int sourceOffset, int destinationOffset)
+{
+    DeviceState* d = device_state();
+    if (!d) return;
+    if (!source || !destination || count < 0) { set_error("CopyFromDevice_Double: bad argument"); return; }
+    if (count == 0) return;
+    // device-to-device, possibly across devices (hipMemcpyDefault resolves the peers); count in ELEMENTS
+    if (!MGCG_HIP(hipMemcpyAsync(destination + destinationOffset, source + sourceOffset, sizeof(double) * (size_t)count, hipMemcpyDefault, d->stream))) return;
+    (void)MGCG_HIP(hipStreamSynchronize(d->stream));
+}
+
+void MgcgFill(Vector* v, double value)
+{
+    DeviceState* d = device_state();
+    if (!d || !v) return;
+    launch_fill(d->stream, v->data, value, v->size);
+}
+
+} // extern "C"

@@ -1,0 +1,543 @@
+// Solver half of the C ABI: the whole CG / preconditioned-CG loop, resident on the device.
+// Replaces Mgcg/cuBlas/MgcgGpu/Mgcg.cu:201-270 (Solve) and the host-driven multi-device loop of
+// Mgcg/cuBlas/Mgcg/ConjugateGradientParallelGpu.cs:424-565.
+//
+// Per iteration the reference issues 7 library calls and 2 blocking 8-byte device->host reads.
+// Here an iteration is 3 streaming kernels + 2 single-workgroup scalar kernels, alpha / beta /
+// the stop test live in device memory, and the host only enqueues: it runs `checkEvery` iterations
+// ahead and looks at a pinned flag the device wrote.  Once the stop test fires on the device every
+// later kernel exits at its first instruction, so x, r, p, Iteration and Residual are exactly those
+// of the iteration the reference would have stopped at.
+#include "common.hpp"
+
+namespace mgcg {
+
+// ---------------------------------------------------------------- multigrid hierarchy
+struct MgLevel {
+    int nx = 0, ny = 0, nz = 0;
+    long long n = 0, nnz = 0;
+    double* elements = nullptr; int* rowOffsets = nullptr; int* columnIndeces = nullptr;
+    bool ownsMatrix = false;
+    double* dinv = nullptr;
+    double *xa = nullptr, *xb = nullptr;   // solution ping-pong (Jacobi is not in place)
+    double *b = nullptr, *r = nullptr;     // right-hand side (restricted residual), residual
+};
+
+} // namespace mgcg
+
+struct MgcgMg {
+    int levels = 0;
+    double omega = 0; int nu = 1, nuCoarse = 4; double sigma = 0.5;
+    std::vector<mgcg::MgLevel> lv;
+    mgcg::SpmvConfig cfg;
+    hipStream_t stream = nullptr;
+};
+
+namespace mgcg {
+
+static SpmvConfig cfg_of(const MgcgSparse* h)
+{
+    SpmvConfig c; c.kernel = h->kernel; c.rowsPerBlock = h->rowsPerBlock; c.flags = h->flags; c.gridBlocks = h->gridBlocks;
+    return c;
+}
+
+static void mg_jacobi(MgcgMg* mg, MgLevel& L, const double* b, const double* xin, double* xout, const int* done)
+{
+    SpmvArgs a{};
+    a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = xin; a.y = xout;
+    a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.n;
+    a.w = xin; a.b = b; a.dinv = L.dinv; a.omega = mg->omega; a.doneFlag = done;
+    launch_spmv(mg->stream, EPI_JACOBI, a, mg->cfg);
+}
+
+// `sweeps` Jacobi sweeps on level L for right-hand side b.  first: the first sweep starts from zero.
+// cur is the buffer holding the iterate (ignored when first); returns the buffer holding the result.
+static double* mg_smooth(MgcgMg* mg, MgLevel& L, const double* b, double* cur, double* other, int sweeps, bool first, const int* done)
+{
+    for (int sIdx = 0; sIdx < sweeps; ++sIdx) {
+        if (first && sIdx == 0) {
+            launch_jacobi_first(mg->stream, L.n, mg->omega, L.dinv, b, cur, done);
+        } else {
+            mg_jacobi(mg, L, b, cur, other, done);
+            double* t = cur; cur = other; other = t;
+        }
+    }
+    return cur;
+}
+
+// One V(nu,nu) cycle on level l for right-hand side b; x0/x1 are that level's two iterate buffers.
+// Returns the buffer that holds the result.  Mirrors vcycle() of oracle/mg_oracle.c.
+static double* mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1, const int* done)
+{
+    MgLevel& L = mg->lv[l];
+    if (l == mg->levels - 1) return mg_smooth(mg, L, b, x0, x1, mg->nuCoarse, true, done);
+    MgLevel& C = mg->lv[l + 1];
+    double* cur = mg_smooth(mg, L, b, x0, x1, mg->nu, true, done);
+    double* other = (cur == x0) ? x1 : x0;
+    SpmvArgs a{};
+    a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = cur; a.y = L.r;
+    a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.n; a.b = b; a.doneFlag = done;
+    launch_spmv(mg->stream, EPI_RESIDUAL, a, mg->cfg);                        // r = b - A x
+    launch_restrict(mg->stream, L.nx, L.ny, L.nz, L.r, C.b, done);            // b_c = P^T r
+    double* e = mg_vcycle(mg, l + 1, C.b, C.xa, C.xb, done);
+    launch_prolong_add(mg->stream, L.nx, L.ny, L.nz, cur, e, done);           // x += P e
+    return mg_smooth(mg, L, b, cur, other, mg->nu, false, done);
+}
+
+// z = M^-1 r.  Level 0 iterates ping-pong between z and lv[0].xa so that the result lands in z.
+static void mg_apply(MgcgMg* mg, const double* r, double* z, const int* done)
+{
+    MgLevel& L0 = mg->lv[0];
+    // swaps on level 0: (nu-1) pre + nu post, or (nuCoarse-1) when there is a single level
+    const int swaps = (mg->levels == 1) ? (mg->nuCoarse - 1) : (2 * mg->nu - 1);
+    double* start = (swaps % 2 == 0) ? z : L0.xa;
+    double* other = (start == z) ? L0.xa : z;
+    double* res = mg_vcycle(mg, 0, r, start, other, done);
+    if (res != z) launch_copy(mg->stream, z, res, L0.n);   // not reached for the buffer choice above
+}
+
+// ---------------------------------------------------------------- the CG loop
+struct CgRun {
+    Workspace* ws = nullptr;
+    SpmvConfig cfg;
+    MgcgComm* comm = nullptr;
+    HaloPlan* halo = nullptr;
+    MgcgMg* mg = nullptr;
+    const double* elements = nullptr; const int* rowOffsets = nullptr; const int* columnIndeces = nullptr;
+    int elementsCount = 0;
+    double *x = nullptr, *b = nullptr, *Ap = nullptr, *p = nullptr, *r = nullptr, *z = nullptr;  // p is FULL length (count), the rest local
+    long long count = 0, nLocal = 0, offset = 0;
+    int nranks = 1;
+    double tol = 0; int minIt = 0, maxIt = 0, rule = 0;
+    bool wantInf = false;
+    SpmvProfile* prof = nullptr;
+};
+
+static void prof_mark(CgRun& R, bool begin)
+{
+    SpmvProfile* p = R.prof;
+    if (!p || !p->enabled) return;
+    if (begin) {
+        if (p->used >= (int)p->start.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            p->start.push_back(a); p->stop.push_back(b);
+        }
+        (void)hipEventRecord(p->start[p->used], R.ws->stream);
+    } else if (p->used < (int)p->start.size()) {
+        (void)hipEventRecord(p->stop[p->used], R.ws->stream);
+        p->used++;
+    }
+}
+
+__global__ void snapshot_kernel(const CgScalars* sc, HostMirror* m, volatile int* slot)
+{
+    *slot = sc->done;
+    m->residual = sc->residual;
+}
+
+__global__ void clear_done_kernel(CgScalars* sc) { sc->done = 0; sc->status = 0; }
+
+static bool cg_enqueue_init(CgRun& R)
+{
+    hipStream_t s = R.ws->stream;
+    CgScalars* sc = R.ws->scalars;
+    double* pLoc = R.p + R.offset;
+    if (R.rule == MGCG_RULE_SIMPLE) launch_fill(s, R.x, 0.0, R.nLocal);             // SimpleConjugateGradient.cu:53
+    launch_copy(s, pLoc, R.x, R.nLocal);                                             // p_loc = x  (Mgcg.cu:80)
+    if (!halo_exchange(R.comm, R.halo, R.p, s)) return false;                        // SyncP  (ConjugateGradientParallelGpu.cs:427)
+    SpmvArgs a{};
+    a.elements = R.elements; a.rowOffsets = R.rowOffsets; a.columnIndeces = R.columnIndeces; a.x = R.p; a.y = R.r;
+    a.elementsCount = R.elementsCount; a.rowCount = (int)R.nLocal; a.columnCount = (int)R.count; a.b = R.b;
+    launch_spmv(s, EPI_RESIDUAL, a, R.cfg);                                          // r = b - A x   (Mgcg.cu:225-226)
+    int n;
+    if (R.mg) {
+        mg_apply(R.mg, R.r, R.z, nullptr);                                           // z = M^-1 r
+        launch_copy(s, pLoc, R.z, R.nLocal);                                         // p = z
+        n = launch_dot_partials(s, R.r, R.z, R.nLocal, R.ws->partials);              // rz = r.z
+    } else {
+        n = launch_copy_dot(s, pLoc, R.r, R.nLocal, R.ws->partials, nullptr);        // p = r ; rr = r.r  (Mgcg.cu:227-228)
+    }
+    if (R.nranks > 1) {
+        launch_reduce_to(s, R.ws->partials, n, &sc->rr, nullptr);
+        if (!comm_allreduce_sum(R.comm, &sc->rr, 1, s)) return false;                // resultsDot.Sum()  (:463)
+        launch_init_scalars(s, R.ws->partials, n, false, sc, R.ws->mirror, R.rule);
+    } else {
+        launch_init_scalars(s, R.ws->partials, n, true, sc, R.ws->mirror, R.rule);
+    }
+    return MGCG_HIP(hipGetLastError());
+}
+
+static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
+{
+    hipStream_t s = R.ws->stream;
+    CgScalars* sc = R.ws->scalars;
+    double* pLoc = R.p + R.offset;
+    const int* done = &sc->done;
+    if (!halo_exchange(R.comm, R.halo, R.p, s)) return false;                        // SyncP  (:469)
+    SpmvArgs a{};
+    a.elements = R.elements; a.rowOffsets = R.rowOffsets; a.columnIndeces = R.columnIndeces; a.x = R.p; a.y = R.Ap;
+    a.elementsCount = R.elementsCount; a.rowCount = (int)R.nLocal; a.columnCount = (int)R.count;
+    a.w = pLoc; a.partials = R.ws->partials; a.doneFlag = done;
+    prof_mark(R, true);
+    int n = launch_spmv(s, EPI_DOT, a, R.cfg);                                       // Ap = A p ; p.Ap   (Mgcg.cu:244-245)
+    prof_mark(R, false);
+    launch_reduce_to(s, R.ws->partials, n, &sc->pAp, done);
+    if (R.nranks > 1 && !comm_allreduce_sum(R.comm, &sc->pAp, 1, s)) return false;   // (:499)
+    double* pInf = R.wantInf ? R.ws->partials + kMaxGrid : nullptr;
+    n = launch_update_xr(s, sc, R.x, R.r, pLoc, R.Ap, R.nLocal, R.ws->partials, pInf);   // x += a p ; r -= a Ap ; r.r  (:246-248)
+    FinalizeArgs f{};
+    f.sc = sc; f.mirror = R.ws->mirror; f.trace = R.ws->trace; f.traceCap = R.ws->traceCap;
+    f.tol = R.tol; f.minIt = R.minIt; f.maxIt = R.maxIt; f.rule = R.rule; f.preconditioned = R.mg ? 1 : 0;
+    if (!withStopTest) { f.tol = -1.0; f.minIt = 0; f.maxIt = 0x7fffffff; f.rule = MGCG_RULE_NATIVE; }   // never converges
+    if (R.nranks > 1) {
+        launch_reduce_to(s, R.ws->partials, n, &sc->rrNew, done);
+        if (!comm_allreduce_sum(R.comm, &sc->rrNew, 1, s)) return false;             // (:525)
+        launch_finalize(s, R.ws->partials, pInf, n, false, f);
+    } else {
+        launch_finalize(s, R.ws->partials, pInf, n, true, f);                        // residual, stop test, beta  (:251-266)
+    }
+    if (R.mg) {
+        mg_apply(R.mg, R.r, R.z, done);                                              // z = M^-1 r
+        n = launch_dot_partials(s, R.r, R.z, R.nLocal, R.ws->partials);
+        if (R.nranks > 1) {
+            launch_reduce_to(s, R.ws->partials, n, &sc->rzNew, done);
+            if (!comm_allreduce_sum(R.comm, &sc->rzNew, 1, s)) return false;
+            launch_finalize_precond(s, R.ws->partials, n, false, sc);
+        } else {
+            launch_finalize_precond(s, R.ws->partials, n, true, sc);                 // beta = rzNew / rz
+        }
+        launch_update_p(s, sc, pLoc, R.z, R.nLocal);                                 // p = z + beta p
+    } else {
+        launch_update_p(s, sc, pLoc, R.r, R.nLocal);                                 // p = r + beta p   (:265)
+    }
+    return MGCG_HIP(hipGetLastError());
+}
+
+static int cg_solve(CgRun& R, int* iteration, double* residual, double* residualTrace, int traceCapacity)
+{
+    hipStream_t s = R.ws->stream;
+    HostMirror* m = R.ws->mirror;
+    if (R.rule < MGCG_RULE_NATIVE || R.rule > MGCG_RULE_VIENNACL) { set_error("unknown stop rule %d", R.rule); return MGCG_ERROR; }
+    R.wantInf = (R.rule == MGCG_RULE_HANDMADECL);
+    if (R.wantInf && R.nranks > 1) { set_error("the max-norm rule is single-rank only"); return MGCG_ERROR; }
+    if (residualTrace && traceCapacity > 0) { if (!R.ws->ensure_trace(traceCapacity)) return MGCG_ERROR; }
+    const int devTraceCap = (residualTrace && traceCapacity > 0) ? traceCapacity : 0;
+    double* savedTrace = R.ws->trace; const int savedCap = R.ws->traceCap;
+    if (!devTraceCap) { R.ws->trace = nullptr; R.ws->traceCap = 0; } else R.ws->traceCap = devTraceCap;
+
+    int status = MGCG_ERROR;
+    int checkEvery = 4;
+    if (const char* e = getenv("MGCG_CHECK_EVERY")) { checkEvery = atoi(e); if (checkEvery < 1) checkEvery = 1; }
+    const long long hostCap = (long long)(R.maxIt > R.minIt ? R.maxIt : R.minIt) + 4;
+    hipEvent_t ev[2] = { nullptr, nullptr };
+    volatile int* slots = (volatile int*)&R.ws->hostScalar[2];   // two ints per double: slots[0..3]
+    bool ok = MGCG_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming)) && MGCG_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    for (int i = 0; i < 4; ++i) slots[i] = 0;
+    ok = ok && cg_enqueue_init(R);
+    long long enqueued = 0;
+    int chunk = 0;
+    bool finished = false;
+    while (ok && !finished) {
+        for (int k = 0; ok && k < checkEvery; ++k) ok = cg_enqueue_iteration(R, true);
+        enqueued += checkEvery;
+        hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(1), 0, s, R.ws->scalars, m, &slots[chunk & 1]);
+        ok = ok && MGCG_HIP(hipEventRecord(ev[chunk & 1], s));
+        if (chunk > 0) {                                  // look at the chunk BEFORE the one just enqueued
+            ok = ok && MGCG_HIP(hipEventSynchronize(ev[(chunk - 1) & 1]));
+            if (ok && slots[(chunk - 1) & 1] != 0) finished = true;
+        }
+        if (!finished && enqueued > hostCap + 2LL * checkEvery) {
+            ok = ok && MGCG_HIP(hipStreamSynchronize(s));
+            if (ok && slots[chunk & 1] != 0) finished = true;
+            else { set_error("CG: the device never raised its stop flag after %lld iterations", enqueued); ok = false; }
+        }
+        ++chunk;
+    }
+    ok = MGCG_HIP(hipStreamSynchronize(s)) && ok;
+    if (ok) {
+        status = m->status;
+        if (iteration) *iteration = m->iteration;
+        if (residual) *residual = m->residual;
+        if (devTraceCap) {
+            int nTrace = m->iteration + 1; if (nTrace > devTraceCap) nTrace = devTraceCap;
+            ok = MGCG_HIP(hipMemcpy(residualTrace, R.ws->trace, sizeof(double) * (size_t)nTrace, hipMemcpyDeviceToHost));
+        }
+        if (status == MGCG_MAXIT_EXCEEDED) set_error("CG did not converge: iteration %d exceeded maxIteration %d (residual %g)", m->iteration, R.maxIt, m->residual);
+        if (status == MGCG_NONFINITE) set_error("CG stopped: residual is not finite at iteration %d", m->iteration);
+    }
+    if (ev[0]) (void)hipEventDestroy(ev[0]);
+    if (ev[1]) (void)hipEventDestroy(ev[1]);
+    R.ws->trace = savedTrace; R.ws->traceCap = savedCap;
+    return ok ? status : MGCG_ERROR;
+}
+
+static bool check_vectors(const char* who, Vector* e, VectorInt* ro, VectorInt* ci, Vector* x, Vector* b, Vector* Ap, Vector* p, Vector* r,
+                          long long elementsCount, long long nLocal, long long count)
+{
+    if (!e || !ro || !ci || !x || !b || !Ap || !p || !r) { set_error("%s: null vector handle", who); return false; }
+    if (elementsCount < 0 || nLocal < 0 || count < nLocal) { set_error("%s: bad sizes", who); return false; }
+    if (e->size < elementsCount || ci->size < elementsCount || ro->size < nLocal + 1 || x->size < nLocal || b->size < nLocal ||
+        Ap->size < nLocal || r->size < nLocal || p->size < count) { set_error("%s: a device vector is smaller than the problem", who); return false; }
+    return true;
+}
+
+} // namespace mgcg
+
+using namespace mgcg;
+
+extern "C" {
+
+int SolveEx(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr,
+            Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+            Vector* xVector, Vector* bVector, Vector* ApVector, Vector* pVector, Vector* rVector,
+            int elementsCount, int count,
+            double allowableResidual, int minIteration, int maxIteration, int rule,
+            int* iteration, double* residual, double* residualTrace, int traceCapacity)
+{
+    (void)matDescr;
+    if (!device_state()) return MGCG_ERROR;
+    if (!cublas || !cusparse) { set_error("SolveEx: null handle"); return MGCG_ERROR; }
+    if (!check_vectors("SolveEx", elementsVector, rowOffsetsVector, columnIndecesVector, xVector, bVector, ApVector, pVector, rVector, elementsCount, count, count)) return MGCG_ERROR;
+    CgRun R;
+    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof;
+    R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCount;
+    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data;
+    R.count = count; R.nLocal = count; R.offset = 0;
+    R.tol = allowableResidual; R.minIt = minIteration; R.maxIt = maxIteration; R.rule = rule;
+    return cg_solve(R, iteration, residual, residualTrace, traceCapacity);
+}
+
+void Solve(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr,
+           Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+           Vector* xVector, Vector* bVector, Vector* ApVector, Vector* pVector, Vector* rVector,
+           int elementsCount, int count,
+           double allowableResidual, int minIteration, int maxIteration,
+           int* iteration, double* residual)
+{
+    int it = 0; double res = NAN;
+    const int st = SolveEx(cublas, cusparse, matDescr, elementsVector, rowOffsetsVector, columnIndecesVector, xVector, bVector,
+                           ApVector, pVector, rVector, elementsCount, count, allowableResidual, minIteration, maxIteration,
+                           MGCG_RULE_NATIVE, &it, &res, nullptr, 0);
+    (void)st;
+    if (iteration) *iteration = it + 1;     // the reference returns its post-incremented loop counter (Mgcg.cu:234)
+    if (residual) *residual = res;
+}
+
+int SolveParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr,
+                  Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+                  Vector* xVector, Vector* bVector, Vector* ApVector, Vector* pVector, Vector* rVector,
+                  int count, int countForDevice, int offsetForDevice, int elementsCountForDevice,
+                  int minJ, int maxJ,
+                  double allowableResidual, int minIteration, int maxIteration, int rule,
+                  int* iteration, double* residual, double* residualTrace, int traceCapacity)
+{
+    (void)matDescr;
+    if (!device_state()) return MGCG_ERROR;
+    if (!cublas || !cusparse) { set_error("SolveParallel: null handle"); return MGCG_ERROR; }
+    if (!check_vectors("SolveParallel", elementsVector, rowOffsetsVector, columnIndecesVector, xVector, bVector, ApVector, pVector, rVector,
+                       elementsCountForDevice, countForDevice, count)) return MGCG_ERROR;
+    if (offsetForDevice < 0 || (long long)offsetForDevice + countForDevice > count) { set_error("SolveParallel: bad partition"); return MGCG_ERROR; }
+    CgRun R;
+    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.comm = comm; R.nranks = MgcgCommSize(comm);
+    R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCountForDevice;
+    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data;
+    R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice;
+    R.tol = allowableResidual; R.minIt = minIteration; R.maxIt = maxIteration; R.rule = rule;
+    if (R.nranks > 1) {
+        R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ);
+        if (!R.halo) return MGCG_ERROR;
+    }
+    const int st = cg_solve(R, iteration, residual, residualTrace, traceCapacity);
+    if (R.halo) halo_plan_destroy(R.halo);
+    return st;
+}
+
+double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
+               Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+               Vector* xVector, Vector* bVector, Vector* ApVector, Vector* pVector, Vector* rVector,
+               int count, int countForDevice, int offsetForDevice, int elementsCountForDevice,
+               int minJ, int maxJ, int steps, int restart)
+{
+    if (!device_state()) return NAN;
+    if (!cublas || !cusparse) { set_error("CgSteps: null handle"); return NAN; }
+    if (!check_vectors("CgSteps", elementsVector, rowOffsetsVector, columnIndecesVector, xVector, bVector, ApVector, pVector, rVector,
+                       elementsCountForDevice, countForDevice, count)) return NAN;
+    CgRun R;
+    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.comm = comm; R.nranks = MgcgCommSize(comm);
+    R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCountForDevice;
+    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data;
+    R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice; R.rule = MGCG_RULE_NATIVE;
+    double* savedTrace = R.ws->trace; const int savedCap = R.ws->traceCap;
+    R.ws->trace = nullptr; R.ws->traceCap = 0;
+    bool ok = true;
+    if (R.nranks > 1) { R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ); ok = R.halo != nullptr; }
+    if (ok && restart) ok = cg_enqueue_init(R);
+    else if (ok) hipLaunchKernelGGL(clear_done_kernel, dim3(1), dim3(1), 0, R.ws->stream, R.ws->scalars);
+    for (int k = 0; ok && k < steps; ++k) ok = cg_enqueue_iteration(R, false);
+    if (ok) hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(1), 0, R.ws->stream, R.ws->scalars, R.ws->mirror, (volatile int*)&R.ws->hostScalar[2]);
+    ok = MGCG_HIP(hipStreamSynchronize(R.ws->stream)) && ok;
+    if (R.halo) halo_plan_destroy(R.halo);
+    R.ws->trace = savedTrace; R.ws->traceCap = savedCap;
+    return ok ? (double)R.ws->mirror->residual : NAN;
+}
+
+void MgcgProfileSpmv(MgcgSparse* h, int enable)
+{
+    if (!h) return;
+    h->prof.enabled = enable != 0;
+    h->prof.used = 0;
+}
+
+double MgcgProfileSpmvMs(MgcgSparse* h, int* launches)
+{
+    if (launches) *launches = 0;
+    if (!h) return 0.0;
+    double total = 0.0;
+    for (int i = 0; i < h->prof.used; ++i) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(h->prof.stop[i]) != hipSuccess) continue;
+        if (hipEventElapsedTime(&ms, h->prof.start[i], h->prof.stop[i]) != hipSuccess) continue;
+        total += ms;
+        if (launches) (*launches)++;
+    }
+    return total;
+}
+
+// ---------------------------------------------------------------- multigrid
+MgcgMg* MgSetup(MgcgBlas* cublas, MgcgSparse* cusparse,
+                Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+                int elementsCount, int nx, int ny, int nz,
+                int levels, double omega, int nu, int nuCoarse, double sigma)
+{
+    DeviceState* d = device_state();
+    if (!d) return nullptr;
+    if (!cublas || !cusparse || !elementsVector || !rowOffsetsVector || !columnIndecesVector) { set_error("MgSetup: null argument"); return nullptr; }
+    const long long n0 = (long long)nx * ny * nz;
+    if (nx < 1 || ny < 1 || nz < 1 || levels < 1 || nu < 1 || nuCoarse < 1 || n0 > 0x7fffffffLL) { set_error("MgSetup: bad parameters"); return nullptr; }
+    if (rowOffsetsVector->size < n0 + 1 || elementsVector->size < elementsCount || columnIndecesVector->size < elementsCount) { set_error("MgSetup: matrix vectors too small"); return nullptr; }
+    hipStream_t s = d->stream;
+    MgcgMg* mg = new MgcgMg();
+    mg->omega = omega; mg->nu = nu; mg->nuCoarse = nuCoarse; mg->sigma = sigma; mg->stream = s; mg->cfg = cfg_of(cusparse);
+    mg->cfg.kernel = 0;   // every level picks its kernel from its own nnz/row
+    int* dErr = nullptr;
+    bool ok = MGCG_HIP(hipMalloc((void**)&dErr, sizeof(int))) && MGCG_HIP(hipMemsetAsync(dErr, 0, sizeof(int), s));
+    for (int l = 0; ok && l < levels; ++l) {
+        MgLevel L;
+        if (l == 0) {
+            L.nx = nx; L.ny = ny; L.nz = nz; L.n = n0; L.nnz = elementsCount;
+            L.elements = elementsVector->data; L.rowOffsets = rowOffsetsVector->data; L.columnIndeces = columnIndecesVector->data;
+        } else {
+            const MgLevel& F = mg->lv[l - 1];
+            if ((F.nx > 1 && F.nx % 2) || (F.ny > 1 && F.ny % 2) || (F.nz > 1 && F.nz % 2)) break;   // cannot coarsen an odd extent
+            if (F.nx == 1 && F.ny == 1 && F.nz == 1) break;
+            L.nx = F.nx > 1 ? F.nx / 2 : 1; L.ny = F.ny > 1 ? F.ny / 2 : 1; L.nz = F.nz > 1 ? F.nz / 2 : 1;
+            L.n = (long long)L.nx * L.ny * L.nz;
+            L.ownsMatrix = true;
+            int* counts = nullptr;
+            ok = ok && MGCG_HIP(hipMalloc((void**)&L.rowOffsets, sizeof(int) * (size_t)(L.n + 1)));
+            ok = ok && MGCG_HIP(hipMalloc((void**)&counts, sizeof(int) * (size_t)L.n));
+            if (!ok) break;
+            launch_galerkin(s, F.nx, F.ny, F.nz, F.elements, F.rowOffsets, F.columnIndeces, sigma, nullptr, counts, nullptr, nullptr, dErr);
+            std::vector<int> h((size_t)L.n + 1);
+            ok = ok && MGCG_HIP(hipMemcpyAsync(h.data() + 1, counts, sizeof(int) * (size_t)L.n, hipMemcpyDeviceToHost, s));
+            int err = 0;
+            ok = ok && MGCG_HIP(hipMemcpyAsync(&err, dErr, sizeof(int), hipMemcpyDeviceToHost, s));
+            ok = ok && MGCG_HIP(hipStreamSynchronize(s));
+            (void)hipFree(counts);
+            if (!ok) break;
+            if (err) { set_error("MgSetup: matrix is not a 27-point-neighbourhood operator on the %dx%dx%d grid", F.nx, F.ny, F.nz); ok = false; (void)hipFree(L.rowOffsets); break; }
+            h[0] = 0;
+            long long run = 0;
+            for (long long i = 1; i <= L.n; ++i) { run += h[(size_t)i]; h[(size_t)i] = (int)run; }   // exclusive scan on the host (set-up only)
+            L.nnz = run;
+            ok = ok && MGCG_HIP(hipMemcpyAsync(L.rowOffsets, h.data(), sizeof(int) * (size_t)(L.n + 1), hipMemcpyHostToDevice, s));
+            ok = ok && MGCG_HIP(hipMalloc((void**)&L.elements, sizeof(double) * (size_t)(L.nnz > 0 ? L.nnz : 1)));
+            ok = ok && MGCG_HIP(hipMalloc((void**)&L.columnIndeces, sizeof(int) * (size_t)(L.nnz > 0 ? L.nnz : 1)));
+            if (!ok) break;
+            launch_galerkin(s, F.nx, F.ny, F.nz, F.elements, F.rowOffsets, F.columnIndeces, sigma, L.rowOffsets, nullptr, L.elements, L.columnIndeces, dErr);
+            ok = ok && MGCG_HIP(hipStreamSynchronize(s));   // h must outlive the copy
+        }
+        ok = ok && MGCG_HIP(hipMalloc((void**)&L.dinv, sizeof(double) * (size_t)L.n));
+        ok = ok && MGCG_HIP(hipMalloc((void**)&L.xa, sizeof(double) * (size_t)L.n));
+        ok = ok && MGCG_HIP(hipMalloc((void**)&L.r, sizeof(double) * (size_t)L.n));
+        if (l > 0) {
+            ok = ok && MGCG_HIP(hipMalloc((void**)&L.xb, sizeof(double) * (size_t)L.n));
+            ok = ok && MGCG_HIP(hipMalloc((void**)&L.b, sizeof(double) * (size_t)L.n));
+        }
+        if (ok) launch_extract_dinv(s, L.elements, L.rowOffsets, L.columnIndeces, L.n, 0, L.dinv);
+        mg->lv.push_back(L);
+        mg->levels = (int)mg->lv.size();
+    }
+    ok = ok && MGCG_HIP(hipStreamSynchronize(s));
+    if (dErr) (void)hipFree(dErr);
+    if (!ok || mg->levels == 0) { MgDestroy(mg); return nullptr; }
+    return mg;
+}
+
+void MgDestroy(MgcgMg* mg)
+{
+    if (!mg) return;
+    if (mg->stream) (void)hipStreamSynchronize(mg->stream);
+    for (auto& L : mg->lv) {
+        if (L.ownsMatrix) { if (L.elements) (void)hipFree(L.elements); if (L.rowOffsets) (void)hipFree(L.rowOffsets); if (L.columnIndeces) (void)hipFree(L.columnIndeces); }
+        if (L.dinv) (void)hipFree(L.dinv);
+        if (L.xa) (void)hipFree(L.xa);
+        if (L.xb) (void)hipFree(L.xb);
+        if (L.b) (void)hipFree(L.b);
+        if (L.r) (void)hipFree(L.r);
+    }
+    delete mg;
+}
+
+int MgLevels(const MgcgMg* mg) { return mg ? mg->levels : 0; }
+long long MgLevelRows(const MgcgMg* mg, int l) { return (mg && l >= 0 && l < mg->levels) ? mg->lv[l].n : -1; }
+long long MgLevelNnz(const MgcgMg* mg, int l) { return (mg && l >= 0 && l < mg->levels) ? mg->lv[l].nnz : -1; }
+
+void MgLevelCopyCsr(const MgcgMg* mg, int l, double elements[], int columnIndeces[], int rowOffsets[])
+{
+    if (!mg || l < 0 || l >= mg->levels) { set_error("MgLevelCopyCsr: bad level"); return; }
+    const MgLevel& L = mg->lv[l];
+    (void)hipStreamSynchronize(mg->stream);
+    (void)MGCG_HIP(hipMemcpy(elements, L.elements, sizeof(double) * (size_t)L.nnz, hipMemcpyDeviceToHost));
+    (void)MGCG_HIP(hipMemcpy(columnIndeces, L.columnIndeces, sizeof(int) * (size_t)L.nnz, hipMemcpyDeviceToHost));
+    (void)MGCG_HIP(hipMemcpy(rowOffsets, L.rowOffsets, sizeof(int) * (size_t)(L.n + 1), hipMemcpyDeviceToHost));
+}
+void MgLevelCopyDinv(const MgcgMg* mg, int l, double dinv[])
+{
+    if (!mg || l < 0 || l >= mg->levels) { set_error("MgLevelCopyDinv: bad level"); return; }
+    (void)hipStreamSynchronize(mg->stream);
+    (void)MGCG_HIP(hipMemcpy(dinv, mg->lv[l].dinv, sizeof(double) * (size_t)mg->lv[l].n, hipMemcpyDeviceToHost));
+}
+
+void MgApply(MgcgMg* mg, const double* r, double* z)
+{
+    if (!device_state()) return;
+    if (!mg || !r || !z) { set_error("MgApply: null argument"); return; }
+    mg_apply(mg, r, z, nullptr);
+    (void)MGCG_HIP(hipGetLastError());
+}
+
+int SolveMg(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr, MgcgMg* mg,
+            Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+            Vector* xVector, Vector* bVector, Vector* ApVector, Vector* pVector, Vector* rVector, Vector* zVector,
+            int elementsCount, int count,
+            double allowableResidual, int minIteration, int maxIteration, int rule,
+            int* iteration, double* residual, double* residualTrace, int traceCapacity)
+{
+    (void)matDescr;
+    if (!device_state()) return MGCG_ERROR;
+    if (!cublas || !cusparse || !mg || !zVector) { set_error("SolveMg: null handle"); return MGCG_ERROR; }
+    if (!check_vectors("SolveMg", elementsVector, rowOffsetsVector, columnIndecesVector, xVector, bVector, ApVector, pVector, rVector, elementsCount, count, count)) return MGCG_ERROR;
+    if (zVector->size < count || mg->lv[0].n != count) { set_error("SolveMg: z vector or hierarchy does not match the problem"); return MGCG_ERROR; }
+    if (rule == MGCG_RULE_HANDMADECL || rule == MGCG_RULE_VIENNACL) { set_error("SolveMg supports the 2-norm absolute rules only"); return MGCG_ERROR; }
+    CgRun R;
+    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.mg = mg;
+    R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCount;
+    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data; R.z = zVector->data;
+    R.count = count; R.nLocal = count; R.offset = 0;
+    R.tol = allowableResidual; R.minIt = minIteration; R.maxIt = maxIteration; R.rule = rule;
+    return cg_solve(R, iteration, residual, residualTrace, traceCapacity);
+}
+
+} // extern "C"

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Interleaved A/B sweep of the SpMV kernel variants on the 7-point Poisson matrix (one process,
+rounds interleaved -- cdna_hip_programming.md rule 24).  Prints median/min ms and algorithmic GB/s."""
+import argparse
+import ctypes as C
+import json
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from conjugategradient_amd import _lib  # noqa: E402
+from conjugategradient_amd.solver import VectorDouble, VectorInt  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--variants", default="")
+    a = ap.parse_args()
+    L = _lib.lib()
+    _lib.require_gpu()
+    L.SetDevice(0)
+    blas, sparse, descr = L.CreateBlas(), L.CreateSparse(), L.CreateMatDescr()
+    n = a.grid
+    N = n**3
+    nnz = L.MgcgPoissonNnz(n, n, n, 0, n)
+    e, c, r = VectorDouble(nnz), VectorInt(nnz), VectorInt(N + 1)
+    assert L.MgcgGeneratePoisson(e.Ptr, r.Ptr, c.Ptr, n, n, n, 0, n) == 0
+    x, y = VectorDouble(N), VectorDouble(N)
+    L.MgcgFill(x.Ptr, 1.0)
+    _lib.check("setup")
+    algo = 12 * nnz + 4 * (N + 1) + 16 * N
+    # (label, kernel, rows, flags, grid)
+    variants = [("stream R256", 1, 256, 0, 0), ("stream R256 nt", 1, 256, 1, 0), ("stream R256 xcd", 1, 256, 2, 0),
+                ("stream R256 nt+xcd", 1, 256, 3, 0), ("stream R128", 1, 128, 0, 0), ("stream R64", 1, 64, 0, 0),
+                ("stream R256 g1024", 1, 256, 0, 1024), ("stream R256 g4096", 1, 256, 0, 4096),
+                ("vector 8 lanes", 5, 256, 0, 0), ("vector 4 lanes", 4, 256, 0, 0), ("vector 64 lanes", 8, 256, 0, 0)]
+    if a.variants:
+        keep = set(a.variants.split(","))
+        variants = [v for v in variants if v[0] in keep]
+    ev0, ev1 = L.MgcgEventCreate(), L.MgcgEventCreate()
+    times = {v[0]: [] for v in variants}
+
+    def run(v):
+        L.MgcgSetSpmvKernel(sparse, v[1])
+        L.MgcgSetSpmvTuning(sparse, v[2], v[3], v[4])
+        L.MgcgEventRecord(ev0)
+        for _ in range(a.reps):
+            L.CsrMV(sparse, descr, y.ToRawPtr(), e.ToRawPtr(), r.ToRawPtr(), c.ToRawPtr(), x.ToRawPtr(), nnz, N, N, 1.0, 0.0)
+        L.MgcgEventRecord(ev1)
+        return L.MgcgEventElapsedMs(ev0, ev1) / a.reps
+
+    for v in variants:      # warm-up
+        run(v)
+    for _ in range(a.rounds):
+        for v in variants:
+            times[v[0]].append(run(v))
+    _lib.check("sweep")
+    # attainable copy bandwidth for reference: Copy = hipMemcpyAsync D2D of N doubles (16N bytes moved)
+    L.MgcgEventRecord(ev0)
+    for _ in range(20):
+        L.Copy(blas, y.ToRawPtr(), x.ToRawPtr(), N, 0, 0)
+    L.MgcgEventRecord(ev1)
+    copy_ms = L.MgcgEventElapsedMs(ev0, ev1) / 20
+    L.MgcgEventRecord(ev0)
+    for _ in range(20):
+        L.Axpy(blas, y.ToRawPtr(), x.ToRawPtr(), N, 0.5)
+    L.MgcgEventRecord(ev1)
+    axpy_ms = L.MgcgEventElapsedMs(ev0, ev1) / 20
+    print(f"grid {n}^3 rows {N} nnz {nnz} algorithmic bytes {algo}")
+    print(f"  memcpy D2D {16 * N / copy_ms / 1e6:8.1f} GB/s   axpy {24 * N / axpy_ms / 1e6:8.1f} GB/s")
+    rows = []
+    for v in variants:
+        t = times[v[0]]
+        med, mn = statistics.median(t), min(t)
+        rows.append(dict(variant=v[0], median_ms=med, min_ms=mn, gbps=algo / med / 1e6, frac=algo / med / 1e6 / 8000.0))
+        print(f"  {v[0]:22s} median {med:8.3f} ms  min {mn:8.3f} ms  {algo / med / 1e6:8.1f} GB/s  {algo / med / 1e6 / 80.0:5.1f}% of 8 TB/s")
+    print(json.dumps(dict(grid=n, copy_gbps=16 * N / copy_ms / 1e6, axpy_gbps=24 * N / axpy_ms / 1e6, variants=rows)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,299 @@
+/*
+ * MgcgGpu.h -- C ABI of libMgcgGpu.so, the MI355X (gfx950) replacement for the
+ * reference's native library MgcgGpu.dll (the .cu files under Mgcg/cuBlas/MgcgGpu/), which the
+ * C# solver classes bind with [DllImport(MgcgGpu.DLL_NAME, EntryPoint = "...")]
+ * (Mgcg/cuBlas/Mgcg/MgcgGpu.cs:11).
+ *
+ * Part 1 declares the reference's 32 exports with identical names, argument
+ * order and meaning (each cites the reference definition it replaces).  The
+ * reference's `int&`/`double&` out-parameters are pointers here: identical at
+ * the binary level on x86-64, which is what P/Invoke `out int` relies on.
+ * `_stdcall` is a no-op on x64.
+ *
+ * Part 2 is additive (no reference analogue): error reporting, fused ops, the
+ * device problem generator, the multigrid preconditioner and the
+ * one-process-per-GPU RCCL solver.
+ *
+ * Conventions: plain pointers and sizes only; every function is safe to call
+ * concurrently from different host threads working on different devices; the
+ * current device is per host thread (SetDevice); every call is complete (its
+ * results visible to the host / to later calls) when it returns a value, and
+ * stream-ordered on the device's single stream otherwise (same contract as
+ * cuBLAS/cuSPARSE on the default stream).  Errors never abort: the call
+ * returns 0 / NaN / NULL, and MgcgGetLastError() holds a message.
+ */
+#ifndef MGCG_GPU_H
+#define MGCG_GPU_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Opaque handles.  In the reference these are heap pointers to the vendor
+ * handles (cublasHandle_t*, cusparseHandle_t*, cusparseMatDescr_t*,
+ * thrust::device_vector<T>*); here they are heap pointers to library-owned
+ * structs.  Caller owns them and frees them with the matching Destroy/Delete. */
+typedef struct MgcgBlas     MgcgBlas;      /* stream + reduction workspace           */
+typedef struct MgcgSparse   MgcgSparse;    /* stream + SpMV launch state             */
+typedef struct MgcgMatDescr MgcgMatDescr;  /* general matrix, index base 0           */
+typedef struct Vector       Vector;        /* device double[]  (zero-initialised)    */
+typedef struct VectorInt    VectorInt;     /* device int[]     (zero-initialised)    */
+
+/* ===================================================================== */
+/* Part 1: the reference's exports                                        */
+/* ===================================================================== */
+
+/* ---- Runtime.cu ---- */
+int           GetDeviceCount(void);                                  /* Runtime.cu:7  */
+void          SetDevice(int deviceID);                               /* Runtime.cu:15 */
+MgcgBlas*     CreateBlas(void);                                      /* Runtime.cu:20 */
+void          DestroyBlas(MgcgBlas* cublas);                         /* Runtime.cu:28 */
+MgcgSparse*   CreateSparse(void);                                    /* Runtime.cu:34 */
+void          DestroySparse(MgcgSparse* cusparse);                   /* Runtime.cu:42 */
+MgcgMatDescr* CreateMatDescr(void);                                  /* Runtime.cu:48 */
+void          DestroyMatDescr(MgcgMatDescr* matDescr);               /* Runtime.cu:58 */
+
+/* ---- Vector_Double.cu ---- (counts and offsets in ELEMENTS) */
+Vector* Create_Double(int size);                                                       /* :7  */
+void    CopyToArray_Double(const Vector* source, double destination[],
+                           int count, int sourceOffset, int destinationOffset);        /* :15 */
+void    CopyFromArray_Double(Vector* destination, const double source[],
+                             int count, int sourceOffset, int destinationOffset);      /* :22 */
+void    Delete_Double(Vector* vec);                                                    /* :29 */
+double* ToRawPtr_Double(Vector* vec);                                                  /* :35 */
+/* Vector_Double.cu:41.  The reference passes `count` as the BYTE count to
+ * cudaMemcpy (missing *sizeof(double)); here count is in elements, as the
+ * name and every other export imply. */
+void    CopyFromDevice_Double(const double* source, double* destination,
+                              int count, int sourceOffset, int destinationOffset);
+
+/* ---- Vector_Int.cu ---- */
+VectorInt* Create_Int(int size);                                                       /* :9  */
+void       CopyToArray_Int(const VectorInt* source, int destination[],
+                           int count, int sourceOffset, int destinationOffset);        /* :17 */
+void       CopyFromArray_Int(VectorInt* destination, int source[],
+                             int count, int sourceOffset, int destinationOffset);      /* :24 */
+void       Delete_Int(VectorInt* vec);                                                 /* :31 */
+int*       ToRawPtr_Int(VectorInt* vec);                                               /* :37 */
+
+/* ---- Mgcg.cu: ops on RAW DEVICE POINTERS ---- */
+/* y = alpha*A*x + beta*y, A general CSR, 0-based int32 (Mgcg.cu:10-19, was cusparseDcsrmv_v2).
+ * Columns may be unsorted within a row.  beta == 0 never reads y. */
+void   CsrMV(MgcgSparse* cusparse, MgcgMatDescr* matDescr,
+             double* y,
+             const double* elements, const int* rowOffsets, const int* columnIndeces,
+             const double* x,
+             int elementsCount, int rowCount, int columnCount,
+             double alpha, double beta);
+void   Axpy(MgcgBlas* cublas, double* y, const double* x, int count, double alpha);    /* y += alpha x   Mgcg.cu:22 */
+double Dot(MgcgBlas* cublas, double* y, const double* x, int count);                   /* sum x_i y_i    Mgcg.cu:30 */
+void   Scal(MgcgBlas* cublas, double* x, double alpha, int count);                     /* x *= alpha     Mgcg.cu:41 */
+void   Copy(MgcgBlas* cublas, double* y, const double* x,
+            int count, int yOffset, int xOffset);                                      /* y[yOff..] = x[xOff..]  Mgcg.cu:49 */
+
+/* ---- Mgcg.cu: multi-device partition set-up and halo staging (HOST arrays in) ---- */
+/* Mgcg.cu:57-85: upload rows [offsetForDevice, +countForDevice) of A, rebase the
+ * row offsets by elementOffsetForDevice, upload the x and b slices, seed
+ * p[offsetForDevice..] = x slice, return min/max column id of the slice. */
+void Initialize(const double elements[], const int rowOffsets[], const int columnIndeces[],
+                const double x[], const double b[],
+                Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+                Vector* xVector, Vector* bVector,
+                Vector* pVector,
+                int* minJ, int* maxJ,
+                int count,
+                int countForDevice, int offsetForDevice, int elementCountForDevice, int elementOffsetForDevice);
+/* Mgcg.cu:88-99: publish the first lastCount and last nextCount entries of this
+ * device's slice of p into the shared host array p[]. */
+void P2Host(Vector* pVector, double p[], int thisCount, int thisOffset, int lastCount, int nextCount);
+/* Mgcg.cu:102-113: pull the lastCount entries before and nextCount entries after
+ * this device's slice from the shared host array into pVector. */
+void P2Device(Vector* pVector, double p[], int thisCount, int thisOffset, int lastCount, int nextCount);
+
+/* ---- Mgcg.cu: the CG loop split at its three global-scalar dependencies ---- */
+/* Mgcg.cu:116-142: Ap = A_loc p; r = b - Ap; p[offset..] = r; returns r.r (local) */
+double Solve0(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr,
+              Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+              Vector* xVector, Vector* bVector,
+              Vector* ApVector, Vector* pVector, Vector* rVector,
+              int count,
+              int countForDevice, int offsetForDevice, int elementsCountForDevice);
+/* Mgcg.cu:145-163: Ap = A_loc p; returns p_loc.Ap (local) */
+double Solve1(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr,
+              Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+              Vector* ApVector, Vector* pVector,
+              int count,
+              int countForDevice, int offsetForDevice, int elementsCountForDevice);
+/* Mgcg.cu:166-184: x += alpha p_loc; r -= alpha Ap; returns r.r (local) */
+double Solve2(MgcgBlas* cublas, double alpha,
+              Vector* xVector,
+              Vector* ApVector, Vector* pVector, Vector* rVector,
+              int countForDevice, int offsetForDevice);
+/* Mgcg.cu:187-198: p_loc = beta p_loc + r */
+void   Solve3(MgcgBlas* cublas, double beta,
+              Vector* pVector, Vector* rVector,
+              int countForDevice, int offsetForDevice);
+
+/* Mgcg.cu:201-270: the whole single-device CG.  x is initial guess and result.
+ * *iteration = number of loop bodies executed (last index + 1, as the
+ * reference's post-incremented counter); *residual = sqrt(r.r) of the
+ * recurrence residual.  Stop rule (minIteration <= it) && (residual <
+ * allowableResidual).  Unlike the reference (which never reads maxIteration and
+ * spins forever on NaN), the loop also ends after index maxIteration or on a
+ * non-finite residual; MgcgGetLastError() then says so. */
+void Solve(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr,
+           Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+           Vector* xVector, Vector* bVector,
+           Vector* ApVector, Vector* pVector, Vector* rVector,
+           int elementsCount, int count,
+           double allowableResidual, int minIteration, int maxIteration,
+           int* iteration, double* residual);
+
+/* ===================================================================== */
+/* Part 2: additive exports (no reference analogue)                       */
+/* ===================================================================== */
+
+/* Thread-local message of the last failed call ("" if none); cleared by MgcgClearLastError. */
+const char* MgcgGetLastError(void);
+void        MgcgClearLastError(void);
+/* Library ABI revision. */
+int         MgcgAbiVersion(void);
+/* Wait for the current device's stream.  Returns 0 on success. */
+int         MgcgDeviceSynchronize(void);
+/* Elapsed-time helpers on the current device's stream (HIP events). */
+void*       MgcgEventCreate(void);
+void        MgcgEventRecord(void* ev);
+float       MgcgEventElapsedMs(void* start, void* stop);   /* synchronises on stop */
+void        MgcgEventDestroy(void* ev);
+/* Free / total bytes of HBM on the current device. */
+int         MgcgMemGetInfo(long long* freeBytes, long long* totalBytes);
+/* 64-bit-size vector creation (Create_Double takes int). */
+Vector*     MgcgCreateDouble64(long long size);
+VectorInt*  MgcgCreateInt64(long long size);
+long long   MgcgVectorSize(const Vector* v);
+
+/* ---- extra BLAS-1 / fused ops on raw device pointers ---- */
+/* y = x + beta*y  (the reference's Scal+Axpy pair Mgcg.cu:197,265 in one pass) */
+void   Xpay(MgcgBlas* cublas, double* y, const double* x, int count, double beta);
+/* max_i |x_i|  (HandmadeCL residual norm, Mgcg/HandmadeCL/MgcgCL/Mgcg.cl:110-159) */
+double NrmInf(MgcgBlas* cublas, const double* x, int count);
+/* y = A x and returns sum_i w_i y_i in the same pass (w = the rows' own slice of x in CG) */
+double CsrMVDot(MgcgBlas* cublas, MgcgSparse* cusparse,
+                double* y, const double* elements, const int* rowOffsets, const int* columnIndeces,
+                const double* x, const double* w,
+                int elementsCount, int rowCount, int columnCount);
+/* SpMV kernel selection for CsrMV-family calls on this handle:
+ * 0 auto, 1 row-block LDS stream kernel, 2..8 = 2^(k-2) lanes per row (k=8: one wavefront per row). */
+void   MgcgSetSpmvKernel(MgcgSparse* cusparse, int kernel);
+/* Tuning knobs of the stream kernel: rowsPerBlock in {64,128,256}, flags bit0 = non-temporal matrix
+ * loads, bit1 = XCD-contiguous row-block mapping, gridBlocks (0 = default). */
+void   MgcgSetSpmvTuning(MgcgSparse* cusparse, int rowsPerBlock, int flags, int gridBlocks);
+
+/* Per-launch HIP-event timing of the SpMV kernel inside the Solve.. / CgSteps calls on this handle's stream:
+ * enable, run, then read the summed milliseconds and the number of launches timed. */
+void   MgcgProfileSpmv(MgcgSparse* cusparse, int enable);
+double MgcgProfileSpmvMs(MgcgSparse* cusparse, int* launches);
+
+/* ---- synthetic structured problems generated directly in HBM ---- */
+/* nnz of rows z in [zBegin, zEnd) of the 5/7-point Poisson matrix on nx*ny*nz. */
+long long MgcgPoissonNnz(int nx, int ny, int nz, int zBegin, int zEnd);
+/* Fill the CSR slice for rows with z in [zBegin, zEnd): diagonal 2*dim, off-diagonals -1,
+ * Dirichlet, lexicographic x-fastest, ascending GLOBAL column ids, row offsets rebased to the
+ * slice (as Initialize does).  Vectors must hold MgcgPoissonNnz / rows+1 entries.  Returns 0 on success. */
+int MgcgGeneratePoisson(Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+                        int nx, int ny, int nz, int zBegin, int zEnd);
+/* min / max column id over the first elementCount entries (what Initialize returns as minJ, maxJ;
+ * Mgcg.cu:83-84) for matrices that were generated on the device.  Returns 0 on success. */
+int MgcgMinMaxColumn(VectorInt* columnIndecesVector, int elementCount, int* minJ, int* maxJ);
+/* Fill a device vector with a constant. */
+void MgcgFill(Vector* v, double value);
+
+/* ---- solver with selectable stop rule ---- */
+enum {
+    MGCG_RULE_NATIVE     = 0,  /* Mgcg.cu:251-252   (min <= it) && res < tol                      */
+    MGCG_RULE_CSHARP     = 1,  /* ConjugateGradient.cs:56-79  it<min: no; it>max: error; res<tol  */
+    MGCG_RULE_SIMPLE     = 2,  /* SimpleConjugateGradient.cu:53,107  x:=0; (min < it) && res<tol  */
+    MGCG_RULE_HANDMADECL = 3,  /* HandmadeCL ConjugateGradientCpu.cs:68-95  max-norm, C# rule     */
+    MGCG_RULE_VIENNACL   = 4   /* ViennaCL ComputerGpu.cpp:78  (min < it) && rrNew/rr0 < tol^2    */
+};
+enum { MGCG_OK = 0, MGCG_MAXIT_EXCEEDED = 1, MGCG_NONFINITE = 3, MGCG_ERROR = -1 };
+/* As Solve, plus: rule (above); residualTrace (host, may be NULL) receives the residual of each
+ * iteration up to traceCapacity; returns a status code.  *iteration is the zero-based index of the
+ * last executed loop body (what the C# classes expose as Iteration). */
+int SolveEx(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr,
+            Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+            Vector* xVector, Vector* bVector,
+            Vector* ApVector, Vector* pVector, Vector* rVector,
+            int elementsCount, int count,
+            double allowableResidual, int minIteration, int maxIteration, int rule,
+            int* iteration, double* residual,
+            double* residualTrace, int traceCapacity);
+
+/* ---- multigrid preconditioner (defined by this build; the reference's "Mgcg" never implemented it) ---- */
+typedef struct MgcgMg MgcgMg;
+/* Geometric cell-centred hierarchy on an nx*ny*nz lexicographic grid for the CSR matrix in the
+ * vectors (count = nx*ny*nz rows): piecewise-constant P, R = P^T, A_c = sigma*P^T A P, weighted-Jacobi
+ * V(nu,nu), nuCoarse sweeps on the last level.  levels is clipped to what the grid allows. */
+MgcgMg* MgSetup(MgcgBlas* cublas, MgcgSparse* cusparse,
+                Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+                int elementsCount, int nx, int ny, int nz,
+                int levels, double omega, int nu, int nuCoarse, double sigma);
+void    MgDestroy(MgcgMg* mg);
+int     MgLevels(const MgcgMg* mg);
+/* rows / nnz / grid of level l; copy level l's CSR and D^-1 to host arrays (for tests). */
+long long MgLevelRows(const MgcgMg* mg, int level);
+long long MgLevelNnz(const MgcgMg* mg, int level);
+void    MgLevelCopyCsr(const MgcgMg* mg, int level, double elements[], int columnIndeces[], int rowOffsets[]);
+void    MgLevelCopyDinv(const MgcgMg* mg, int level, double dinv[]);
+/* z = M^-1 r : one V-cycle from a zero guess (raw device pointers, count = level-0 rows). */
+void    MgApply(MgcgMg* mg, const double* r, double* z);
+/* Preconditioned CG with the reference's shell and stop rules; zVector is one more work vector. */
+int     SolveMg(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr, MgcgMg* mg,
+                Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+                Vector* xVector, Vector* bVector,
+                Vector* ApVector, Vector* pVector, Vector* rVector, Vector* zVector,
+                int elementsCount, int count,
+                double allowableResidual, int minIteration, int maxIteration, int rule,
+                int* iteration, double* residual,
+                double* residualTrace, int traceCapacity);
+
+/* ---- one process per GPU: RCCL over xGMI ---- */
+typedef struct MgcgComm MgcgComm;
+/* 128-byte RCCL unique id created on one rank and handed to every rank by the launcher
+ * (torch.distributed store / MPI / a file). Returns 0 on success. */
+int       MgcgCommGetUniqueId(void* id128);
+MgcgComm* MgcgCommInitRank(const void* id128, int nranks, int rank);
+void      MgcgCommDestroy(MgcgComm* comm);
+int       MgcgCommRank(const MgcgComm* comm);
+int       MgcgCommSize(const MgcgComm* comm);
+/* sum of one double over all ranks (test / bootstrap helper; blocking). */
+double    MgcgCommAllReduceSum(MgcgComm* comm, double value);
+/* The whole multi-rank CG of ConjugateGradientParallelGpu.Solve (ConjugateGradientParallelGpu.cs:424-565)
+ * run natively: this rank owns rows [offsetForDevice, +countForDevice) set up by Initialize; pVector is
+ * full length (count).  Halo = the entries of p in [minJ, offset) and [offset+count, maxJ] (exchanged with
+ * grouped ncclSend/ncclRecv between the ranks that own them), dot products = local partial + ncclAllReduce.
+ * comm == NULL means a single rank.  Same outputs and rules as SolveEx. */
+int SolveParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr,
+                  Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+                  Vector* xVector, Vector* bVector,
+                  Vector* ApVector, Vector* pVector, Vector* rVector,
+                  int count, int countForDevice, int offsetForDevice, int elementsCountForDevice,
+                  int minJ, int maxJ,
+                  double allowableResidual, int minIteration, int maxIteration, int rule,
+                  int* iteration, double* residual,
+                  double* residualTrace, int traceCapacity);
+
+/* Fixed number of CG iterations with no stop test and no host synchronisation inside (bench.py's
+ * "steps"): runs `steps` more iterations of the recurrence held in x,r,p (call with restart != 0 first
+ * to compute r = b - A x, p = r, rr).  comm may be NULL.  Returns the residual after the last step. */
+double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
+               Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+               Vector* xVector, Vector* bVector,
+               Vector* ApVector, Vector* pVector, Vector* rVector,
+               int count, int countForDevice, int offsetForDevice, int elementsCountForDevice,
+               int minJ, int maxJ, int steps, int restart);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGCG_GPU_H */

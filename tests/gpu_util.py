@@ -1,0 +1,64 @@
+"""Helpers shared by the -m gpu tests: everything goes through the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from conjugategradient_amd import _lib
+from conjugategradient_amd.solver import VectorDouble, VectorInt
+
+
+class Handles:
+    def __init__(self):
+        L = _lib.lib()
+        _lib.require_gpu()
+        L.SetDevice(0)
+        self.blas = L.CreateBlas()
+        self.sparse = L.CreateSparse()
+        self.descr = L.CreateMatDescr()
+        _lib.check("handles")
+        assert self.blas and self.sparse and self.descr
+
+    def close(self):
+        L = _lib.lib()
+        L.DestroyBlas(self.blas)
+        L.DestroySparse(self.sparse)
+        L.DestroyMatDescr(self.descr)
+
+
+def dvec(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    v = VectorDouble(max(a.shape[0], 1))
+    if a.shape[0]:
+        v.CopyFrom(a, a.shape[0])
+    return v
+
+
+def ivec(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    v = VectorInt(max(a.shape[0], 1))
+    if a.shape[0]:
+        v.CopyFrom(a, a.shape[0])
+    return v
+
+
+class DeviceCsr:
+    def __init__(self, system):
+        self.s = system
+        self.e, self.c, self.r = dvec(system.Elements[: system.nnz]), ivec(system.ColumnIndeces[: system.nnz]), ivec(system.RowOffsets)
+
+    def spmv(self, h, x, alpha=1.0, beta=0.0, y0=None, kernel=None, tuning=None, cols=None):
+        L = _lib.lib()
+        n = self.s.Count
+        vx = dvec(x)
+        vy = dvec(np.zeros(n) if y0 is None else y0)
+        if kernel is not None:
+            L.MgcgSetSpmvKernel(h.sparse, kernel)
+        if tuning is not None:
+            L.MgcgSetSpmvTuning(h.sparse, *tuning)
+        L.CsrMV(h.sparse, h.descr, vy.ToRawPtr(), self.e.ToRawPtr(), self.r.ToRawPtr(), self.c.ToRawPtr(), vx.ToRawPtr(),
+                self.s.nnz, n, n if cols is None else cols, alpha, beta)
+        _lib.check("CsrMV")
+        out = vy.to_numpy(n)
+        L.MgcgSetSpmvKernel(h.sparse, 0)
+        L.MgcgSetSpmvTuning(h.sparse, 256, 0, 0)
+        return out

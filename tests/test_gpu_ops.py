@@ -1,0 +1,174 @@
+"""HIP kernels vs the CPU oracle, through the C ABI (raw-device-pointer ops of Mgcg.cu:10-54)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conjugategradient_amd import _lib, problems
+from tests.gpu_util import DeviceCsr, Handles, dvec, ivec
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def h():
+    hh = Handles()
+    yield hh
+    hh.close()
+
+
+def _systems():
+    yield problems.poisson(37, 29, 1)                 # 5-point, odd sizes
+    yield problems.poisson(20, 17, 13)                # 7-point, ragged row-block tail
+    yield problems.tridiagonal(1000)                  # diag,left,right order (unsorted)
+    yield problems.mgcg_main(3000, 160)               # 159/row, diagonal first
+    yield problems.mgcg_main(700, 24)
+    yield problems.random_spd(5000, mean_upper=14.0, seed=7)
+    yield problems.random_spd(3000, mean_upper=3.0, seed=8, sort_columns=False)
+
+
+@pytest.mark.parametrize("system", list(_systems()), ids=lambda s: s.name)
+def test_csrmv_stream_kernel_is_bit_exact(h, oracle, system):
+    """Row-block LDS kernel: products rounded, added in stored order => identical bits to
+    SparseMatrix.Multiply (SparseMatrix.cs:68-88), for every rows-per-block / mapping variant."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(system.Count)
+    ref = oracle.spmv(system.Elements, system.ColumnIndeces, system.RowOffsets, x)
+    A = DeviceCsr(system)
+    for tuning in [(256, 0, 0), (128, 0, 0), (64, 0, 0), (256, 1, 0), (256, 2, 0), (256, 3, 0), (256, 0, 16)]:
+        y = A.spmv(h, x, kernel=1, tuning=tuning)
+        assert np.array_equal(y, ref), f"tuning {tuning}"
+    y = A.spmv(h, x)                                   # auto selection
+    np.testing.assert_allclose(y, ref, rtol=1e-13, atol=1e-13 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("kernel", [3, 4, 5, 6, 7, 8])
+def test_csrmv_vector_kernels(h, oracle, kernel):
+    """2..64 lanes per row with a shuffle tree: same value up to summation order (rtol 1e-13)."""
+    for system in (problems.mgcg_main(2000, 160), problems.poisson(15, 14, 13), problems.random_spd(4000, seed=5)):
+        x = np.sin(np.arange(system.Count) * 0.11) + 0.5
+        ref = oracle.spmv(system.Elements, system.ColumnIndeces, system.RowOffsets, x)
+        y = DeviceCsr(system).spmv(h, x, kernel=kernel)
+        np.testing.assert_allclose(y, ref, rtol=2e-13, atol=2e-13 * np.abs(ref).max())
+
+
+def test_csrmv_alpha_beta_and_edges(h, oracle):
+    s = problems.poisson(9, 8, 7)
+    rng = np.random.default_rng(11)
+    x, y0 = rng.standard_normal(s.Count), rng.standard_normal(s.Count)
+    Ax = oracle.spmv(s.Elements, s.ColumnIndeces, s.RowOffsets, x)
+    A = DeviceCsr(s)
+    assert np.array_equal(A.spmv(h, x, alpha=2.5, beta=0.0, kernel=1), 2.5 * Ax)
+    assert np.array_equal(A.spmv(h, x, alpha=2.5, beta=-0.75, y0=y0, kernel=1), 2.5 * Ax + (-0.75) * y0)
+    # beta == 0 must not read y (NaN in y does not propagate), as cusparse csrmv
+    assert np.array_equal(A.spmv(h, x, alpha=1.0, beta=0.0, y0=np.full(s.Count, np.nan), kernel=1), Ax)
+    # matrix with empty rows, an empty matrix, and a single row
+    import scipy.sparse as sp
+    M = sp.random(400, 400, density=0.004, random_state=3, format="csr")
+    M.sort_indices()
+    sysm = problems.LinearSystem(M.data.astype(np.float64), M.indices.astype(np.int32), M.indptr.astype(np.int32), np.zeros(400), np.zeros(400), "holes")
+    xv = rng.standard_normal(400)
+    for k in (1, 5, 8):
+        assert np.allclose(DeviceCsr(sysm).spmv(h, xv, kernel=k), oracle.spmv(sysm.Elements, sysm.ColumnIndeces, sysm.RowOffsets, xv), rtol=1e-13, atol=1e-15)
+    assert np.array_equal(DeviceCsr(sysm).spmv(h, xv, kernel=1), oracle.spmv(sysm.Elements, sysm.ColumnIndeces, sysm.RowOffsets, xv))
+    empty = problems.LinearSystem(np.zeros(0), np.zeros(0, np.int32), np.zeros(6, np.int32), np.zeros(5), np.zeros(5), "empty")
+    assert np.array_equal(DeviceCsr(empty).spmv(h, np.ones(5), kernel=1, y0=np.full(5, 7.0)), np.zeros(5))
+
+
+def test_csrmv_unaligned_subarrays(h, oracle):
+    """Raw pointers offset by an odd number of elements (a caller slicing its own arrays)."""
+    L = _lib.lib()
+    s = problems.poisson(13, 11, 5)
+    n, nnz = s.Count, s.nnz
+    e = dvec(np.concatenate([[9.0], s.Elements[:nnz]]))
+    c = ivec(np.concatenate([[0], s.ColumnIndeces[:nnz]]))
+    r = ivec(s.RowOffsets)
+    x = np.cos(np.arange(n) * 0.3)
+    vx, vy = dvec(np.concatenate([[5.0], x])), dvec(np.zeros(n + 1))
+    L.MgcgSetSpmvKernel(h.sparse, 1)
+    L.CsrMV(h.sparse, h.descr, vy.ToRawPtr() + 8, e.ToRawPtr() + 8, r.ToRawPtr(), c.ToRawPtr() + 4, vx.ToRawPtr() + 8, nnz, n, n, 1.0, 0.0)
+    _lib.check("CsrMV")
+    L.MgcgSetSpmvKernel(h.sparse, 0)
+    assert np.array_equal(vy.to_numpy(n + 1)[1:], oracle.spmv(s.Elements, s.ColumnIndeces, s.RowOffsets, x))
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 1001, 4097, 300001])
+def test_blas1(h, oracle, n):
+    L = _lib.lib()
+    rng = np.random.default_rng(n)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    vx, vy = dvec(x), dvec(y)
+    L.Axpy(h.blas, vy.ToRawPtr(), vx.ToRawPtr(), n, 0.37)                 # y += a x  (bit-exact: mul then add)
+    assert np.array_equal(vy.to_numpy(n), oracle.set_added(y, x, 0.37))
+    L.Scal(h.blas, vx.ToRawPtr(), -1.25, n)
+    assert np.array_equal(vx.to_numpy(n), -1.25 * x)
+    vx2, vy2 = dvec(x), dvec(y)
+    L.Xpay(h.blas, vy2.ToRawPtr(), vx2.ToRawPtr(), n, 0.6)                # y = x + b y
+    assert np.array_equal(vy2.to_numpy(n), oracle.set_added(x, y, 0.6))
+    d = L.Dot(h.blas, vy2.ToRawPtr(), vx2.ToRawPtr(), n)
+    ref = oracle.dot(vy2.to_numpy(n), x)
+    assert abs(d - ref) <= 1e-13 * np.abs(vy2.to_numpy(n) * x).sum() + 1e-300
+    assert d == L.Dot(h.blas, vy2.ToRawPtr(), vx2.ToRawPtr(), n)         # run-to-run reproducible
+    assert L.NrmInf(h.blas, vx2.ToRawPtr(), n) == oracle.max_absolute(x)
+    # Copy with element offsets (Mgcg.cu:49-54)
+    if n >= 8:
+        vz = dvec(np.zeros(n))
+        L.Copy(h.blas, vz.ToRawPtr(), vx2.ToRawPtr(), n - 5, 3, 2)
+        out = vz.to_numpy(n)
+        assert np.array_equal(out[3:n - 2], x[2:n - 3]) and np.all(out[:3] == 0)
+        # odd offsets => 8-byte aligned only: scalar path of axpy/dot
+        L.Axpy(h.blas, vz.ToRawPtr() + 8, vx2.ToRawPtr() + 24, n - 4, 2.0)
+        exp = out.copy()
+        exp[1:n - 3] = exp[1:n - 3] + 2.0 * x[3:n - 1]
+        assert np.array_equal(vz.to_numpy(n), exp)
+    _lib.check("blas1")
+
+
+def test_vectors_and_runtime(h):
+    L = _lib.lib()
+    assert L.GetDeviceCount() >= 1
+    v = L.Create_Double(10)
+    out = np.ones(10)
+    L.CopyToArray_Double(v, out.ctypes.data_as(C.c_void_p), 10, 0, 0)
+    assert np.all(out == 0)                                              # device_vector(size) is zero-initialised
+    src = np.arange(10, dtype=np.float64)
+    L.CopyFromArray_Double(v, src.ctypes.data_as(C.c_void_p), 4, 3, 5)   # src[3:7] -> v[5:9]
+    L.CopyToArray_Double(v, out.ctypes.data_as(C.c_void_p), 10, 0, 0)
+    assert list(out) == [0, 0, 0, 0, 0, 3, 4, 5, 6, 0]
+    w = L.Create_Double(10)
+    L.CopyFromDevice_Double(L.ToRawPtr_Double(v), L.ToRawPtr_Double(w), 3, 5, 1)  # count in ELEMENTS (reference bug fixed)
+    L.CopyToArray_Double(w, out.ctypes.data_as(C.c_void_p), 10, 0, 0)
+    assert list(out) == [0, 3, 4, 5, 0, 0, 0, 0, 0, 0]
+    L.CopyToArray_Double(v, out.ctypes.data_as(C.c_void_p), 4, 8, 0)      # out of range -> error, no crash
+    assert "outside vector" in _lib.last_error()
+    L.MgcgClearLastError()
+    L.Delete_Double(v)
+    L.Delete_Double(w)
+    iv = L.Create_Int(5)
+    isrc = np.array([5, 4, 3, 2, 1], dtype=np.int32)
+    L.CopyFromArray_Int(iv, isrc.ctypes.data_as(C.c_void_p), 5, 0, 0)
+    iout = np.zeros(5, dtype=np.int32)
+    L.CopyToArray_Int(iv, iout.ctypes.data_as(C.c_void_p), 5, 0, 0)
+    assert list(iout) == [5, 4, 3, 2, 1]
+    L.Delete_Int(iv)
+
+
+def test_device_generator_matches_host(h):
+    L = _lib.lib()
+    for (nx, ny, nz) in [(8, 6, 4), (5, 7, 1), (16, 16, 16), (3, 2, 2)]:
+        s = problems.poisson(nx, ny, nz)
+        for (z0, z1) in [(0, nz), (0, max(1, nz // 2)), (nz // 2, nz)]:
+            if z1 <= z0:
+                continue
+            nnz = L.MgcgPoissonNnz(nx, ny, nz, z0, z1)
+            rows = (z1 - z0) * nx * ny
+            lo, hi = s.RowOffsets[z0 * nx * ny], s.RowOffsets[z1 * nx * ny]
+            assert nnz == hi - lo
+            e, c, r = dvec(np.zeros(nnz)), ivec(np.zeros(nnz, np.int32)), ivec(np.zeros(rows + 1, np.int32))
+            assert L.MgcgGeneratePoisson(e.Ptr, r.Ptr, c.Ptr, nx, ny, nz, z0, z1) == 0
+            assert np.array_equal(e.to_numpy(nnz), s.Elements[lo:hi])
+            assert np.array_equal(c.to_numpy(nnz), s.ColumnIndeces[lo:hi])
+            assert np.array_equal(r.to_numpy(rows + 1), s.RowOffsets[z0 * nx * ny: z1 * nx * ny + 1] - lo)
+            mn, mx = C.c_int(), C.c_int()
+            assert L.MgcgMinMaxColumn(c.Ptr, nnz, C.byref(mn), C.byref(mx)) == 0
+            assert (mn.value, mx.value) == (int(s.ColumnIndeces[lo:hi].min()), int(s.ColumnIndeces[lo:hi].max()))

@@ -1,0 +1,164 @@
+"""The CPU oracle against the known-answer systems the reference hard-codes and against independent
+dense / scipy solves.  CPU only."""
+import numpy as np
+import pytest
+
+from conjugategradient_amd import problems
+from tests.conftest import golden
+
+
+def test_spmv_matches_scipy_and_is_order_faithful(oracle):
+    s = problems.mgcg_main(300, 40)           # diagonal-first rows: columns are NOT sorted
+    v = np.cos(np.arange(s.Count) * 0.37)
+    y = oracle.spmv(s.Elements, s.ColumnIndeces, s.RowOffsets, v)
+    np.testing.assert_allclose(y, s.to_scipy() @ v, rtol=1e-13)
+    # stored-order, product-rounded-first summation (SparseMatrix.cs:78-85), checked bit for bit
+    for i in (0, 17, 299):
+        acc = 0.0
+        for k in range(s.RowOffsets[i], s.RowOffsets[i + 1]):
+            acc += s.Elements[k] * v[s.ColumnIndeces[k]]
+        assert y[i] == acc
+
+
+def test_blas1_semantics(oracle):
+    rng = np.random.default_rng(1)
+    a, b = rng.standard_normal(1001), rng.standard_normal(1001)
+    acc = 0.0
+    for i in range(1001):
+        acc += a[i] * b[i]
+    assert oracle.dot(a, b) == acc                               # LongVector.cs:15-31 left-to-right
+    assert np.array_equal(oracle.set_added(a, b, 0.3), a + 0.3 * b)   # LongVector.cs:41-51
+    assert oracle.max_absolute(a) == np.abs(a).max()             # LongVector.cs:58-72
+
+
+def test_generators_agree(oracle):
+    for dims in [(7, 5, 1), (6, 5, 4), (1, 1, 1), (16, 16, 16), (2, 2, 2)]:
+        s = problems.poisson(*dims)
+        e, c, r = oracle.poisson_csr(*dims)
+        assert np.array_equal(e, s.Elements) and np.array_equal(c, s.ColumnIndeces) and np.array_equal(r, s.RowOffsets)
+        assert s.nnz == problems.poisson_nnz(*dims)
+    s = problems.mgcg_main(500, 160)
+    e, c, r = oracle.mgcgmain_csr(500, 160)
+    assert np.array_equal(e, s.Elements) and np.array_equal(c, s.ColumnIndeces) and np.array_equal(r, s.RowOffsets)
+    # MgcgMain.cs:59-60: diagonal first, and it equals the row's off-diagonal sum
+    assert all(s.ColumnIndeces[s.RowOffsets[i]] == i for i in range(s.Count))
+    A = s.to_scipy().toarray()
+    assert np.abs(A - A.T).max() == 0.0
+    assert int(np.diff(s.RowOffsets).max()) == 159
+
+
+def test_tridiagonal_rhs_wraps_like_the_reference():
+    s = problems.tridiagonal(65536)
+    assert s.b[3] == 4.5
+    i = 46341                                                    # i*i overflows 32-bit int in the C++ expression
+    assert s.b[i] == float(np.int32(np.int64(i * i) - 2**32)) * 0.5
+    assert s.nnz == 3 * 65536 - 2
+    assert list(s.ColumnIndeces[2:5]) == [1, 0, 2]               # row 1: diag, left, right
+
+
+@pytest.mark.parametrize("name,builder,rule_name,kw", [
+    ("ka1_tridiagonal10", lambda: problems.tridiagonal(10), "RULE_SIMPLE", dict(max_iteration=10, hard_cap=100)),
+    ("ka2_rcg21", lambda: problems.mgcg_main(21, 6, 10.0), "RULE_NATIVE", dict(max_iteration=21, hard_cap=100)),
+    ("ka3_mgcgmain2000", lambda: problems.mgcg_main(2000, 160), "RULE_CSHARP", dict(max_iteration=2000)),
+    ("poisson5_32x32", lambda: problems.poisson(32, 32, 1), "RULE_NATIVE", dict(max_iteration=4096, hard_cap=5000)),
+    ("poisson7_12x12x12", lambda: problems.poisson(12, 12, 12), "RULE_NATIVE", dict(max_iteration=4096, hard_cap=5000)),
+])
+def test_known_answers(oracle, name, builder, rule_name, kw):
+    g = golden(name)
+    s = builder()
+    r = oracle.cg(s, rule=getattr(oracle, rule_name), allowable_residual=1e-8, min_iteration=0, trace=True, **kw)
+    assert r["status"] == oracle.OK
+    assert r["iteration"] == int(g["iteration"])
+    assert r["residual"] == float(g["residual"])
+    assert np.array_equal(r["trace"], g["trace"])
+    assert np.array_equal(r["x"], g["x_cg"])
+    # independent check: the direct (dense / sparse LU) solution
+    scale = np.abs(g["x_direct"]).max()
+    assert np.abs(r["x"] - g["x_direct"]).max() <= 1e-8 * max(scale, 1.0)
+    A = s.to_scipy()
+    assert np.linalg.norm(s.b - A @ r["x"]) < 2e-8
+
+
+def test_survey_scratch_numbers(oracle):
+    """KA-1 stops at index 9, KA-2 at 19 (res 2.3e-9), KA-3 at 26 (res 4.6e-9);
+    5-pt 256^2 at 543, 7-pt 16^3 at 43, 32^3 at 91."""
+    assert oracle.cg(problems.tridiagonal(10), rule=oracle.RULE_SIMPLE, max_iteration=10)["iteration"] == 9
+    r = oracle.cg(problems.mgcg_main(21, 6, 10.0), rule=oracle.RULE_NATIVE, max_iteration=21, hard_cap=50)
+    assert r["iteration"] == 19 and abs(r["residual"] - 2.3e-9) < 1e-10
+    x_direct_head = [7.6291282319, 0.26620308074, -3.9380281738, -1.2208790683]
+    np.testing.assert_allclose(r["x"][:4], x_direct_head, atol=1e-8)
+    r = oracle.cg(problems.mgcg_main(2000, 160), rule=oracle.RULE_CSHARP, max_iteration=2000)
+    assert r["iteration"] == 26 and abs(r["residual"] - 4.6e-9) < 1e-10
+    assert oracle.cg(problems.poisson(256, 256, 1), rule=oracle.RULE_NATIVE, max_iteration=5000, hard_cap=5000)["iteration"] == 543
+    assert oracle.cg(problems.poisson(16, 16, 16), rule=oracle.RULE_NATIVE, max_iteration=5000, hard_cap=5000)["iteration"] == 43
+    assert oracle.cg(problems.poisson(32, 32, 32), rule=oracle.RULE_NATIVE, max_iteration=5000, hard_cap=5000)["iteration"] == 91
+
+
+def test_rule_variants(oracle):
+    s = problems.poisson(12, 12, 12)
+    native = oracle.cg(s, rule=oracle.RULE_NATIVE, max_iteration=500, hard_cap=600)
+    csharp = oracle.cg(s, rule=oracle.RULE_CSHARP, max_iteration=500)
+    assert native["iteration"] == csharp["iteration"] and np.array_equal(native["x"], csharp["x"])
+    # minIteration keeps the loop going (MgcgMain MIN_ITERATION=200 idiom)
+    forced = oracle.cg(s, rule=oracle.RULE_NATIVE, min_iteration=60, max_iteration=500, hard_cap=600)
+    assert forced["iteration"] == 60
+    # `<` instead of `<=` (SimpleConjugateGradient.cu:107) needs one more iteration when min == natural stop
+    simple = oracle.cg(s, rule=oracle.RULE_SIMPLE, min_iteration=native["iteration"], max_iteration=500, hard_cap=600)
+    assert simple["iteration"] == native["iteration"] + 1
+    # C# rule past MaxIteration -> ApplicationException (status), one iteration after the limit
+    bad = oracle.cg(s, rule=oracle.RULE_CSHARP, max_iteration=5)
+    assert bad["status"] == oracle.MAXIT_EXCEEDED and bad["iteration"] == 6
+    # relative rule (ViennaCL) and max-norm rule (HandmadeCL) both converge to the same solution
+    rel = oracle.cg(s, rule=oracle.RULE_VIENNACL, allowable_residual=1e-10, max_iteration=500, hard_cap=600)
+    inf = oracle.cg(s, rule=oracle.RULE_HANDMADECL, allowable_residual=1e-10, max_iteration=500)
+    xd = np.linalg.solve(s.to_scipy().toarray(), s.b)
+    assert np.abs(rel["x"] - xd).max() < 1e-8 and np.abs(inf["x"] - xd).max() < 1e-8
+    # simple rule zero-fills x first (SimpleConjugateGradient.cu:53)
+    s2 = problems.poisson(8, 8, 8)
+    s2.x[:] = 5.0
+    z = oracle.cg(s2, rule=oracle.RULE_SIMPLE, max_iteration=500, hard_cap=600)
+    s2.x[:] = 0.0
+    z0 = oracle.cg(s2, rule=oracle.RULE_SIMPLE, max_iteration=500, hard_cap=600)
+    assert np.array_equal(z["x"], z0["x"])
+
+
+def test_partition_and_parallel_oracle(oracle):
+    assert list(oracle.partition(207402, 8)) == problems.partition_offsets(207402, 8)
+    assert problems.partition_offsets(10, 3) == [0, 3, 6, 10]
+    assert problems.partition_offsets(134217728, 8)[1] == 16777216
+    s = problems.mgcg_main(1200, 160)
+    lo, hi = oracle.minmax_column(s, 400, 800)
+    assert (lo, hi) == (400 - 79, 799 + 79)      # j in [i-79, i+80)
+    serial = oracle.cg(s, rule=oracle.RULE_CSHARP, max_iteration=1200, trace=True)
+    for ndev in (1, 2, 3, 8):
+        par = oracle.cg_parallel(s, ndev, max_iteration=1200, trace=True)
+        assert par["iteration"] == serial["iteration"]
+        np.testing.assert_allclose(par["trace"], serial["trace"], rtol=1e-9)
+        np.testing.assert_allclose(par["x"], serial["x"], rtol=1e-10, atol=1e-13)
+    one = oracle.cg_parallel(s, 1, max_iteration=1200)
+    assert np.array_equal(one["x"], serial["x"])       # one device == the serial order exactly
+
+
+def test_oracle_asan_build_runs():
+    """Sanitizers run on the CPU build only (no GPU ASan on this pool)."""
+    import ctypes
+    import subprocess
+    import sys
+    import os
+    from oracle import oracle as O
+
+    path = O.build(asan=True)
+    code = (
+        "import ctypes, numpy as np, sys; sys.path.insert(0, %r);"
+        "from conjugategradient_amd import problems;"
+        "L = ctypes.CDLL(%r);"
+        "s = problems.poisson(6,5,4); x = s.x.copy(); it = ctypes.c_int(); res = ctypes.c_double();"
+        "dp = np.ctypeslib.ndpointer(np.float64); ip = np.ctypeslib.ndpointer(np.int32);"
+        "L.oracle_cg.argtypes=[dp,ip,ip,ctypes.c_int64,dp,dp,ctypes.c_int,ctypes.c_double,ctypes.c_int,ctypes.c_int,ctypes.c_int64,ctypes.POINTER(ctypes.c_int),ctypes.POINTER(ctypes.c_double),ctypes.c_void_p,ctypes.c_int64,ctypes.c_void_p];"
+        "st = L.oracle_cg(s.Elements,s.ColumnIndeces,s.RowOffsets,s.Count,x,s.b,1,1e-8,0,500,600,ctypes.byref(it),ctypes.byref(res),None,0,None);"
+        "assert st == 0 and res.value < 1e-8; print('asan-ok')"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path)
+    asan_rt = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    env = dict(os.environ, LD_PRELOAD=asan_rt, ASAN_OPTIONS="detect_leaks=0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "asan-ok" in out.stdout, out.stderr[-2000:]
