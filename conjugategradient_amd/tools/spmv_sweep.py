@@ -8,7 +8,7 @@ import os
 import statistics
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from conjugategradient_amd import _lib  # noqa: E402
 from conjugategradient_amd.solver import VectorDouble, VectorInt  # noqa: E402
 
