@@ -97,7 +97,7 @@ struct MgcgSparse {
     mgcg::Workspace ws;
     mgcg::SpmvProfile prof;
     int kernel = 0;          // 0 auto
-    int rowsPerBlock = 256;
+    int rowsPerBlock = 128;
     int flags = 0;           // bit0 nt loads, bit1 xcd-contiguous mapping
     int gridBlocks = 0;
 };
@@ -113,7 +113,8 @@ enum SpmvEpilogue {
     EPI_DOT = 1,     // y = A x ; partial += w_i * y_i
     EPI_RESIDUAL = 2,// y = b - A x
     EPI_JACOBI = 3,  // y = xo + omega*(dinv*(b - A x))
-    EPI_RESIDUAL_DOT = 4 // y = b - A x ; partial += y_i*y_i
+    EPI_RESIDUAL_DOT = 4, // y = b - A x ; partial += y_i*y_i
+    EPI_AXPBY_BETA = 5   // internal: EPI_AXPBY with beta != 0 (reads y)
 };
 
 struct SpmvArgs {
@@ -134,7 +135,7 @@ struct SpmvArgs {
     const int* doneFlag;     // optional: exit at once when *doneFlag != 0
 };
 
-struct SpmvConfig { int kernel = 0; int rowsPerBlock = 256; int flags = 0; int gridBlocks = 0; };
+struct SpmvConfig { int kernel = 0; int rowsPerBlock = 128; int flags = 0; int gridBlocks = 0; };
 
 // Launches the SpMV; returns the number of partials written (grid size) for dot epilogues.
 int launch_spmv(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg);

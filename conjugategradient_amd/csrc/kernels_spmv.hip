@@ -44,39 +44,92 @@ __device__ __forceinline__ double block_sum_256(double v, double* s_red)
     return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
+// Epilogue operands of one row, loaded early (with the gathers) so the epilogue itself issues no load.
+struct EpiOperands { double w, b, dinv, yold; };
+
 template <int EPI>
-__device__ __forceinline__ void spmv_epilogue(const SpmvArgs& a, long long row, double acc, double& dotacc)
+__device__ __forceinline__ EpiOperands epi_prefetch(const SpmvArgs& a, long long row)
+{
+    EpiOperands o; o.w = 0.0; o.b = 0.0; o.dinv = 0.0; o.yold = 0.0;
+    if constexpr (EPI == EPI_AXPBY_BETA) o.yold = a.y[row];
+    if constexpr (EPI == EPI_DOT) o.w = a.w[row];
+    if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_DOT) o.b = a.b[row];
+    if constexpr (EPI == EPI_JACOBI) { o.b = a.b[row]; o.dinv = a.dinv[row]; o.w = a.w[row]; }
+    return o;
+}
+
+template <int EPI>
+__device__ __forceinline__ void spmv_epilogue(const SpmvArgs& a, long long row, double acc, const EpiOperands& o, double& dotacc)
 {
     if constexpr (EPI == EPI_AXPBY) {
+        a.y[row] = a.alpha * acc;
+    } else if constexpr (EPI == EPI_AXPBY_BETA) {
         double v = a.alpha * acc;
-        if (a.beta != 0.0) { double t = a.beta * a.y[row]; v = v + t; }
-        a.y[row] = v;
+        double t = a.beta * o.yold;
+        a.y[row] = v + t;
     } else if constexpr (EPI == EPI_DOT) {
         a.y[row] = acc;
-        double t = a.w[row] * acc;
+        double t = o.w * acc;
         dotacc += t;
     } else if constexpr (EPI == EPI_RESIDUAL) {
-        a.y[row] = a.b[row] - acc;
+        a.y[row] = o.b - acc;
     } else if constexpr (EPI == EPI_RESIDUAL_DOT) {
-        double r = a.b[row] - acc;
+        double r = o.b - acc;
         a.y[row] = r;
         double t = r * r;
         dotacc += t;
     } else if constexpr (EPI == EPI_JACOBI) {
-        double res = a.b[row] - acc;
-        double t = a.dinv[row] * res;
+        double res = o.b - acc;
+        double t = o.dinv * res;
         double s = a.omega * t;
-        a.y[row] = a.w[row] + s;
+        a.y[row] = o.w + s;
     }
 }
 
+// One pipeline stage: the first-pass loads of a row block (CH 16-byte chunks of column ids and values
+// per lane), the lane's own row bounds and the block's nonzero span.
+template <int CH>
+struct StreamStage {
+    i4 col[CH];
+    d2 va[CH], vb[CH];
+    int my_s, my_e;     // nonzero range of this lane's row
+    int s, e;           // nonzero span of the whole row block (wave-uniform)
+};
+
+// In-order sum of s_prod[lo-tb .. hi-tb): LDS reads are issued eight at a time, the adds stay strictly
+// left to right (adding +0.0 for the masked tail is exact: the accumulator is never -0.0).
+template <int CAP>
+__device__ __forceinline__ double reduce_row(const double* s_prod, int lo, int hi, int tb, double acc)
+{
+    for (int j = lo; j < hi; j += 8) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int idx = j + q - tb;
+            idx = idx < CAP - 1 ? idx : CAP - 1;
+            v[q] = s_prod[idx];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += (j + q < hi) ? v[q] : 0.0;
+    }
+    return acc;
+}
+
 // R rows per workgroup, CH 16-byte chunks per lane per pass (pass capacity CAP = 1024*CH nonzeros).
+// Software pipeline per workgroup, one row block per trip:
+//   gathers of x + epilogue operands of block i  ->  wide loads of block i+1  ->  products of i to LDS
+//   ->  barrier  ->  one lane per row adds its products in stored order  ->  store  ->  barrier
+// The matrix stream of the next block is in flight while this block is multiplied and reduced.  vmcnt
+// counts in issue order, so the gathers are issued BEFORE the prefetch and every load in the trip's
+// head is unconditional (clamped addresses instead of branches): the compiler can then wait for the
+// gathers with a counted vmcnt that leaves the prefetch in flight.  Row-block spans are prefetched two
+// trips ahead with scalar loads.
 template <int EPI, int R, int CH, bool NT, bool XCD, bool ALIGNED>
 __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRowBlocks)
 {
     constexpr int CAP = kBlock * 4 * CH;
+    static_assert(R <= kBlock, "one lane per row in the reduce phase");
     __shared__ double s_prod[CAP];
-    __shared__ int s_ro[R + 1];
     __shared__ double s_red[4];
 
     if (a.doneFlag != nullptr && *a.doneFlag != 0) return;
@@ -95,46 +148,86 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRo
     } else {
         rbBegin = blockIdx.x; rbEnd = nRowBlocks; rbStep = gridDim.x;
     }
+    const long long lastRow = (long long)a.rowCount - 1;
+    // last 16-byte-aligned chunk that lies wholly inside the arrays (host guarantees elementsCount >= 4 when ALIGNED)
+    const int kMaxWide = ALIGNED ? ((a.elementsCount - 4) & ~3) : 0;
 
-    double dotacc = 0.0;
-    for (long long rb = rbBegin; rb < rbEnd; rb += rbStep) {
+    auto span_of = [&](long long rb, int& s, int& e) {
         const long long r0 = rb * R;
-        const int nr = (int)(((long long)a.rowCount - r0) < R ? ((long long)a.rowCount - r0) : R);
-        __syncthreads();                       // previous row block is done with s_ro / s_prod
-        for (int t = tid; t <= nr; t += kBlock) s_ro[t] = a.rowOffsets[r0 + t];
-        __syncthreads();
-        const int s = s_ro[0], e = s_ro[nr];
-        int my_s = e, my_e = e;
-        if (tid < nr) { my_s = s_ro[tid]; my_e = s_ro[tid + 1]; }
-        double acc = 0.0;
-        const int tb0 = s & ~3;
-        for (int tb = tb0; tb < e; tb += CAP) {
-            if (tb != tb0) __syncthreads();    // the previous pass has been consumed
-            // ---- load phase: every lane issues all its wide loads, then gathers ----
-            i4 col[CH]; d2 va[CH], vb[CH]; bool wide[CH];
+        const long long r1 = (r0 + R < (long long)a.rowCount) ? r0 + R : (long long)a.rowCount;
+        s = a.rowOffsets[r0];
+        e = a.rowOffsets[r1];
+    };
+    // Issue the first-pass loads of row block rb (st.s / st.e known).  Branch-free: out-of-range lanes
+    // load a clamped, valid address and ignore the result.
+    auto issue = [&](StreamStage<CH>& st, long long rb) {
+        const long long r0 = rb * R;
+        long long row = r0 + tid;
+        const bool live = (tid < R) && (row <= lastRow);
+        row = row <= lastRow ? row : lastRow;
+        const int ms = a.rowOffsets[row], me = a.rowOffsets[row + 1];
+        st.my_s = live ? ms : st.e;
+        st.my_e = live ? me : st.e;
+        if constexpr (ALIGNED) {
+            const int tb0 = st.s & ~3;
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
-                const int k = tb + c * (kBlock * 4) + 4 * tid;
-                wide[c] = ALIGNED && (k < e) && (k + 4 <= a.elementsCount);
-                if (wide[c]) {
-                    col[c] = ld_stream<NT>((const i4*)(a.columnIndeces + k));
-                    va[c] = ld_stream<NT>((const d2*)(a.elements + k));
-                    vb[c] = ld_stream<NT>((const d2*)(a.elements + k + 2));
+                int k = tb0 + c * (kBlock * 4) + 4 * tid;
+                k = k < kMaxWide ? k : kMaxWide;
+                st.col[c] = ld_stream<NT>((const i4*)(a.columnIndeces + k));
+                st.va[c] = ld_stream<NT>((const d2*)(a.elements + k));
+                st.vb[c] = ld_stream<NT>((const d2*)(a.elements + k + 2));
+            }
+        }
+    };
+
+    double dotacc = 0.0;
+    if (rbBegin < rbEnd) {
+        StreamStage<CH> cur, nxt;
+        span_of(rbBegin, cur.s, cur.e);
+        issue(cur, rbBegin);
+        nxt.s = cur.s; nxt.e = cur.e;
+        if (rbBegin + rbStep < rbEnd) span_of(rbBegin + rbStep, nxt.s, nxt.e);
+
+        for (long long rb = rbBegin; rb < rbEnd; rb += rbStep) {
+            const long long r0 = rb * R;
+            const long long left = (long long)a.rowCount - r0;
+            const int nr = (int)(left < R ? left : R);
+            const long long rbn = rb + rbStep, rbnn = rbn + rbStep;
+            int s2 = nxt.s, e2 = nxt.e;
+            if (rbnn < rbEnd) span_of(rbnn, s2, e2);                 // scalar prefetch, two trips ahead
+
+            const int s = cur.s, e = cur.e;
+            const int tb0 = s & ~3;
+            // ---- head of the trip, all loads unconditional ----
+            // (1) gathers for the current block; clamped chunks hold real matrix entries, so the column ids are valid
+            double xg[CH][4];
+            if constexpr (ALIGNED) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    xg[c][0] = a.x[cur.col[c].x]; xg[c][1] = a.x[cur.col[c].y];
+                    xg[c][2] = a.x[cur.col[c].z]; xg[c][3] = a.x[cur.col[c].w];
                 }
             }
+            // (2) epilogue operands of this lane's row
+            long long myRow = r0 + tid;
+            myRow = myRow <= lastRow ? myRow : lastRow;
+            const EpiOperands eo = epi_prefetch<EPI>(a, myRow);
+            // (3) the next block's matrix stream goes in flight behind them (the last trip re-reads its own block)
+            issue(nxt, rbn < rbEnd ? rbn : rb);
+            // ---- products of the current block to LDS ----
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 const int o = c * (kBlock * 4) + 4 * tid;
-                if (wide[c]) {
-                    const double x0 = a.x[col[c].x], x1 = a.x[col[c].y], x2 = a.x[col[c].z], x3 = a.x[col[c].w];
+                const int k = tb0 + o;
+                if (ALIGNED && k <= kMaxWide) {
                     d2 p0, p1;
-                    p0.x = va[c].x * x0; p0.y = va[c].y * x1;
-                    p1.x = vb[c].x * x2; p1.y = vb[c].y * x3;
+                    p0.x = cur.va[c].x * xg[c][0]; p0.y = cur.va[c].y * xg[c][1];
+                    p1.x = cur.vb[c].x * xg[c][2]; p1.y = cur.vb[c].y * xg[c][3];
                     *(d2*)(s_prod + o) = p0;
                     *(d2*)(s_prod + o + 2) = p1;
                 } else if constexpr (ALIGNED) {
                     // last few nonzeros of the arrays (k+4 would overrun elementsCount): guarded scalars
-                    const int k = tb + o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (k + j < e) s_prod[o + j] = a.elements[k + j] * a.x[a.columnIndeces[k + j]];
@@ -143,21 +236,43 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRo
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int oo = c * (kBlock * 4) + j * kBlock + tid;
-                        const int kk = tb + oo;
+                        const int kk = tb0 + oo;
                         if (kk >= s && kk < e) s_prod[oo] = a.elements[kk] * a.x[a.columnIndeces[kk]];
                     }
                 }
             }
             __syncthreads();
-            // ---- reduce phase: one lane per row, stored order ----
-            const int lo = my_s > tb ? my_s : tb;
-            const int hi = my_e < tb + CAP ? my_e : tb + CAP;
-            for (int j = lo; j < hi; ++j) acc += s_prod[j - tb];
+            // ---- reduce: one lane per row, stored order ----
+            double acc = 0.0;
+            {
+                const int lo = cur.my_s > tb0 ? cur.my_s : tb0;
+                const int hi = cur.my_e < tb0 + CAP ? cur.my_e : tb0 + CAP;
+                acc = reduce_row<CAP>(s_prod, lo, hi, tb0, acc);
+            }
+            // ---- further passes for row blocks longer than CAP (long rows): not pipelined ----
+            for (int tb = tb0 + CAP; tb < e; tb += CAP) {
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int oo = c * (kBlock * 4) + j * kBlock + tid;
+                        const int kk = tb + oo;
+                        if (kk < e) s_prod[oo] = a.elements[kk] * a.x[a.columnIndeces[kk]];
+                    }
+                }
+                __syncthreads();
+                const int lo = cur.my_s > tb ? cur.my_s : tb;
+                const int hi = cur.my_e < tb + CAP ? cur.my_e : tb + CAP;
+                acc = reduce_row<CAP>(s_prod, lo, hi, tb, acc);
+            }
+            if (tid < nr) spmv_epilogue<EPI>(a, r0 + tid, acc, eo, dotacc);
+            __syncthreads();                                          // LDS is free for the next trip
+            cur = nxt;
+            nxt.s = s2; nxt.e = e2;
         }
-        if (tid < nr) spmv_epilogue<EPI>(a, r0 + tid, acc, dotacc);
     }
     if constexpr (EPI == EPI_DOT || EPI == EPI_RESIDUAL_DOT) {
-        __syncthreads();
         const double t = block_sum_256(dotacc, s_red);
         if (tid == 0) a.partials[blockIdx.x] = t;
     }
@@ -185,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void spmv_vector_kernel(SpmvArgs a)
         }
 #pragma unroll
         for (int off = LANES / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, LANES);
-        if (sub == 0 && row < a.rowCount) spmv_epilogue<EPI>(a, row, acc, dotacc);
+        if (sub == 0 && row < a.rowCount) { const EpiOperands eo = epi_prefetch<EPI>(a, row); spmv_epilogue<EPI>(a, row, acc, eo, dotacc); }
     }
     if constexpr (EPI == EPI_DOT || EPI == EPI_RESIDUAL_DOT) {
         const double t = block_sum_256(dotacc, s_red);
@@ -195,39 +310,63 @@ __global__ __launch_bounds__(kBlock) void spmv_vector_kernel(SpmvArgs a)
 
 // ------------------------------------------------------------------ launch plumbing
 
+// Resident workgroups per CU for a kernel (occupancy API, cached per instantiation); the grid of a
+// grid-stride kernel is sized to exactly fill the chip so no workgroup waits for a slot.
+template <typename K>
+static int resident_blocks_per_cu(K kernel)
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kBlock, 0) != hipSuccess || n < 1) n = 4;
+    if (n > 8) n = 8;
+    return n;
+}
+
+static int device_cu_count()
+{
+    DeviceState* d = device_state();
+    return d ? d->numCu : kNumCu;
+}
+
+template <int EPI, int R, int CH, bool NT, bool XCD, bool AL>
+static int launch_stream_inst(hipStream_t s, const SpmvArgs& a, int gridReq, int nRowBlocks)
+{
+    static const int perCu = resident_blocks_per_cu(spmv_stream_kernel<EPI, R, CH, NT, XCD, AL>);
+    int grid = gridReq > 0 ? gridReq : perCu * device_cu_count();
+    if (grid > kMaxGrid) grid = kMaxGrid;
+    if (grid > nRowBlocks) grid = nRowBlocks;
+    if (XCD) grid = (grid / kNumXcd) * kNumXcd;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((spmv_stream_kernel<EPI, R, CH, NT, XCD, AL>), dim3(grid), dim3(kBlock), 0, s, a, nRowBlocks);
+    return grid;
+}
+
 template <int EPI, int R, int CH>
-static void launch_stream_rc(hipStream_t s, const SpmvArgs& a, int flags, int grid, int nRowBlocks, bool aligned)
+static int launch_stream_rc(hipStream_t s, const SpmvArgs& a, int flags, int gridReq, int nRowBlocks, bool aligned)
 {
     const bool nt = flags & 1, xcd = flags & 2;
-#define MGCG_GO(NT_, XCD_, AL_) hipLaunchKernelGGL((spmv_stream_kernel<EPI, R, CH, NT_, XCD_, AL_>), dim3(grid), dim3(kBlock), 0, s, a, nRowBlocks)
-    if (!aligned) { if (xcd) MGCG_GO(false, true, false); else MGCG_GO(false, false, false); }
-    else if (nt) { if (xcd) MGCG_GO(true, true, true); else MGCG_GO(true, false, true); }
-    else { if (xcd) MGCG_GO(false, true, true); else MGCG_GO(false, false, true); }
-#undef MGCG_GO
+    if (!aligned) return xcd ? launch_stream_inst<EPI, R, CH, false, true, false>(s, a, gridReq, nRowBlocks)
+                             : launch_stream_inst<EPI, R, CH, false, false, false>(s, a, gridReq, nRowBlocks);
+    if (nt) return xcd ? launch_stream_inst<EPI, R, CH, true, true, true>(s, a, gridReq, nRowBlocks)
+                       : launch_stream_inst<EPI, R, CH, true, false, true>(s, a, gridReq, nRowBlocks);
+    return xcd ? launch_stream_inst<EPI, R, CH, false, true, true>(s, a, gridReq, nRowBlocks)
+               : launch_stream_inst<EPI, R, CH, false, false, true>(s, a, gridReq, nRowBlocks);
 }
 
 template <int EPI>
 static int launch_stream(hipStream_t s, const SpmvArgs& a, const SpmvConfig& cfg)
 {
     int R = cfg.rowsPerBlock;
-    if (R != 64 && R != 128 && R != 256) R = 256;
+    if (R != 64 && R != 128 && R != 256) R = 128;
     const int nRowBlocks = (int)(((long long)a.rowCount + R - 1) / R);
     int flags = cfg.flags;
-    int grid = cfg.gridBlocks > 0 ? cfg.gridBlocks : kMaxGrid;
-    if (grid > nRowBlocks) grid = nRowBlocks;
-    if (grid < 1) grid = 1;
-    if (flags & 2) {                       // XCD mapping needs a multiple of 8 workgroups and enough row blocks
-        if (nRowBlocks < 8 * kNumXcd) flags &= ~2;
-        else grid = (grid / kNumXcd) * kNumXcd;
-    }
-    const bool aligned = (((uintptr_t)a.elements & 15) == 0) && (((uintptr_t)a.columnIndeces & 15) == 0);
-    // pass capacity: 2 chunks (2048 nnz) covers R=256 rows of a 7-point stencil in one pass
+    if ((flags & 2) && nRowBlocks < 8 * kNumXcd) flags &= ~2;    // XCD mapping needs enough row blocks
+    const bool aligned = (((uintptr_t)a.elements & 15) == 0) && (((uintptr_t)a.columnIndeces & 15) == 0) && a.elementsCount >= 4;
+    // pass capacity: 1024 nonzeros covers 128 rows of a 7-point stencil in one pass; 2048 covers 256
     switch (R) {
-    case 64:  launch_stream_rc<EPI, 64, 1>(s, a, flags, grid, nRowBlocks, aligned); break;
-    case 128: launch_stream_rc<EPI, 128, 1>(s, a, flags, grid, nRowBlocks, aligned); break;
-    default:  launch_stream_rc<EPI, 256, 2>(s, a, flags, grid, nRowBlocks, aligned); break;
+    case 64:  return launch_stream_rc<EPI, 64, 1>(s, a, flags, cfg.gridBlocks, nRowBlocks, aligned);
+    case 256: return launch_stream_rc<EPI, 256, 2>(s, a, flags, cfg.gridBlocks, nRowBlocks, aligned);
+    default:  return launch_stream_rc<EPI, 128, 1>(s, a, flags, cfg.gridBlocks, nRowBlocks, aligned);
     }
-    return grid;
 }
 
 template <int EPI, int LANES>
@@ -268,7 +407,7 @@ int launch_spmv(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig
 {
     if (a.rowCount <= 0) return 0;
     switch (epilogue) {
-    case EPI_AXPBY:        return launch_spmv_epi<EPI_AXPBY>(s, a, cfg);
+    case EPI_AXPBY:        return a.beta != 0.0 ? launch_spmv_epi<EPI_AXPBY_BETA>(s, a, cfg) : launch_spmv_epi<EPI_AXPBY>(s, a, cfg);
     case EPI_DOT:          return launch_spmv_epi<EPI_DOT>(s, a, cfg);
     case EPI_RESIDUAL:     return launch_spmv_epi<EPI_RESIDUAL>(s, a, cfg);
     case EPI_RESIDUAL_DOT: return launch_spmv_epi<EPI_RESIDUAL_DOT>(s, a, cfg);

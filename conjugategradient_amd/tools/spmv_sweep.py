@@ -34,10 +34,10 @@ def main():
     _lib.check("setup")
     algo = 12 * nnz + 4 * (N + 1) + 16 * N
     # (label, kernel, rows, flags, grid)
-    variants = [("stream R256", 1, 256, 0, 0), ("stream R256 nt", 1, 256, 1, 0), ("stream R256 xcd", 1, 256, 2, 0),
-                ("stream R256 nt+xcd", 1, 256, 3, 0), ("stream R128", 1, 128, 0, 0), ("stream R64", 1, 64, 0, 0),
-                ("stream R256 g1024", 1, 256, 0, 1024), ("stream R256 g4096", 1, 256, 0, 4096),
-                ("vector 8 lanes", 5, 256, 0, 0), ("vector 4 lanes", 4, 256, 0, 0), ("vector 64 lanes", 8, 256, 0, 0)]
+    variants = [("stream R128", 1, 128, 0, 0), ("stream R128 nt", 1, 128, 1, 0), ("stream R128 xcd", 1, 128, 2, 0),
+                ("stream R64", 1, 64, 0, 0), ("stream R256", 1, 256, 0, 0), ("stream R256 xcd", 1, 256, 2, 0),
+                ("stream R128 g1024", 1, 128, 0, 1024), ("stream R128 g1536", 1, 128, 0, 1536), ("stream R128 g4096", 1, 128, 0, 4096),
+                ("vector 4 lanes", 4, 128, 0, 0), ("vector 8 lanes", 5, 128, 0, 0)]
     if a.variants:
         keep = set(a.variants.split(","))
         variants = [v for v in variants if v[0] in keep]

@@ -60,5 +60,17 @@ class DeviceCsr:
         _lib.check("CsrMV")
         out = vy.to_numpy(n)
         L.MgcgSetSpmvKernel(h.sparse, 0)
-        L.MgcgSetSpmvTuning(h.sparse, 256, 0, 0)
+        L.MgcgSetSpmvTuning(h.sparse, 128, 0, 0)
         return out
+
+
+def assert_trace_close(actual, desired, strict=1e-10, loose=1e-3, floor=1e-6):
+    """Per-iteration residuals of the GPU loop vs the oracle.  The loops differ only in the summation
+    order of the dot products (1e-16 relative per dot); CG amplifies that as the residual falls, so the
+    north-star tolerance (1e-10 relative) is demanded while the residual is above `floor` * its first
+    value and a loose bound below it (round-off dominated region)."""
+    actual, desired = np.asarray(actual), np.asarray(desired)
+    assert len(actual) == len(desired) and len(actual) > 0, (len(actual), len(desired))
+    hi = desired >= floor * desired[0]
+    np.testing.assert_allclose(actual[hi], desired[hi], rtol=strict)
+    np.testing.assert_allclose(actual[~hi], desired[~hi], rtol=loose)
