@@ -78,6 +78,7 @@ SIGNATURES = {
     "CsrMVDot": (_d, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
     "MgcgSetSpmvKernel": (None, [_vp, _i]),
     "MgcgSetSpmvTuning": (None, [_vp, _i, _i, _i]),
+    "MgcgSetSpmvPeriod": (None, [_vp, _i]),
     "MgcgProfileSpmv": (None, [_vp, _i]),
     "MgcgProfileSpmvMs": (_d, [_vp, _pi]),
     "MgcgPoissonNnz": (_ll, [_i, _i, _i, _i, _i]),

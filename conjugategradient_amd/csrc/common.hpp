@@ -98,8 +98,9 @@ struct MgcgSparse {
     mgcg::SpmvProfile prof;
     int kernel = 0;          // 0 auto
     int rowsPerBlock = 128;
-    int flags = 0;           // bit0 nt loads, bit1 xcd-contiguous mapping
+    int flags = 0;           // bit0 nt loads, bit1 xcd-contiguous mapping, bit2 banded schedule (periodRows)
     int gridBlocks = 0;
+    int periodRows = 0;      // rows between strongly coupled windows (a grid plane); 0 = unknown
 };
 struct MgcgMatDescr { int type = 0; int base = 0; };
 struct Vector    { double* data = nullptr; long long size = 0; int device = -1; };
@@ -135,7 +136,7 @@ struct SpmvArgs {
     const int* doneFlag;     // optional: exit at once when *doneFlag != 0
 };
 
-struct SpmvConfig { int kernel = 0; int rowsPerBlock = 128; int flags = 0; int gridBlocks = 0; };
+struct SpmvConfig { int kernel = 0; int rowsPerBlock = 128; int flags = 0; int gridBlocks = 0; int periodRows = 0; };
 
 // Launches the SpMV; returns the number of partials written (grid size) for dot epilogues.
 int launch_spmv(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg);

@@ -124,8 +124,16 @@ __device__ __forceinline__ double reduce_row(const double* s_prod, int lo, int h
 // head is unconditional (clamped addresses instead of branches): the compiler can then wait for the
 // gathers with a counted vmcnt that leaves the prefetch in flight.  Row-block spans are prefetched two
 // trips ahead with scalar loads.
-template <int EPI, int R, int CH, bool NT, bool XCD, bool ALIGNED>
-__global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRowBlocks)
+// MAP selects the row-block schedule of the grid-stride loop:
+//   0  plain: workgroup b takes row blocks b, b+grid, ...
+//   1  each XCD (workgroups b, b+8, ... share one) takes one contiguous eighth of the matrix
+//   2  banded: the matrix couples row i with rows i +- P (P = periodRb row blocks: a grid plane of a 3-D
+//      stencil).  Inside every window of P row blocks XCD k owns the contiguous eighth k, and a
+//      workgroup keeps its position while it steps from window to window, so the +-1 and +-line
+//      neighbours of x are fetched once into that XCD's L2 and the +-plane neighbours are the rows the
+//      same workgroup handled one and two trips ago.
+template <int EPI, int R, int CH, bool NT, int MAP, bool ALIGNED>
+__global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRowBlocks, int periodRb)
 {
     constexpr int CAP = kBlock * 4 * CH;
     static_assert(R <= kBlock, "one lane per row in the reduce phase");
@@ -135,19 +143,46 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRo
     if (a.doneFlag != nullptr && *a.doneFlag != 0) return;
 
     const int tid = threadIdx.x;
-    long long rbBegin, rbEnd, rbStep;
-    if constexpr (XCD) {
-        // Workgroups b and b+8 share an XCD (round-robin dispatch): give each XCD one contiguous
-        // eighth of the row blocks so neighbouring rows' x windows meet in that XCD's L2.
+    // trip t of this workgroup handles row block rbBase + (t / tripsInner) * outerStep + (t % tripsInner) * innerStep
+    long long rbBase, innerStep, outerStep;
+    int tripsInner, nTrips;
+    if constexpr (MAP == 2) {
+        const int xcd = blockIdx.x & (kNumXcd - 1);
+        const int loc = blockIdx.x >> 3;
+        const int perXcd = gridDim.x >> 3;
+        const int T = periodRb >> 3;                         // row blocks per XCD per window
+        const int windows = nRowBlocks / periodRb;           // host guarantees divisibility
+        if (perXcd >= T) {                                   // a window is smaller than the XCD: split the windows Q ways
+            const int Q = perXcd / T;
+            const int l = loc % T, q = loc / T;
+            const int wBeg = (int)((long long)windows * q / Q), wEnd = (int)((long long)windows * (q + 1) / Q);
+            rbBase = (long long)wBeg * periodRb + (long long)xcd * T + l;
+            innerStep = periodRb; outerStep = 0;
+            tripsInner = wEnd - wBeg; nTrips = (q < Q) ? tripsInner : 0;
+            if (tripsInner < 1) tripsInner = 1;
+        } else {                                             // a window is larger: a workgroup takes several positions
+            const int nl = (T - loc + perXcd - 1) / perXcd;
+            rbBase = (long long)xcd * T + loc;
+            innerStep = periodRb; outerStep = perXcd;
+            tripsInner = windows; nTrips = nl * windows;
+        }
+    } else if constexpr (MAP == 1) {
         const int xcd = blockIdx.x & (kNumXcd - 1);
         const int local = blockIdx.x >> 3;
         const int perXcd = gridDim.x >> 3;
-        rbBegin = (long long)nRowBlocks * xcd / kNumXcd + local;
-        rbEnd = (long long)nRowBlocks * (xcd + 1) / kNumXcd;
-        rbStep = perXcd;
+        const long long b = (long long)nRowBlocks * xcd / kNumXcd + local;
+        const long long e = (long long)nRowBlocks * (xcd + 1) / kNumXcd;
+        rbBase = b; innerStep = perXcd; outerStep = 0;
+        nTrips = (e > b) ? (int)((e - b + perXcd - 1) / perXcd) : 0;
+        tripsInner = nTrips > 0 ? nTrips : 1;
     } else {
-        rbBegin = blockIdx.x; rbEnd = nRowBlocks; rbStep = gridDim.x;
+        rbBase = blockIdx.x; innerStep = gridDim.x; outerStep = 0;
+        nTrips = ((long long)nRowBlocks > (long long)blockIdx.x) ? (int)(((long long)nRowBlocks - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
+        tripsInner = nTrips > 0 ? nTrips : 1;
     }
+    auto rb_of = [&](int t) -> long long {
+        return rbBase + (long long)(t / tripsInner) * outerStep + (long long)(t % tripsInner) * innerStep;
+    };
     const long long lastRow = (long long)a.rowCount - 1;
     // last 16-byte-aligned chunk that lies wholly inside the arrays (host guarantees elementsCount >= 4 when ALIGNED)
     const int kMaxWide = ALIGNED ? ((a.elementsCount - 4) & ~3) : 0;
@@ -182,20 +217,20 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRo
     };
 
     double dotacc = 0.0;
-    if (rbBegin < rbEnd) {
+    if (nTrips > 0) {
         StreamStage<CH> cur, nxt;
-        span_of(rbBegin, cur.s, cur.e);
-        issue(cur, rbBegin);
+        span_of(rb_of(0), cur.s, cur.e);
+        issue(cur, rb_of(0));
         nxt.s = cur.s; nxt.e = cur.e;
-        if (rbBegin + rbStep < rbEnd) span_of(rbBegin + rbStep, nxt.s, nxt.e);
+        if (nTrips > 1) span_of(rb_of(1), nxt.s, nxt.e);
 
-        for (long long rb = rbBegin; rb < rbEnd; rb += rbStep) {
+        for (int t = 0; t < nTrips; ++t) {
+            const long long rb = rb_of(t);
             const long long r0 = rb * R;
             const long long left = (long long)a.rowCount - r0;
             const int nr = (int)(left < R ? left : R);
-            const long long rbn = rb + rbStep, rbnn = rbn + rbStep;
             int s2 = nxt.s, e2 = nxt.e;
-            if (rbnn < rbEnd) span_of(rbnn, s2, e2);                 // scalar prefetch, two trips ahead
+            if (t + 2 < nTrips) span_of(rb_of(t + 2), s2, e2);       // scalar prefetch, two trips ahead
 
             const int s = cur.s, e = cur.e;
             const int tb0 = s & ~3;
@@ -214,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRo
             myRow = myRow <= lastRow ? myRow : lastRow;
             const EpiOperands eo = epi_prefetch<EPI>(a, myRow);
             // (3) the next block's matrix stream goes in flight behind them (the last trip re-reads its own block)
-            issue(nxt, rbn < rbEnd ? rbn : rb);
+            issue(nxt, t + 1 < nTrips ? rb_of(t + 1) : rb);
             // ---- products of the current block to LDS ----
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
@@ -327,29 +362,39 @@ static int device_cu_count()
     return d ? d->numCu : kNumCu;
 }
 
-template <int EPI, int R, int CH, bool NT, bool XCD, bool AL>
-static int launch_stream_inst(hipStream_t s, const SpmvArgs& a, int gridReq, int nRowBlocks)
+template <int EPI, int R, int CH, bool NT, int MAP, bool AL>
+static int launch_stream_inst(hipStream_t s, const SpmvArgs& a, int gridReq, int nRowBlocks, int periodRb)
 {
-    static const int perCu = resident_blocks_per_cu(spmv_stream_kernel<EPI, R, CH, NT, XCD, AL>);
+    static const int perCu = resident_blocks_per_cu(spmv_stream_kernel<EPI, R, CH, NT, MAP, AL>);
     int grid = gridReq > 0 ? gridReq : perCu * device_cu_count();
     if (grid > kMaxGrid) grid = kMaxGrid;
-    if (grid > nRowBlocks) grid = nRowBlocks;
-    if (XCD) grid = (grid / kNumXcd) * kNumXcd;
+    if (MAP == 2) {
+        // perXcd workgroups per XCD; a window holds T = periodRb/8 row blocks per XCD
+        const int T = periodRb / kNumXcd;
+        int perXcd = grid / kNumXcd;
+        if (perXcd >= T) perXcd = (perXcd / T) * T;        // whole z-splits only
+        grid = perXcd * kNumXcd;
+    } else {
+        if (grid > nRowBlocks) grid = nRowBlocks;
+        if (MAP == 1) grid = (grid / kNumXcd) * kNumXcd;
+    }
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((spmv_stream_kernel<EPI, R, CH, NT, XCD, AL>), dim3(grid), dim3(kBlock), 0, s, a, nRowBlocks);
+    hipLaunchKernelGGL((spmv_stream_kernel<EPI, R, CH, NT, MAP, AL>), dim3(grid), dim3(kBlock), 0, s, a, nRowBlocks, periodRb);
     return grid;
 }
 
 template <int EPI, int R, int CH>
-static int launch_stream_rc(hipStream_t s, const SpmvArgs& a, int flags, int gridReq, int nRowBlocks, bool aligned)
+static int launch_stream_rc(hipStream_t s, const SpmvArgs& a, int flags, int gridReq, int nRowBlocks, int periodRb, bool aligned)
 {
-    const bool nt = flags & 1, xcd = flags & 2;
-    if (!aligned) return xcd ? launch_stream_inst<EPI, R, CH, false, true, false>(s, a, gridReq, nRowBlocks)
-                             : launch_stream_inst<EPI, R, CH, false, false, false>(s, a, gridReq, nRowBlocks);
-    if (nt) return xcd ? launch_stream_inst<EPI, R, CH, true, true, true>(s, a, gridReq, nRowBlocks)
-                       : launch_stream_inst<EPI, R, CH, true, false, true>(s, a, gridReq, nRowBlocks);
-    return xcd ? launch_stream_inst<EPI, R, CH, false, true, true>(s, a, gridReq, nRowBlocks)
-               : launch_stream_inst<EPI, R, CH, false, false, true>(s, a, gridReq, nRowBlocks);
+    const bool nt = flags & 1;
+    const int map = (flags & 4) ? 2 : ((flags & 2) ? 1 : 0);
+#define MGCG_GO(NT_, MAP_, AL_) return launch_stream_inst<EPI, R, CH, NT_, MAP_, AL_>(s, a, gridReq, nRowBlocks, periodRb)
+    if (!aligned) { if (map == 2) MGCG_GO(false, 2, false); if (map == 1) MGCG_GO(false, 1, false); MGCG_GO(false, 0, false); }
+    if (nt) { if (map == 2) MGCG_GO(true, 2, true); if (map == 1) MGCG_GO(true, 1, true); MGCG_GO(true, 0, true); }
+    if (map == 2) MGCG_GO(false, 2, true);
+    if (map == 1) MGCG_GO(false, 1, true);
+    MGCG_GO(false, 0, true);
+#undef MGCG_GO
 }
 
 template <int EPI>
@@ -360,12 +405,19 @@ static int launch_stream(hipStream_t s, const SpmvArgs& a, const SpmvConfig& cfg
     const int nRowBlocks = (int)(((long long)a.rowCount + R - 1) / R);
     int flags = cfg.flags;
     if ((flags & 2) && nRowBlocks < 8 * kNumXcd) flags &= ~2;    // XCD mapping needs enough row blocks
+    // banded schedule: the period must be whole row blocks, split evenly over the 8 XCDs and tile the matrix
+    int periodRb = 0;
+    if ((flags & 4) && cfg.periodRows > 0 && cfg.periodRows % (R * kNumXcd) == 0 && a.rowCount % R == 0) {
+        periodRb = cfg.periodRows / R;
+        if (nRowBlocks % periodRb != 0 || nRowBlocks / periodRb < 2) periodRb = 0;
+    }
+    if (periodRb == 0) flags &= ~4;
     const bool aligned = (((uintptr_t)a.elements & 15) == 0) && (((uintptr_t)a.columnIndeces & 15) == 0) && a.elementsCount >= 4;
     // pass capacity: 1024 nonzeros covers 128 rows of a 7-point stencil in one pass; 2048 covers 256
     switch (R) {
-    case 64:  return launch_stream_rc<EPI, 64, 1>(s, a, flags, cfg.gridBlocks, nRowBlocks, aligned);
-    case 256: return launch_stream_rc<EPI, 256, 2>(s, a, flags, cfg.gridBlocks, nRowBlocks, aligned);
-    default:  return launch_stream_rc<EPI, 128, 1>(s, a, flags, cfg.gridBlocks, nRowBlocks, aligned);
+    case 64:  return launch_stream_rc<EPI, 64, 1>(s, a, flags, cfg.gridBlocks, nRowBlocks, periodRb, aligned);
+    case 256: return launch_stream_rc<EPI, 256, 2>(s, a, flags, cfg.gridBlocks, nRowBlocks, periodRb, aligned);
+    default:  return launch_stream_rc<EPI, 128, 1>(s, a, flags, cfg.gridBlocks, nRowBlocks, periodRb, aligned);
     }
 }
 

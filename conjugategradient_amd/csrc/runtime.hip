@@ -179,6 +179,7 @@ MgcgSparse* CreateSparse(void)
     const char* r = getenv("MGCG_SPMV_ROWS");         if (r) h->rowsPerBlock = atoi(r);
     const char* f = getenv("MGCG_SPMV_FLAGS");        if (f) h->flags = atoi(f);
     const char* g = getenv("MGCG_SPMV_GRID");         if (g) h->gridBlocks = atoi(g);
+    const char* p = getenv("MGCG_SPMV_PERIOD");       if (p) { h->periodRows = atoi(p); if (h->periodRows > 0) h->flags |= 4; }
     return h;
 }
 void DestroySparse(MgcgSparse* h) { if (!h) return; h->ws.destroy(); delete h; }
@@ -191,6 +192,12 @@ void MgcgSetSpmvTuning(MgcgSparse* h, int rowsPerBlock, int flags, int gridBlock
 {
     if (!h) return;
     h->rowsPerBlock = rowsPerBlock; h->flags = flags; h->gridBlocks = gridBlocks;
+}
+void MgcgSetSpmvPeriod(MgcgSparse* h, int periodRows)
+{
+    if (!h) return;
+    h->periodRows = periodRows;
+    if (periodRows > 0) h->flags |= 4; else h->flags &= ~4;
 }
 
 int MgcgDeviceSynchronize(void)

@@ -21,6 +21,7 @@ struct MgLevel {
     double* dinv = nullptr;
     double *xa = nullptr, *xb = nullptr;   // solution ping-pong (Jacobi is not in place)
     double *b = nullptr, *r = nullptr;     // right-hand side (restricted residual), residual
+    SpmvConfig cfg;                        // per level: kernel picked from its nnz/row, banded period = nx*ny
 };
 
 } // namespace mgcg
@@ -37,7 +38,7 @@ namespace mgcg {
 
 static SpmvConfig cfg_of(const MgcgSparse* h)
 {
-    SpmvConfig c; c.kernel = h->kernel; c.rowsPerBlock = h->rowsPerBlock; c.flags = h->flags; c.gridBlocks = h->gridBlocks;
+    SpmvConfig c; c.kernel = h->kernel; c.rowsPerBlock = h->rowsPerBlock; c.flags = h->flags; c.gridBlocks = h->gridBlocks; c.periodRows = h->periodRows;
     return c;
 }
 
@@ -47,7 +48,7 @@ static void mg_jacobi(MgcgMg* mg, MgLevel& L, const double* b, const double* xin
     a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = xin; a.y = xout;
     a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.n;
     a.w = xin; a.b = b; a.dinv = L.dinv; a.omega = mg->omega; a.doneFlag = done;
-    launch_spmv(mg->stream, EPI_JACOBI, a, mg->cfg);
+    launch_spmv(mg->stream, EPI_JACOBI, a, L.cfg);
 }
 
 // `sweeps` Jacobi sweeps on level L for right-hand side b.  first: the first sweep starts from zero.
@@ -77,7 +78,7 @@ static double* mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double*
     SpmvArgs a{};
     a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = cur; a.y = L.r;
     a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.n; a.b = b; a.doneFlag = done;
-    launch_spmv(mg->stream, EPI_RESIDUAL, a, mg->cfg);                        // r = b - A x
+    launch_spmv(mg->stream, EPI_RESIDUAL, a, L.cfg);                          // r = b - A x
     launch_restrict(mg->stream, L.nx, L.ny, L.nz, L.r, C.b, done);            // b_c = P^T r
     double* e = mg_vcycle(mg, l + 1, C.b, C.xa, C.xb, done);
     launch_prolong_add(mg->stream, L.nx, L.ny, L.nz, cur, e, done);           // x += P e
@@ -466,6 +467,9 @@ MgcgMg* MgSetup(MgcgBlas* cublas, MgcgSparse* cusparse,
             ok = ok && MGCG_HIP(hipMalloc((void**)&L.b, sizeof(double) * (size_t)L.n));
         }
         if (ok) launch_extract_dinv(s, L.elements, L.rowOffsets, L.columnIndeces, L.n, 0, L.dinv);
+        L.cfg = mg->cfg;
+        L.cfg.periodRows = (L.nz > 1) ? L.nx * L.ny : 0;       // far band of a 3-D stencil = one grid plane
+        if (L.cfg.periodRows > 0) L.cfg.flags |= 4; else L.cfg.flags &= ~4;
         mg->lv.push_back(L);
         mg->levels = (int)mg->lv.size();
     }

@@ -186,8 +186,13 @@ double CsrMVDot(MgcgBlas* cublas, MgcgSparse* cusparse,
  * 0 auto, 1 row-block LDS stream kernel, 2..8 = 2^(k-2) lanes per row (k=8: one wavefront per row). */
 void   MgcgSetSpmvKernel(MgcgSparse* cusparse, int kernel);
 /* Tuning knobs of the stream kernel: rowsPerBlock in {64,128,256}, flags bit0 = non-temporal matrix
- * loads, bit1 = XCD-contiguous row-block mapping, gridBlocks (0 = default). */
+ * loads, bit1 = XCD-contiguous row-block mapping, bit2 = banded schedule; gridBlocks (0 = chip-filling default). */
 void   MgcgSetSpmvTuning(MgcgSparse* cusparse, int rowsPerBlock, int flags, int gridBlocks);
+/* Banded schedule hint for the stream kernel: periodRows = distance (in rows) of the far band of the
+ * matrix, e.g. nx*ny for a 3-D stencil (sets flag bit2).  The Solve-family exports detect it themselves;
+ * 0 switches the schedule off.  A period the kernel cannot use (not a multiple of 8 row blocks, not
+ * tiling the matrix) silently falls back to the plain schedule.  Results are identical either way. */
+void   MgcgSetSpmvPeriod(MgcgSparse* cusparse, int periodRows);
 
 /* Per-launch HIP-event timing of the SpMV kernel inside the Solve.. / CgSteps calls on this handle's stream:
  * enable, run, then read the summed milliseconds and the number of launches timed. */

@@ -52,6 +52,25 @@ def test_csrmv_vector_kernels(h, oracle, kernel):
         np.testing.assert_allclose(y, ref, rtol=2e-13, atol=2e-13 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("dims,rows,grid,period", [
+    ((32, 16, 12), 64, 0, 512),        # T = 1 row block per XCD per plane, windows split over the XCD's workgroups
+    ((64, 32, 6), 64, 16, 2048),       # T = 4 > 2 workgroups per XCD: several positions per workgroup
+    ((64, 32, 9), 128, 0, 2048),       # T = 2
+    ((64, 64, 5), 256, 64, 4096),      # R = 256 (two chunks per lane)
+    ((20, 17, 13), 128, 0, 340),       # period the kernel cannot use -> silent fallback, same bits
+])
+def test_csrmv_banded_schedule_is_bit_exact(h, oracle, dims, rows, grid, period):
+    """XCD-aware banded schedule (flag bit2): a different traversal order of the row blocks, identical results."""
+    s = problems.poisson(*dims)
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal(s.Count)
+    ref = oracle.spmv(s.Elements, s.ColumnIndeces, s.RowOffsets, x)
+    y = DeviceCsr(s).spmv(h, x, kernel=1, tuning=(rows, 0, grid), period=period)
+    assert np.array_equal(y, ref)
+    y = DeviceCsr(s).spmv(h, x, kernel=1, tuning=(rows, 1, grid), period=period)      # + non-temporal loads
+    assert np.array_equal(y, ref)
+
+
 def test_csrmv_alpha_beta_and_edges(h, oracle):
     s = problems.poisson(9, 8, 7)
     rng = np.random.default_rng(11)
