@@ -19,6 +19,7 @@ namespace mgcg {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef int    i4 __attribute__((ext_vector_type(4)));
+typedef int    i2 __attribute__((ext_vector_type(2)));
 
 template <bool NT, typename T>
 __device__ __forceinline__ T ld_stream(const T* p)
@@ -88,13 +89,18 @@ __device__ __forceinline__ void spmv_epilogue(const SpmvArgs& a, long long row, 
 
 // One pipeline stage: the first-pass loads of a row block (CH 16-byte chunks of column ids and values
 // per lane), the lane's own row bounds and the block's nonzero span.
+// Layout of a chunk (1024 nonzeros): two halves of 512; in half h lane t owns nonzeros 512*h + 2*t, +1.
+// Every wave-instruction then reads whole, distinct 128-byte lines (64 lanes x 16 B of values = 8 lines,
+// x 8 B of column ids = 4 lines), which is what lets the stream use non-temporal loads: no line is
+// touched by two instructions.
 template <int CH>
 struct StreamStage {
-    i4 col[CH];
-    d2 va[CH], vb[CH];
+    i2 col[CH][2];
+    d2 val[CH][2];
     int my_s, my_e;     // nonzero range of this lane's row
     int s, e;           // nonzero span of the whole row block (wave-uniform)
 };
+constexpr int kSpanAlign = 32;   // row-block spans are read from a 32-nonzero boundary (128 B of column ids, 256 B of values)
 
 // In-order sum of s_prod[lo-tb .. hi-tb): LDS reads are issued eight at a time, the adds stay strictly
 // left to right (adding +0.0 for the masked tail is exact: the accumulator is never -0.0).
@@ -184,8 +190,8 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRo
         return rbBase + (long long)(t / tripsInner) * outerStep + (long long)(t % tripsInner) * innerStep;
     };
     const long long lastRow = (long long)a.rowCount - 1;
-    // last 16-byte-aligned chunk that lies wholly inside the arrays (host guarantees elementsCount >= 4 when ALIGNED)
-    const int kMaxWide = ALIGNED ? ((a.elementsCount - 4) & ~3) : 0;
+    // last aligned pair that lies wholly inside the arrays (host guarantees elementsCount >= 2 when ALIGNED)
+    const int kMaxWide = ALIGNED ? ((a.elementsCount - 2) & ~1) : 0;
 
     auto span_of = [&](long long rb, int& s, int& e) {
         const long long r0 = rb * R;
@@ -204,14 +210,16 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRo
         st.my_s = live ? ms : st.e;
         st.my_e = live ? me : st.e;
         if constexpr (ALIGNED) {
-            const int tb0 = st.s & ~3;
+            const int tb0 = st.s & ~(kSpanAlign - 1);
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
-                int k = tb0 + c * (kBlock * 4) + 4 * tid;
-                k = k < kMaxWide ? k : kMaxWide;
-                st.col[c] = ld_stream<NT>((const i4*)(a.columnIndeces + k));
-                st.va[c] = ld_stream<NT>((const d2*)(a.elements + k));
-                st.vb[c] = ld_stream<NT>((const d2*)(a.elements + k + 2));
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    int k = tb0 + c * (kBlock * 4) + h * (kBlock * 2) + 2 * tid;
+                    k = k < kMaxWide ? k : kMaxWide;
+                    st.col[c][h] = ld_stream<NT>((const i2*)(a.columnIndeces + k));
+                    st.val[c][h] = ld_stream<NT>((const d2*)(a.elements + k));
+                }
             }
         }
     };
@@ -233,15 +241,15 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRo
             if (t + 2 < nTrips) span_of(rb_of(t + 2), s2, e2);       // scalar prefetch, two trips ahead
 
             const int s = cur.s, e = cur.e;
-            const int tb0 = s & ~3;
+            const int tb0 = ALIGNED ? (s & ~(kSpanAlign - 1)) : s;
             // ---- head of the trip, all loads unconditional ----
             // (1) gathers for the current block; clamped chunks hold real matrix entries, so the column ids are valid
-            double xg[CH][4];
+            double xg[CH][2][2];
             if constexpr (ALIGNED) {
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
-                    xg[c][0] = a.x[cur.col[c].x]; xg[c][1] = a.x[cur.col[c].y];
-                    xg[c][2] = a.x[cur.col[c].z]; xg[c][3] = a.x[cur.col[c].w];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) { xg[c][h][0] = a.x[cur.col[c][h].x]; xg[c][h][1] = a.x[cur.col[c][h].y]; }
                 }
             }
             // (2) epilogue operands of this lane's row
@@ -253,26 +261,29 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRo
             // ---- products of the current block to LDS ----
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
-                const int o = c * (kBlock * 4) + 4 * tid;
-                const int k = tb0 + o;
-                if (ALIGNED && k <= kMaxWide) {
-                    d2 p0, p1;
-                    p0.x = cur.va[c].x * xg[c][0]; p0.y = cur.va[c].y * xg[c][1];
-                    p1.x = cur.vb[c].x * xg[c][2]; p1.y = cur.vb[c].y * xg[c][3];
-                    *(d2*)(s_prod + o) = p0;
-                    *(d2*)(s_prod + o + 2) = p1;
-                } else if constexpr (ALIGNED) {
-                    // last few nonzeros of the arrays (k+4 would overrun elementsCount): guarded scalars
+                if constexpr (ALIGNED) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (k + j < e) s_prod[o + j] = a.elements[k + j] * a.x[a.columnIndeces[k + j]];
+                    for (int h = 0; h < 2; ++h) {
+                        const int o = c * (kBlock * 4) + h * (kBlock * 2) + 2 * tid;
+                        const int k = tb0 + o;
+                        if (k <= kMaxWide) {
+                            d2 p;
+                            p.x = cur.val[c][h].x * xg[c][h][0]; p.y = cur.val[c][h].y * xg[c][h][1];
+                            *(d2*)(s_prod + o) = p;
+                        } else {
+                            // last nonzero of an odd-length array: guarded scalars
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                if (k + j < e) s_prod[o + j] = a.elements[k + j] * a.x[a.columnIndeces[k + j]];
+                        }
+                    }
                 } else {
                     // base pointers not 16-byte aligned (a caller-offset sub-array): lane-contiguous scalars
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int oo = c * (kBlock * 4) + j * kBlock + tid;
                         const int kk = tb0 + oo;
-                        if (kk >= s && kk < e) s_prod[oo] = a.elements[kk] * a.x[a.columnIndeces[kk]];
+                        if (kk < e) s_prod[oo] = a.elements[kk] * a.x[a.columnIndeces[kk]];
                     }
                 }
             }
@@ -412,8 +423,10 @@ static int launch_stream(hipStream_t s, const SpmvArgs& a, const SpmvConfig& cfg
         if (nRowBlocks % periodRb != 0 || nRowBlocks / periodRb < 2) periodRb = 0;
     }
     if (periodRb == 0) flags &= ~4;
-    const bool aligned = (((uintptr_t)a.elements & 15) == 0) && (((uintptr_t)a.columnIndeces & 15) == 0) && a.elementsCount >= 4;
-    // pass capacity: 1024 nonzeros covers 128 rows of a 7-point stencil in one pass; 2048 covers 256
+    // The wide path reads pairs from a 32-nonzero boundary of the span: needs 8-byte aligned column ids and
+    // 16-byte aligned values at even nonzero indices.
+    const bool aligned = (((uintptr_t)a.elements & 15) == 0) && (((uintptr_t)a.columnIndeces & 7) == 0) && a.elementsCount >= 2;
+    // pass capacity: 1024 nonzeros covers 128 rows of a 7-point stencil (896 + <=31 of alignment) in one pass
     switch (R) {
     case 64:  return launch_stream_rc<EPI, 64, 1>(s, a, flags, cfg.gridBlocks, nRowBlocks, periodRb, aligned);
     case 256: return launch_stream_rc<EPI, 256, 2>(s, a, flags, cfg.gridBlocks, nRowBlocks, periodRb, aligned);
