@@ -79,6 +79,7 @@ SIGNATURES = {
     "MgcgSetSpmvKernel": (None, [_vp, _i]),
     "MgcgSetSpmvTuning": (None, [_vp, _i, _i, _i]),
     "MgcgSetSpmvPeriod": (None, [_vp, _i]),
+    "MgcgSetSpmvTile": (None, [_vp, _i, _i]),
     "MgcgProfileSpmv": (None, [_vp, _i]),
     "MgcgProfileSpmvMs": (_d, [_vp, _pi]),
     "MgcgPoissonNnz": (_ll, [_i, _i, _i, _i, _i]),

@@ -101,6 +101,7 @@ struct MgcgSparse {
     int flags = 0;           // bit0 nt loads, bit1 xcd-contiguous mapping, bit2 banded schedule (periodRows)
     int gridBlocks = 0;
     int periodRows = 0;      // rows between strongly coupled windows (a grid plane); 0 = unknown
+    int tileRows = 0, tilePlanes = 0;   // banded schedule tile (0 = default)
 };
 struct MgcgMatDescr { int type = 0; int base = 0; };
 struct Vector    { double* data = nullptr; long long size = 0; int device = -1; };
@@ -136,7 +137,7 @@ struct SpmvArgs {
     const int* doneFlag;     // optional: exit at once when *doneFlag != 0
 };
 
-struct SpmvConfig { int kernel = 0; int rowsPerBlock = 128; int flags = 0; int gridBlocks = 0; int periodRows = 0; };
+struct SpmvConfig { int kernel = 0; int rowsPerBlock = 128; int flags = 0; int gridBlocks = 0; int periodRows = 0; int tileRows = 0; int tilePlanes = 0; };
 
 // Launches the SpMV; returns the number of partials written (grid size) for dot epilogues.
 int launch_spmv(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg);

@@ -134,12 +134,12 @@ __device__ __forceinline__ double reduce_row(const double* s_prod, int lo, int h
 //   0  plain: workgroup b takes row blocks b, b+grid, ...
 //   1  each XCD (workgroups b, b+8, ... share one) takes one contiguous eighth of the matrix
 //   2  banded: the matrix couples row i with rows i +- P (P = periodRb row blocks: a grid plane of a 3-D
-//      stencil).  Inside every window of P row blocks XCD k owns the contiguous eighth k, and a
-//      workgroup keeps its position while it steps from window to window, so the +-1 and +-line
-//      neighbours of x are fetched once into that XCD's L2 and the +-plane neighbours are the rows the
-//      same workgroup handled one and two trips ago.
+//      stencil).  Inside every window of P row blocks XCD k owns the contiguous eighth k; its resident
+//      workgroups cover tileRb neighbouring row blocks of zPar consecutive windows at a time, so the
+//      +-1 / +-line neighbours of x and the +-plane neighbours are all in flight in the same XCD's L2
+//      together (x is fetched ~(zPar+2)/zPar * (lines+2)/lines times instead of 5+ times).
 template <int EPI, int R, int CH, bool NT, int MAP, bool ALIGNED>
-__global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRowBlocks, int periodRb)
+__global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRowBlocks, int periodRb, int tileRb, int zPar)
 {
     constexpr int CAP = kBlock * 4 * CH;
     static_assert(R <= kBlock, "one lane per row in the reduce phase");
@@ -153,25 +153,19 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRo
     long long rbBase, innerStep, outerStep;
     int tripsInner, nTrips;
     if constexpr (MAP == 2) {
+        // XCD k owns the contiguous eighth k of every window (grid plane).  Its workgroups form a tile of
+        // tileRb neighbouring row blocks x zPar consecutive windows that advances zPar windows per trip;
+        // when the sweep over the windows ends the tile moves on inside the XCD's eighth.
+        // Host guarantees: gridDim.x == 8*tileRb*zPar, (periodRb/8) % tileRb == 0, windows % zPar == 0.
         const int xcd = blockIdx.x & (kNumXcd - 1);
         const int loc = blockIdx.x >> 3;
-        const int perXcd = gridDim.x >> 3;
-        const int T = periodRb >> 3;                         // row blocks per XCD per window
-        const int windows = nRowBlocks / periodRb;           // host guarantees divisibility
-        if (perXcd >= T) {                                   // a window is smaller than the XCD: split the windows Q ways
-            const int Q = perXcd / T;
-            const int l = loc % T, q = loc / T;
-            const int wBeg = (int)((long long)windows * q / Q), wEnd = (int)((long long)windows * (q + 1) / Q);
-            rbBase = (long long)wBeg * periodRb + (long long)xcd * T + l;
-            innerStep = periodRb; outerStep = 0;
-            tripsInner = wEnd - wBeg; nTrips = (q < Q) ? tripsInner : 0;
-            if (tripsInner < 1) tripsInner = 1;
-        } else {                                             // a window is larger: a workgroup takes several positions
-            const int nl = (T - loc + perXcd - 1) / perXcd;
-            rbBase = (long long)xcd * T + loc;
-            innerStep = periodRb; outerStep = perXcd;
-            tripsInner = windows; nTrips = nl * windows;
-        }
+        const int eighth = periodRb >> 3;
+        const int windows = nRowBlocks / periodRb;
+        const int l = loc % tileRb, q = loc / tileRb;
+        rbBase = (long long)q * periodRb + (long long)xcd * eighth + l;
+        innerStep = (long long)zPar * periodRb; outerStep = tileRb;
+        tripsInner = windows / zPar;
+        nTrips = (eighth / tileRb) * tripsInner;
     } else if constexpr (MAP == 1) {
         const int xcd = blockIdx.x & (kNumXcd - 1);
         const int local = blockIdx.x >> 3;
@@ -374,35 +368,54 @@ static int device_cu_count()
 }
 
 template <int EPI, int R, int CH, bool NT, int MAP, bool AL>
-static int launch_stream_inst(hipStream_t s, const SpmvArgs& a, int gridReq, int nRowBlocks, int periodRb)
+static int launch_stream_inst(hipStream_t s, const SpmvArgs& a, const SpmvConfig& cfg, int nRowBlocks, int periodRb)
 {
     static const int perCu = resident_blocks_per_cu(spmv_stream_kernel<EPI, R, CH, NT, MAP, AL>);
-    int grid = gridReq > 0 ? gridReq : perCu * device_cu_count();
+    int grid = cfg.gridBlocks > 0 ? cfg.gridBlocks : perCu * device_cu_count();
     if (grid > kMaxGrid) grid = kMaxGrid;
+    int tileRb = 0, zPar = 0;
     if (MAP == 2) {
-        // perXcd workgroups per XCD; a window holds T = periodRb/8 row blocks per XCD
-        const int T = periodRb / kNumXcd;
+        // choose the tile: tileRb row blocks (a power-of-two fraction of the XCD's eighth) x zPar windows = perXcd workgroups
+        const int eighth = periodRb / kNumXcd, windows = nRowBlocks / periodRb;
         int perXcd = grid / kNumXcd;
-        if (perXcd >= T) perXcd = (perXcd / T) * T;        // whole z-splits only
-        grid = perXcd * kNumXcd;
+        if (perXcd < 1) perXcd = 1;
+        tileRb = cfg.tileRows > 0 ? cfg.tileRows / R : 0;
+        if (tileRb < 1 || eighth % tileRb != 0 || tileRb > perXcd) {
+            tileRb = eighth;
+            const int want = perXcd >= 64 ? perXcd / 8 : perXcd;       // default: about 8 windows in flight per XCD
+            while (tileRb > want && tileRb % 2 == 0) tileRb /= 2;
+            while (tileRb > perXcd && tileRb % 2 == 0) tileRb /= 2;
+        }
+        zPar = cfg.tilePlanes > 0 ? cfg.tilePlanes : perXcd / tileRb;
+        if (zPar < 1) zPar = 1;
+        if (zPar > windows) zPar = windows;
+        while (zPar > 1 && (windows % zPar != 0 || tileRb * zPar > perXcd)) --zPar;
+        if (tileRb > perXcd) { tileRb = 0; }                           // cannot tile: handled by the caller's fallback
+        grid = kNumXcd * tileRb * zPar;
     } else {
         if (grid > nRowBlocks) grid = nRowBlocks;
         if (MAP == 1) grid = (grid / kNumXcd) * kNumXcd;
     }
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((spmv_stream_kernel<EPI, R, CH, NT, MAP, AL>), dim3(grid), dim3(kBlock), 0, s, a, nRowBlocks, periodRb);
+    if (grid < 1) return -1;
+    hipLaunchKernelGGL((spmv_stream_kernel<EPI, R, CH, NT, MAP, AL>), dim3(grid), dim3(kBlock), 0, s, a, nRowBlocks, periodRb, tileRb, zPar);
     return grid;
 }
 
 template <int EPI, int R, int CH>
-static int launch_stream_rc(hipStream_t s, const SpmvArgs& a, int flags, int gridReq, int nRowBlocks, int periodRb, bool aligned)
+static int launch_stream_rc(hipStream_t s, const SpmvArgs& a, int flags, const SpmvConfig& cfg, int nRowBlocks, int periodRb, bool aligned)
 {
     const bool nt = flags & 1;
     const int map = (flags & 4) ? 2 : ((flags & 2) ? 1 : 0);
-#define MGCG_GO(NT_, MAP_, AL_) return launch_stream_inst<EPI, R, CH, NT_, MAP_, AL_>(s, a, gridReq, nRowBlocks, periodRb)
-    if (!aligned) { if (map == 2) MGCG_GO(false, 2, false); if (map == 1) MGCG_GO(false, 1, false); MGCG_GO(false, 0, false); }
-    if (nt) { if (map == 2) MGCG_GO(true, 2, true); if (map == 1) MGCG_GO(true, 1, true); MGCG_GO(true, 0, true); }
-    if (map == 2) MGCG_GO(false, 2, true);
+    if (map == 2) {     // banded schedule; if the tile cannot be formed fall through to the plain schedule
+        int g = -1;
+        if (!aligned) g = launch_stream_inst<EPI, R, CH, false, 2, false>(s, a, cfg, nRowBlocks, periodRb);
+        else if (nt) g = launch_stream_inst<EPI, R, CH, true, 2, true>(s, a, cfg, nRowBlocks, periodRb);
+        else g = launch_stream_inst<EPI, R, CH, false, 2, true>(s, a, cfg, nRowBlocks, periodRb);
+        if (g > 0) return g;
+    }
+#define MGCG_GO(NT_, MAP_, AL_) return launch_stream_inst<EPI, R, CH, NT_, MAP_, AL_>(s, a, cfg, nRowBlocks, periodRb)
+    if (!aligned) { if (map == 1) MGCG_GO(false, 1, false); MGCG_GO(false, 0, false); }
+    if (nt) { if (map == 1) MGCG_GO(true, 1, true); MGCG_GO(true, 0, true); }
     if (map == 1) MGCG_GO(false, 1, true);
     MGCG_GO(false, 0, true);
 #undef MGCG_GO
@@ -428,9 +441,9 @@ static int launch_stream(hipStream_t s, const SpmvArgs& a, const SpmvConfig& cfg
     const bool aligned = (((uintptr_t)a.elements & 15) == 0) && (((uintptr_t)a.columnIndeces & 7) == 0) && a.elementsCount >= 2;
     // pass capacity: 1024 nonzeros covers 128 rows of a 7-point stencil (896 + <=31 of alignment) in one pass
     switch (R) {
-    case 64:  return launch_stream_rc<EPI, 64, 1>(s, a, flags, cfg.gridBlocks, nRowBlocks, periodRb, aligned);
-    case 256: return launch_stream_rc<EPI, 256, 2>(s, a, flags, cfg.gridBlocks, nRowBlocks, periodRb, aligned);
-    default:  return launch_stream_rc<EPI, 128, 1>(s, a, flags, cfg.gridBlocks, nRowBlocks, periodRb, aligned);
+    case 64:  return launch_stream_rc<EPI, 64, 1>(s, a, flags, cfg, nRowBlocks, periodRb, aligned);
+    case 256: return launch_stream_rc<EPI, 256, 2>(s, a, flags, cfg, nRowBlocks, periodRb, aligned);
+    default:  return launch_stream_rc<EPI, 128, 1>(s, a, flags, cfg, nRowBlocks, periodRb, aligned);
     }
 }
 

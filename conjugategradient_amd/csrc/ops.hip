@@ -14,7 +14,7 @@ __global__ void set_alpha_kernel(CgScalars* sc, double alpha, double beta)
 
 static SpmvConfig cfg_of(const MgcgSparse* h)
 {
-    SpmvConfig c; c.kernel = h->kernel; c.rowsPerBlock = h->rowsPerBlock; c.flags = h->flags; c.gridBlocks = h->gridBlocks; c.periodRows = h->periodRows;
+    SpmvConfig c; c.kernel = h->kernel; c.rowsPerBlock = h->rowsPerBlock; c.flags = h->flags; c.gridBlocks = h->gridBlocks; c.periodRows = h->periodRows; c.tileRows = h->tileRows; c.tilePlanes = h->tilePlanes;
     return c;
 }
 

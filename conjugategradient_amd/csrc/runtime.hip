@@ -179,6 +179,8 @@ MgcgSparse* CreateSparse(void)
     const char* r = getenv("MGCG_SPMV_ROWS");         if (r) h->rowsPerBlock = atoi(r);
     const char* f = getenv("MGCG_SPMV_FLAGS");        if (f) h->flags = atoi(f);
     const char* g = getenv("MGCG_SPMV_GRID");         if (g) h->gridBlocks = atoi(g);
+    const char* tr = getenv("MGCG_SPMV_TILE_ROWS");   if (tr) h->tileRows = atoi(tr);
+    const char* tp = getenv("MGCG_SPMV_TILE_PLANES"); if (tp) h->tilePlanes = atoi(tp);
     const char* p = getenv("MGCG_SPMV_PERIOD");       if (p) { h->periodRows = atoi(p); if (h->periodRows > 0) h->flags |= 4; }
     return h;
 }
@@ -198,6 +200,11 @@ void MgcgSetSpmvPeriod(MgcgSparse* h, int periodRows)
     if (!h) return;
     h->periodRows = periodRows;
     if (periodRows > 0) h->flags |= 4; else h->flags &= ~4;
+}
+void MgcgSetSpmvTile(MgcgSparse* h, int tileRows, int tilePlanes)
+{
+    if (!h) return;
+    h->tileRows = tileRows; h->tilePlanes = tilePlanes;
 }
 
 int MgcgDeviceSynchronize(void)

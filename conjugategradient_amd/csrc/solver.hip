@@ -38,7 +38,7 @@ namespace mgcg {
 
 static SpmvConfig cfg_of(const MgcgSparse* h)
 {
-    SpmvConfig c; c.kernel = h->kernel; c.rowsPerBlock = h->rowsPerBlock; c.flags = h->flags; c.gridBlocks = h->gridBlocks; c.periodRows = h->periodRows;
+    SpmvConfig c; c.kernel = h->kernel; c.rowsPerBlock = h->rowsPerBlock; c.flags = h->flags; c.gridBlocks = h->gridBlocks; c.periodRows = h->periodRows; c.tileRows = h->tileRows; c.tilePlanes = h->tilePlanes;
     return c;
 }
 

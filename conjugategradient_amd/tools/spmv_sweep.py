@@ -34,11 +34,14 @@ def main():
     _lib.check("setup")
     algo = 12 * nnz + 4 * (N + 1) + 16 * N
     # (label, kernel, rows, flags, grid)
-    variants = [("stream R128 band", 1, 128, 4, 0), ("stream R128 band nt", 1, 128, 5, 0), ("stream R256 band", 1, 256, 4, 0),
-                ("stream R128", 1, 128, 0, 0), ("stream R128 nt", 1, 128, 1, 0), ("stream R128 xcd", 1, 128, 2, 0),
-                ("stream R64", 1, 64, 0, 0), ("stream R256", 1, 256, 0, 0), ("stream R256 xcd", 1, 256, 2, 0),
-                ("stream R128 g1024", 1, 128, 0, 1024), ("stream R128 g1536", 1, 128, 0, 1536), ("stream R128 g4096", 1, 128, 0, 4096),
-                ("vector 4 lanes", 4, 128, 0, 0), ("vector 8 lanes", 5, 128, 0, 0)]
+    # (label, kernel, rows, flags, grid, tileRows, tilePlanes)
+    variants = [("stream R128", 1, 128, 0, 0, 0, 0), ("stream R128 nt", 1, 128, 1, 0, 0, 0),
+                ("band default", 1, 128, 4, 0, 0, 0), ("band default nt", 1, 128, 5, 0, 0, 0),
+                ("band 64L x1", 1, 128, 4, 0, 64 * n, 1), ("band 16L x4", 1, 128, 4, 0, 16 * n, 4),
+                ("band 8L x8", 1, 128, 4, 0, 8 * n, 8), ("band 8L x8 nt", 1, 128, 5, 0, 8 * n, 8),
+                ("band 4L x16", 1, 128, 4, 0, 4 * n, 16), ("band 2L x32", 1, 128, 4, 0, 2 * n, 32), ("band 2L x32 nt", 1, 128, 5, 0, 2 * n, 32),
+                ("band 1L x64", 1, 128, 4, 0, n, 64), ("band R256 8L x4", 1, 256, 4, 0, 8 * n, 4),
+                ("vector 4 lanes", 4, 128, 0, 0, 0, 0)]
     if a.variants:
         keep = set(a.variants.split(","))
         variants = [v for v in variants if v[0] in keep]
@@ -49,6 +52,7 @@ def main():
         L.MgcgSetSpmvKernel(sparse, v[1])
         L.MgcgSetSpmvTuning(sparse, v[2], v[3], v[4])
         L.MgcgSetSpmvPeriod(sparse, n * n if (v[3] & 4) else 0)
+        L.MgcgSetSpmvTile(sparse, v[5], v[6])
         L.MgcgEventRecord(ev0)
         for _ in range(a.reps):
             L.CsrMV(sparse, descr, y.ToRawPtr(), e.ToRawPtr(), r.ToRawPtr(), c.ToRawPtr(), x.ToRawPtr(), nnz, N, N, 1.0, 0.0)

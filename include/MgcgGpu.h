@@ -193,6 +193,9 @@ void   MgcgSetSpmvTuning(MgcgSparse* cusparse, int rowsPerBlock, int flags, int 
  * 0 switches the schedule off.  A period the kernel cannot use (not a multiple of 8 row blocks, not
  * tiling the matrix) silently falls back to the plain schedule.  Results are identical either way. */
 void   MgcgSetSpmvPeriod(MgcgSparse* cusparse, int periodRows);
+/* Tile of the banded schedule: tileRows neighbouring rows x tilePlanes consecutive windows are in flight
+ * per XCD at a time (0, 0 = the library's default).  Pure scheduling: results do not change. */
+void   MgcgSetSpmvTile(MgcgSparse* cusparse, int tileRows, int tilePlanes);
 
 /* Per-launch HIP-event timing of the SpMV kernel inside the Solve.. / CgSteps calls on this handle's stream:
  * enable, run, then read the summed milliseconds and the number of launches timed. */

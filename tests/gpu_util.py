@@ -46,7 +46,7 @@ class DeviceCsr:
         self.s = system
         self.e, self.c, self.r = dvec(system.Elements[: system.nnz]), ivec(system.ColumnIndeces[: system.nnz]), ivec(system.RowOffsets)
 
-    def spmv(self, h, x, alpha=1.0, beta=0.0, y0=None, kernel=None, tuning=None, cols=None, period=0):
+    def spmv(self, h, x, alpha=1.0, beta=0.0, y0=None, kernel=None, tuning=None, cols=None, period=0, tile=(0, 0)):
         L = _lib.lib()
         n = self.s.Count
         vx = dvec(x)
@@ -56,6 +56,7 @@ class DeviceCsr:
         if tuning is not None:
             L.MgcgSetSpmvTuning(h.sparse, *tuning)
         L.MgcgSetSpmvPeriod(h.sparse, period)
+        L.MgcgSetSpmvTile(h.sparse, *tile)
         L.CsrMV(h.sparse, h.descr, vy.ToRawPtr(), self.e.ToRawPtr(), self.r.ToRawPtr(), self.c.ToRawPtr(), vx.ToRawPtr(),
                 self.s.nnz, n, n if cols is None else cols, alpha, beta)
         _lib.check("CsrMV")
@@ -63,6 +64,7 @@ class DeviceCsr:
         L.MgcgSetSpmvKernel(h.sparse, 0)
         L.MgcgSetSpmvTuning(h.sparse, 128, 0, 0)
         L.MgcgSetSpmvPeriod(h.sparse, 0)
+        L.MgcgSetSpmvTile(h.sparse, 0, 0)
         return out
 
 

@@ -52,22 +52,25 @@ def test_csrmv_vector_kernels(h, oracle, kernel):
         np.testing.assert_allclose(y, ref, rtol=2e-13, atol=2e-13 * np.abs(ref).max())
 
 
-@pytest.mark.parametrize("dims,rows,grid,period", [
-    ((32, 16, 12), 64, 0, 512),        # T = 1 row block per XCD per plane, windows split over the XCD's workgroups
-    ((64, 32, 6), 64, 16, 2048),       # T = 4 > 2 workgroups per XCD: several positions per workgroup
-    ((64, 32, 9), 128, 0, 2048),       # T = 2
-    ((64, 64, 5), 256, 64, 4096),      # R = 256 (two chunks per lane)
-    ((20, 17, 13), 128, 0, 340),       # period the kernel cannot use -> silent fallback, same bits
+@pytest.mark.parametrize("dims,rows,grid,period,tile", [
+    ((32, 16, 12), 64, 0, 512, (0, 0)),        # 1 row block per XCD per plane, many planes in flight
+    ((64, 32, 6), 64, 16, 2048, (0, 0)),       # 4 row blocks per XCD per plane but only 2 workgroups per XCD
+    ((64, 32, 9), 128, 0, 2048, (0, 0)),       # planes not divisible by the default plane count
+    ((64, 64, 6), 256, 64, 4096, (0, 0)),      # R = 256 (two chunks per lane)
+    ((64, 64, 8), 64, 0, 4096, (128, 4)),      # explicit tile: 2 row blocks x 4 planes
+    ((64, 64, 8), 64, 0, 4096, (512, 1)),      # explicit tile: the whole eighth, one plane
+    ((64, 64, 8), 64, 0, 4096, (192, 3)),      # tile that does not divide -> default tile
+    ((20, 17, 13), 128, 0, 340, (0, 0)),       # period the kernel cannot use -> silent fallback, same bits
 ])
-def test_csrmv_banded_schedule_is_bit_exact(h, oracle, dims, rows, grid, period):
+def test_csrmv_banded_schedule_is_bit_exact(h, oracle, dims, rows, grid, period, tile):
     """XCD-aware banded schedule (flag bit2): a different traversal order of the row blocks, identical results."""
     s = problems.poisson(*dims)
     rng = np.random.default_rng(17)
     x = rng.standard_normal(s.Count)
     ref = oracle.spmv(s.Elements, s.ColumnIndeces, s.RowOffsets, x)
-    y = DeviceCsr(s).spmv(h, x, kernel=1, tuning=(rows, 0, grid), period=period)
+    y = DeviceCsr(s).spmv(h, x, kernel=1, tuning=(rows, 0, grid), period=period, tile=tile)
     assert np.array_equal(y, ref)
-    y = DeviceCsr(s).spmv(h, x, kernel=1, tuning=(rows, 1, grid), period=period)      # + non-temporal loads
+    y = DeviceCsr(s).spmv(h, x, kernel=1, tuning=(rows, 1, grid), period=period, tile=tile)      # + non-temporal loads
     assert np.array_equal(y, ref)
 
 
