@@ -23,6 +23,7 @@ constexpr int kBlock = 256;          // threads per workgroup for every streamin
 constexpr int kNumXcd = 8;
 constexpr int kNumCu = 256;
 constexpr int kMaxGrid = kNumCu * 8; // 8 resident 256-thread workgroups per CU (32 waves/CU)
+constexpr int kMaxPartials = kNumCu * 32; // single-wavefront workgroups: up to 32 per CU, one partial sum each
 constexpr int kMaxDevices = 64;
 
 // ---------------------------------------------------------------- errors

@@ -121,7 +121,8 @@ __device__ __forceinline__ double reduce_row(const double* s_prod, int lo, int h
     return acc;
 }
 
-// R rows per workgroup, CH 16-byte chunks per lane per pass (pass capacity CAP = 1024*CH nonzeros).
+// BLOCK threads per workgroup (256, or 64: a single wavefront, whose barriers cost nothing), R rows per
+// workgroup, CH chunks of 4 nonzeros per lane per pass (pass capacity CAP = 4*BLOCK*CH nonzeros).
 // Software pipeline per workgroup, one row block per trip:
 //   gathers of x + epilogue operands of block i  ->  wide loads of block i+1  ->  products of i to LDS
 //   ->  barrier  ->  one lane per row adds its products in stored order  ->  store  ->  barrier
@@ -138,13 +139,13 @@ __device__ __forceinline__ double reduce_row(const double* s_prod, int lo, int h
 //      workgroups cover tileRb neighbouring row blocks of zPar consecutive windows at a time, so the
 //      +-1 / +-line neighbours of x and the +-plane neighbours are all in flight in the same XCD's L2
 //      together (x is fetched ~(zPar+2)/zPar * (lines+2)/lines times instead of 5+ times).
-template <int EPI, int R, int CH, bool NT, int MAP, bool ALIGNED>
-__global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRowBlocks, int periodRb, int tileRb, int zPar)
+template <int EPI, int BLOCK, int R, int CH, bool NT, int MAP, bool ALIGNED>
+__global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs a, int nRowBlocks, int periodRb, int tileRb, int zPar)
 {
-    constexpr int CAP = kBlock * 4 * CH;
-    static_assert(R <= kBlock, "one lane per row in the reduce phase");
+    constexpr int CAP = BLOCK * 4 * CH;
+    static_assert(R <= BLOCK, "one lane per row in the reduce phase");
     __shared__ double s_prod[CAP];
-    __shared__ double s_red[4];
+    __shared__ double s_red[BLOCK / 64];
 
     if (a.doneFlag != nullptr && *a.doneFlag != 0) return;
 
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRo
             for (int c = 0; c < CH; ++c) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    int k = tb0 + c * (kBlock * 4) + h * (kBlock * 2) + 2 * tid;
+                    int k = tb0 + c * (BLOCK * 4) + h * (BLOCK * 2) + 2 * tid;
                     k = k < kMaxWide ? k : kMaxWide;
                     st.col[c][h] = ld_stream<NT>((const i2*)(a.columnIndeces + k));
                     st.val[c][h] = ld_stream<NT>((const d2*)(a.elements + k));
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRo
                 if constexpr (ALIGNED) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const int o = c * (kBlock * 4) + h * (kBlock * 2) + 2 * tid;
+                        const int o = c * (BLOCK * 4) + h * (BLOCK * 2) + 2 * tid;
                         const int k = tb0 + o;
                         if (k <= kMaxWide) {
                             d2 p;
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRo
                     // base pointers not 16-byte aligned (a caller-offset sub-array): lane-contiguous scalars
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int oo = c * (kBlock * 4) + j * kBlock + tid;
+                        const int oo = c * (BLOCK * 4) + j * BLOCK + tid;
                         const int kk = tb0 + oo;
                         if (kk < e) s_prod[oo] = a.elements[kk] * a.x[a.columnIndeces[kk]];
                     }
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRo
                 for (int c = 0; c < CH; ++c) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int oo = c * (kBlock * 4) + j * kBlock + tid;
+                        const int oo = c * (BLOCK * 4) + j * BLOCK + tid;
                         const int kk = tb + oo;
                         if (kk < e) s_prod[oo] = a.elements[kk] * a.x[a.columnIndeces[kk]];
                     }
@@ -313,7 +314,12 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, int nRo
         }
     }
     if constexpr (EPI == EPI_DOT || EPI == EPI_RESIDUAL_DOT) {
-        const double t = block_sum_256(dotacc, s_red);
+        double t = wave_sum(dotacc);
+        if constexpr (BLOCK > 64) {
+            if ((tid & 63) == 0) s_red[tid >> 6] = t;
+            __syncthreads();
+            t = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        }
         if (tid == 0) a.partials[blockIdx.x] = t;
     }
 }
@@ -353,11 +359,12 @@ __global__ __launch_bounds__(kBlock) void spmv_vector_kernel(SpmvArgs a)
 // Resident workgroups per CU for a kernel (occupancy API, cached per instantiation); the grid of a
 // grid-stride kernel is sized to exactly fill the chip so no workgroup waits for a slot.
 template <typename K>
-static int resident_blocks_per_cu(K kernel)
+static int resident_blocks_per_cu(K kernel, int block)
 {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kBlock, 0) != hipSuccess || n < 1) n = 4;
-    if (n > 8) n = 8;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, 0) != hipSuccess || n < 1) n = 4;
+    const int cap = 2048 / block;          // 32 waves per CU
+    if (n > cap) n = cap;
     return n;
 }
 
@@ -367,12 +374,12 @@ static int device_cu_count()
     return d ? d->numCu : kNumCu;
 }
 
-template <int EPI, int R, int CH, bool NT, int MAP, bool AL>
+template <int EPI, int BLOCK, int R, int CH, bool NT, int MAP, bool AL>
 static int launch_stream_inst(hipStream_t s, const SpmvArgs& a, const SpmvConfig& cfg, int nRowBlocks, int periodRb)
 {
-    static const int perCu = resident_blocks_per_cu(spmv_stream_kernel<EPI, R, CH, NT, MAP, AL>);
+    static const int perCu = resident_blocks_per_cu(spmv_stream_kernel<EPI, BLOCK, R, CH, NT, MAP, AL>, BLOCK);
     int grid = cfg.gridBlocks > 0 ? cfg.gridBlocks : perCu * device_cu_count();
-    if (grid > kMaxGrid) grid = kMaxGrid;
+    if (grid > kMaxPartials) grid = kMaxPartials;
     int tileRb = 0, zPar = 0;
     if (MAP == 2) {
         // choose the tile: tileRb row blocks (a power-of-two fraction of the XCD's eighth) x zPar windows = perXcd workgroups
@@ -382,11 +389,9 @@ static int launch_stream_inst(hipStream_t s, const SpmvArgs& a, const SpmvConfig
         tileRb = cfg.tileRows > 0 ? cfg.tileRows / R : 0;
         if (tileRb < 1 || eighth % tileRb != 0 || tileRb > perXcd) {
             tileRb = eighth;
-            const int want = perXcd >= 64 ? perXcd / 8 : perXcd;       // default: about 8 windows in flight per XCD
-            while (tileRb > want && tileRb % 2 == 0) tileRb /= 2;
-            while (tileRb > perXcd && tileRb % 2 == 0) tileRb /= 2;
+            while (tileRb > perXcd && tileRb % 2 == 0) tileRb /= 2;    // default: the widest tile, one window at a time
         }
-        zPar = cfg.tilePlanes > 0 ? cfg.tilePlanes : perXcd / tileRb;
+        zPar = cfg.tilePlanes > 0 ? cfg.tilePlanes : perXcd / (tileRb > 0 ? tileRb : 1);
         if (zPar < 1) zPar = 1;
         if (zPar > windows) zPar = windows;
         while (zPar > 1 && (windows % zPar != 0 || tileRb * zPar > perXcd)) --zPar;
@@ -397,23 +402,23 @@ static int launch_stream_inst(hipStream_t s, const SpmvArgs& a, const SpmvConfig
         if (MAP == 1) grid = (grid / kNumXcd) * kNumXcd;
     }
     if (grid < 1) return -1;
-    hipLaunchKernelGGL((spmv_stream_kernel<EPI, R, CH, NT, MAP, AL>), dim3(grid), dim3(kBlock), 0, s, a, nRowBlocks, periodRb, tileRb, zPar);
+    hipLaunchKernelGGL((spmv_stream_kernel<EPI, BLOCK, R, CH, NT, MAP, AL>), dim3(grid), dim3(BLOCK), 0, s, a, nRowBlocks, periodRb, tileRb, zPar);
     return grid;
 }
 
-template <int EPI, int R, int CH>
+template <int EPI, int BLOCK, int R, int CH>
 static int launch_stream_rc(hipStream_t s, const SpmvArgs& a, int flags, const SpmvConfig& cfg, int nRowBlocks, int periodRb, bool aligned)
 {
     const bool nt = flags & 1;
     const int map = (flags & 4) ? 2 : ((flags & 2) ? 1 : 0);
     if (map == 2) {     // banded schedule; if the tile cannot be formed fall through to the plain schedule
         int g = -1;
-        if (!aligned) g = launch_stream_inst<EPI, R, CH, false, 2, false>(s, a, cfg, nRowBlocks, periodRb);
-        else if (nt) g = launch_stream_inst<EPI, R, CH, true, 2, true>(s, a, cfg, nRowBlocks, periodRb);
-        else g = launch_stream_inst<EPI, R, CH, false, 2, true>(s, a, cfg, nRowBlocks, periodRb);
+        if (!aligned) g = launch_stream_inst<EPI, BLOCK, R, CH, false, 2, false>(s, a, cfg, nRowBlocks, periodRb);
+        else if (nt) g = launch_stream_inst<EPI, BLOCK, R, CH, true, 2, true>(s, a, cfg, nRowBlocks, periodRb);
+        else g = launch_stream_inst<EPI, BLOCK, R, CH, false, 2, true>(s, a, cfg, nRowBlocks, periodRb);
         if (g > 0) return g;
     }
-#define MGCG_GO(NT_, MAP_, AL_) return launch_stream_inst<EPI, R, CH, NT_, MAP_, AL_>(s, a, cfg, nRowBlocks, periodRb)
+#define MGCG_GO(NT_, MAP_, AL_) return launch_stream_inst<EPI, BLOCK, R, CH, NT_, MAP_, AL_>(s, a, cfg, nRowBlocks, periodRb)
     if (!aligned) { if (map == 1) MGCG_GO(false, 1, false); MGCG_GO(false, 0, false); }
     if (nt) { if (map == 1) MGCG_GO(true, 1, true); MGCG_GO(true, 0, true); }
     if (map == 1) MGCG_GO(false, 1, true);
@@ -421,11 +426,13 @@ static int launch_stream_rc(hipStream_t s, const SpmvArgs& a, int flags, const S
 #undef MGCG_GO
 }
 
+// rowsPerBlock selects the workgroup shape: 64 -> one wavefront per 64 rows (no barriers), 128 -> 256 threads
+// per 128 rows, 256 -> 256 threads per 256 rows, 32 -> one wavefront per 32 rows.
 template <int EPI>
 static int launch_stream(hipStream_t s, const SpmvArgs& a, const SpmvConfig& cfg)
 {
     int R = cfg.rowsPerBlock;
-    if (R != 64 && R != 128 && R != 256) R = 128;
+    if (R != 32 && R != 64 && R != 128 && R != 256) R = 128;
     const int nRowBlocks = (int)(((long long)a.rowCount + R - 1) / R);
     int flags = cfg.flags;
     if ((flags & 2) && nRowBlocks < 8 * kNumXcd) flags &= ~2;    // XCD mapping needs enough row blocks
@@ -439,11 +446,12 @@ static int launch_stream(hipStream_t s, const SpmvArgs& a, const SpmvConfig& cfg
     // The wide path reads pairs from a 32-nonzero boundary of the span: needs 8-byte aligned column ids and
     // 16-byte aligned values at even nonzero indices.
     const bool aligned = (((uintptr_t)a.elements & 15) == 0) && (((uintptr_t)a.columnIndeces & 7) == 0) && a.elementsCount >= 2;
-    // pass capacity: 1024 nonzeros covers 128 rows of a 7-point stencil (896 + <=31 of alignment) in one pass
+    // pass capacity 4*BLOCK*CH must cover R rows of a 7-point stencil plus <=31 nonzeros of alignment in one pass
     switch (R) {
-    case 64:  return launch_stream_rc<EPI, 64, 1>(s, a, flags, cfg, nRowBlocks, periodRb, aligned);
-    case 256: return launch_stream_rc<EPI, 256, 2>(s, a, flags, cfg, nRowBlocks, periodRb, aligned);
-    default:  return launch_stream_rc<EPI, 128, 1>(s, a, flags, cfg, nRowBlocks, periodRb, aligned);
+    case 32:  return launch_stream_rc<EPI, 64, 32, 1>(s, a, flags, cfg, nRowBlocks, periodRb, aligned);     // 224+31 <= 256
+    case 64:  return launch_stream_rc<EPI, 64, 64, 2>(s, a, flags, cfg, nRowBlocks, periodRb, aligned);     // 448+31 <= 512
+    case 256: return launch_stream_rc<EPI, 256, 256, 2>(s, a, flags, cfg, nRowBlocks, periodRb, aligned);   // 1792+31 <= 2048
+    default:  return launch_stream_rc<EPI, 256, 128, 1>(s, a, flags, cfg, nRowBlocks, periodRb, aligned);   // 896+31 <= 1024
     }
 }
 

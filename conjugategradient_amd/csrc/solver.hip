@@ -185,7 +185,7 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
     prof_mark(R, false);
     launch_reduce_to(s, R.ws->partials, n, &sc->pAp, done);
     if (R.nranks > 1 && !comm_allreduce_sum(R.comm, &sc->pAp, 1, s)) return false;   // (:499)
-    double* pInf = R.wantInf ? R.ws->partials + kMaxGrid : nullptr;
+    double* pInf = R.wantInf ? R.ws->partials + kMaxPartials : nullptr;
     n = launch_update_xr(s, sc, R.x, R.r, pLoc, R.Ap, R.nLocal, R.ws->partials, pInf);   // x += a p ; r -= a Ap ; r.r  (:246-248)
     FinalizeArgs f{};
     f.sc = sc; f.mirror = R.ws->mirror; f.trace = R.ws->trace; f.traceCap = R.ws->traceCap;

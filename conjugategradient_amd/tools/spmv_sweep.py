@@ -35,13 +35,11 @@ def main():
     algo = 12 * nnz + 4 * (N + 1) + 16 * N
     # (label, kernel, rows, flags, grid)
     # (label, kernel, rows, flags, grid, tileRows, tilePlanes)
-    variants = [("stream R128", 1, 128, 0, 0, 0, 0), ("stream R128 nt", 1, 128, 1, 0, 0, 0),
-                ("band default", 1, 128, 4, 0, 0, 0), ("band default nt", 1, 128, 5, 0, 0, 0),
-                ("band 64L x1", 1, 128, 4, 0, 64 * n, 1), ("band 16L x4", 1, 128, 4, 0, 16 * n, 4),
-                ("band 8L x8", 1, 128, 4, 0, 8 * n, 8), ("band 8L x8 nt", 1, 128, 5, 0, 8 * n, 8),
-                ("band 4L x16", 1, 128, 4, 0, 4 * n, 16), ("band 2L x32", 1, 128, 4, 0, 2 * n, 32), ("band 2L x32 nt", 1, 128, 5, 0, 2 * n, 32),
-                ("band 1L x64", 1, 128, 4, 0, n, 64), ("band R256 8L x4", 1, 256, 4, 0, 8 * n, 4),
-                ("vector 4 lanes", 4, 128, 0, 0, 0, 0)]
+    variants = [("wg256 R128", 1, 128, 0, 0, 0, 0), ("wg256 R256", 1, 256, 0, 0, 0, 0),
+                ("wave R64", 1, 64, 0, 0, 0, 0), ("wave R64 nt", 1, 64, 1, 0, 0, 0), ("wave R32", 1, 32, 0, 0, 0, 0), ("wave R32 nt", 1, 32, 1, 0, 0, 0),
+                ("wave R32 g4096", 1, 32, 0, 4096, 0, 0), ("wave R64 g4096", 1, 64, 0, 4096, 0, 0),
+                ("wave R64 band", 1, 64, 4, 0, 0, 0), ("wave R32 band", 1, 32, 4, 0, 0, 0), ("wave R32 band 8Lx8", 1, 32, 4, 0, 8 * n, 8),
+                ("wg256 band 64Lx1", 1, 128, 4, 0, 64 * n, 1), ("vector 4 lanes", 4, 128, 0, 0, 0, 0)]
     if a.variants:
         keep = set(a.variants.split(","))
         variants = [v for v in variants if v[0] in keep]

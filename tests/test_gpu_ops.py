@@ -35,7 +35,7 @@ def test_csrmv_stream_kernel_is_bit_exact(h, oracle, system):
     x = rng.standard_normal(system.Count)
     ref = oracle.spmv(system.Elements, system.ColumnIndeces, system.RowOffsets, x)
     A = DeviceCsr(system)
-    for tuning in [(256, 0, 0), (128, 0, 0), (64, 0, 0), (256, 1, 0), (256, 2, 0), (256, 3, 0), (256, 0, 16)]:
+    for tuning in [(256, 0, 0), (128, 0, 0), (64, 0, 0), (32, 0, 0), (32, 1, 24), (64, 2, 0), (256, 1, 0), (256, 2, 0), (256, 3, 0), (256, 0, 16)]:
         y = A.spmv(h, x, kernel=1, tuning=tuning)
         assert np.array_equal(y, ref), f"tuning {tuning}"
     y = A.spmv(h, x)                                   # auto selection
@@ -58,6 +58,7 @@ def test_csrmv_vector_kernels(h, oracle, kernel):
     ((64, 32, 9), 128, 0, 2048, (0, 0)),       # planes not divisible by the default plane count
     ((64, 64, 6), 256, 64, 4096, (0, 0)),      # R = 256 (two chunks per lane)
     ((64, 64, 8), 64, 0, 4096, (128, 4)),      # explicit tile: 2 row blocks x 4 planes
+    ((64, 64, 8), 32, 0, 4096, (128, 2)),      # single-wavefront workgroups of 32 rows
     ((64, 64, 8), 64, 0, 4096, (512, 1)),      # explicit tile: the whole eighth, one plane
     ((64, 64, 8), 64, 0, 4096, (192, 3)),      # tile that does not divide -> default tile
     ((20, 17, 13), 128, 0, 340, (0, 0)),       # period the kernel cannot use -> silent fallback, same bits
