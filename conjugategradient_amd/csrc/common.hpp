@@ -136,6 +136,7 @@ struct SpmvArgs {
     double omega;            // EPI_JACOBI
     double* partials;        // EPI_DOT / EPI_RESIDUAL_DOT: one double per workgroup
     const int* doneFlag;     // optional: exit at once when *doneFlag != 0
+    int ablate;              // diagnostics only (tools/spmv_sweep.py --ablate): bit0 skip the y store, bit1 gathers from L1
 };
 
 struct SpmvConfig { int kernel = 0; int rowsPerBlock = 128; int flags = 0; int gridBlocks = 0; int periodRows = 0; int tileRows = 0; int tilePlanes = 0; };

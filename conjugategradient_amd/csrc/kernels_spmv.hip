@@ -244,7 +244,11 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs a, int nRow
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) { xg[c][h][0] = a.x[cur.col[c][h].x]; xg[c][h][1] = a.x[cur.col[c][h].y]; }
+                    for (int h = 0; h < 2; ++h) {
+                        int c0 = cur.col[c][h].x, c1 = cur.col[c][h].y;
+                        if (a.ablate & 2) { c0 &= 1023; c1 &= 1023; }      // diagnostic: gathers served from L1
+                        xg[c][h][0] = a.x[c0]; xg[c][h][1] = a.x[c1];
+                    }
                 }
             }
             // (2) epilogue operands of this lane's row
@@ -307,7 +311,8 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs a, int nRow
                 const int hi = cur.my_e < tb + CAP ? cur.my_e : tb + CAP;
                 acc = reduce_row<CAP>(s_prod, lo, hi, tb, acc);
             }
-            if (tid < nr) spmv_epilogue<EPI>(a, r0 + tid, acc, eo, dotacc);
+            if (a.ablate & 1) { if (acc == 1.2345e300 && tid < nr) a.y[r0 + tid] = acc; }   // diagnostic: no y store
+            else if (tid < nr) spmv_epilogue<EPI>(a, r0 + tid, acc, eo, dotacc);
             __syncthreads();                                          // LDS is free for the next trip
             cur = nxt;
             nxt.s = s2; nxt.e = e2;

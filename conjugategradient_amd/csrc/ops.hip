@@ -45,6 +45,7 @@ void CsrMV(MgcgSparse* cusparse, MgcgMatDescr* matDescr, double* y,
     SpmvArgs a{};
     a.elements = elements; a.rowOffsets = rowOffsets; a.columnIndeces = columnIndeces; a.x = x; a.y = y;
     a.elementsCount = elementsCount; a.rowCount = rowCount; a.columnCount = columnCount; a.alpha = alpha; a.beta = beta;
+    if (const char* ab = getenv("MGCG_SPMV_ABLATE")) a.ablate = atoi(ab);     // timing diagnostics only (wrong results)
     launch_spmv(cusparse->ws.stream, EPI_AXPBY, a, cfg_of(cusparse));
     (void)MGCG_HIP(hipGetLastError());
 }

@@ -61,6 +61,21 @@ __global__ __launch_bounds__(256) void copy_kernel(const d2* __restrict__ p, d2*
     for (; i < n2; i += stride) q[i] = p[i];
 }
 
+// SpMV-like mix: stream a (4 B/elem) and b (8 B/elem) together, optionally write 8 B per 8 elements
+template <bool WRITE, bool NT>
+__global__ __launch_bounds__(256) void mix_kernel(const int2* __restrict__ a, const d2* __restrict__ b, double* __restrict__ w, long long npairs, double* out)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    double acc = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npairs; i += stride) {
+        int2 c = NT ? __builtin_nontemporal_load(a + i) : a[i];
+        d2 v = NT ? __builtin_nontemporal_load(b + i) : b[i];
+        acc += v.x * c.x + v.y * c.y;
+        if (WRITE && (i & 3) == 0) w[i >> 2] = acc;
+    }
+    if (acc == 1.2345e300) out[0] = acc;
+}
+
 template <typename F>
 static double time_ms(F f, int reps = 5)
 {
@@ -96,6 +111,19 @@ int main(int argc, char** argv)
         double m4 = time_ms([&] { hipLaunchKernelGGL((copy_kernel<4, false>), dim3(g), dim3(256), 0, 0, p, q, n2); });
         double n4 = time_ms([&] { hipLaunchKernelGGL((copy_kernel<4, true>), dim3(g), dim3(256), 0, 0, p, q, n2); });
         printf("copy  grid %6d: U1 %7.1f  U4 %7.1f  U4nt %7.1f GB/s (read+write bytes)\n", g, 2.0 * bytes / m1 / 1e6, 2.0 * bytes / m4 / 1e6, 2.0 * bytes / n4 / 1e6);
+    }
+    {
+        // a: first third of p as int2 (8 B per pair), b: q as d2 (16 B per pair); npairs such that b spans `bytes`
+        const long long npairs = bytes / 16;
+        double* w = (double*)p + (bytes / 8) * 3 / 4;      // write target inside p, away from a
+        for (int g : { 2048, 8192 }) {
+            double r0 = time_ms([&] { hipLaunchKernelGGL((mix_kernel<false, false>), dim3(g), dim3(256), 0, 0, (const int2*)p, q, w, npairs, out); });
+            double r1 = time_ms([&] { hipLaunchKernelGGL((mix_kernel<false, true>), dim3(g), dim3(256), 0, 0, (const int2*)p, q, w, npairs, out); });
+            double w0 = time_ms([&] { hipLaunchKernelGGL((mix_kernel<true, false>), dim3(g), dim3(256), 0, 0, (const int2*)p, q, w, npairs, out); });
+            double w1 = time_ms([&] { hipLaunchKernelGGL((mix_kernel<true, true>), dim3(g), dim3(256), 0, 0, (const int2*)p, q, w, npairs, out); });
+            printf("mix   grid %6d: 2 read streams %7.1f  nt %7.1f | + 8%% writes %7.1f  nt %7.1f GB/s\n", g,
+                   24.0 * npairs / r0 / 1e6, 24.0 * npairs / r1 / 1e6, 26.0 * npairs / w0 / 1e6, 26.0 * npairs / w1 / 1e6);
+        }
     }
     double mm = time_ms([&] { CK(hipMemcpyAsync(q, p, bytes, hipMemcpyDeviceToDevice, 0)); });
     printf("hipMemcpy D2D: %7.1f GB/s (read+write bytes)\n", 2.0 * bytes / mm / 1e6);

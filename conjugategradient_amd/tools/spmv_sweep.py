@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--variants", default="")
+    ap.add_argument("--ablate", action="store_true", help="also time diagnostic ablations (no y store / gathers from L1)")
     a = ap.parse_args()
     L = _lib.lib()
     _lib.require_gpu()
@@ -47,6 +48,7 @@ def main():
     times = {v[0]: [] for v in variants}
 
     def run(v):
+        os.environ["MGCG_SPMV_ABLATE"] = str(v[7]) if len(v) > 7 else "0"
         L.MgcgSetSpmvKernel(sparse, v[1])
         L.MgcgSetSpmvTuning(sparse, v[2], v[3], v[4])
         L.MgcgSetSpmvPeriod(sparse, n * n if (v[3] & 4) else 0)
@@ -57,6 +59,12 @@ def main():
         L.MgcgEventRecord(ev1)
         return L.MgcgEventElapsedMs(ev0, ev1) / a.reps
 
+    if a.ablate:
+        base = [v for v in variants if v[0] in ("wg256 R128", "wave R64 g4096")]
+        for ab, tag in ((1, "no y store"), (2, "gathers from L1"), (3, "no store + L1 gathers")):
+            for v in base:
+                variants.append((v[0] + " | " + tag,) + tuple(v[1:]) + (ab,))
+        times = {v[0]: [] for v in variants}
     for v in variants:      # warm-up
         run(v)
     for _ in range(a.rounds):
