@@ -63,7 +63,8 @@ template <int EPI>
 __device__ __forceinline__ void spmv_epilogue(const SpmvArgs& a, long long row, double acc, const EpiOperands& o, double& dotacc)
 {
     if constexpr (EPI == EPI_AXPBY) {
-        a.y[row] = a.alpha * acc;
+        if (a.ablate & 4) __builtin_nontemporal_store(a.alpha * acc, &a.y[row]);   // diagnostic: streaming store
+        else a.y[row] = a.alpha * acc;
     } else if constexpr (EPI == EPI_AXPBY_BETA) {
         double v = a.alpha * acc;
         double t = a.beta * o.yold;

@@ -8,6 +8,7 @@
 #include <algorithm>
 
 typedef double d2 __attribute__((ext_vector_type(2)));
+typedef int i2v __attribute__((ext_vector_type(2)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
 template <int U, bool NT>
@@ -63,12 +64,12 @@ __global__ __launch_bounds__(256) void copy_kernel(const d2* __restrict__ p, d2*
 
 // SpMV-like mix: stream a (4 B/elem) and b (8 B/elem) together, optionally write 8 B per 8 elements
 template <bool WRITE, bool NT>
-__global__ __launch_bounds__(256) void mix_kernel(const int2* __restrict__ a, const d2* __restrict__ b, double* __restrict__ w, long long npairs, double* out)
+__global__ __launch_bounds__(256) void mix_kernel(const i2v* __restrict__ a, const d2* __restrict__ b, double* __restrict__ w, long long npairs, double* out)
 {
     const long long stride = (long long)gridDim.x * 256;
     double acc = 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npairs; i += stride) {
-        int2 c = NT ? __builtin_nontemporal_load(a + i) : a[i];
+        i2v c = NT ? __builtin_nontemporal_load(a + i) : a[i];
         d2 v = NT ? __builtin_nontemporal_load(b + i) : b[i];
         acc += v.x * c.x + v.y * c.y;
         if (WRITE && (i & 3) == 0) w[i >> 2] = acc;
@@ -117,10 +118,10 @@ int main(int argc, char** argv)
         const long long npairs = bytes / 16;
         double* w = (double*)p + (bytes / 8) * 3 / 4;      // write target inside p, away from a
         for (int g : { 2048, 8192 }) {
-            double r0 = time_ms([&] { hipLaunchKernelGGL((mix_kernel<false, false>), dim3(g), dim3(256), 0, 0, (const int2*)p, q, w, npairs, out); });
-            double r1 = time_ms([&] { hipLaunchKernelGGL((mix_kernel<false, true>), dim3(g), dim3(256), 0, 0, (const int2*)p, q, w, npairs, out); });
-            double w0 = time_ms([&] { hipLaunchKernelGGL((mix_kernel<true, false>), dim3(g), dim3(256), 0, 0, (const int2*)p, q, w, npairs, out); });
-            double w1 = time_ms([&] { hipLaunchKernelGGL((mix_kernel<true, true>), dim3(g), dim3(256), 0, 0, (const int2*)p, q, w, npairs, out); });
+            double r0 = time_ms([&] { hipLaunchKernelGGL((mix_kernel<false, false>), dim3(g), dim3(256), 0, 0, (const i2v*)p, q, w, npairs, out); });
+            double r1 = time_ms([&] { hipLaunchKernelGGL((mix_kernel<false, true>), dim3(g), dim3(256), 0, 0, (const i2v*)p, q, w, npairs, out); });
+            double w0 = time_ms([&] { hipLaunchKernelGGL((mix_kernel<true, false>), dim3(g), dim3(256), 0, 0, (const i2v*)p, q, w, npairs, out); });
+            double w1 = time_ms([&] { hipLaunchKernelGGL((mix_kernel<true, true>), dim3(g), dim3(256), 0, 0, (const i2v*)p, q, w, npairs, out); });
             printf("mix   grid %6d: 2 read streams %7.1f  nt %7.1f | + 8%% writes %7.1f  nt %7.1f GB/s\n", g,
                    24.0 * npairs / r0 / 1e6, 24.0 * npairs / r1 / 1e6, 26.0 * npairs / w0 / 1e6, 26.0 * npairs / w1 / 1e6);
         }
