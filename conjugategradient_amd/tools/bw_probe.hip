@@ -77,6 +77,31 @@ __global__ __launch_bounds__(256) void mix_kernel(const i2v* __restrict__ a, con
     if (acc == 1.2345e300) out[0] = acc;
 }
 
+// as mix_kernel<true>, but every lane keeps B results in registers and stores them in one burst
+template <int B>
+__global__ __launch_bounds__(256) void mix_burst_kernel(const i2v* __restrict__ a, const d2* __restrict__ b, double* __restrict__ w, long long npairs, double* out)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    double acc = 0;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    while (i < npairs) {
+        double buf[B];
+        long long at[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            buf[k] = 0; at[k] = -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {          // 4 pairs read per 8-byte result
+                if (i < npairs) { i2v c = a[i]; d2 v = b[i]; acc += v.x * c.x + v.y * c.y; at[k] = i; i += stride; }
+            }
+            buf[k] = acc;
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) if (at[k] >= 0) w[at[k] >> 2] = buf[k];
+    }
+    if (acc == 1.2345e300) out[0] = acc;
+}
+
 template <typename F>
 static double time_ms(F f, int reps = 5)
 {
@@ -122,6 +147,9 @@ int main(int argc, char** argv)
             double r1 = time_ms([&] { hipLaunchKernelGGL((mix_kernel<false, true>), dim3(g), dim3(256), 0, 0, (const i2v*)p, q, w, npairs, out); });
             double w0 = time_ms([&] { hipLaunchKernelGGL((mix_kernel<true, false>), dim3(g), dim3(256), 0, 0, (const i2v*)p, q, w, npairs, out); });
             double w1 = time_ms([&] { hipLaunchKernelGGL((mix_kernel<true, true>), dim3(g), dim3(256), 0, 0, (const i2v*)p, q, w, npairs, out); });
+            double b4 = time_ms([&] { hipLaunchKernelGGL((mix_burst_kernel<4>), dim3(g), dim3(256), 0, 0, (const i2v*)p, q, w, npairs, out); });
+            double b16 = time_ms([&] { hipLaunchKernelGGL((mix_burst_kernel<16>), dim3(g), dim3(256), 0, 0, (const i2v*)p, q, w, npairs, out); });
+            printf("burst grid %6d: 4 results/burst %7.1f  16 results/burst %7.1f GB/s\n", g, 26.0 * npairs / b4 / 1e6, 26.0 * npairs / b16 / 1e6);
             printf("mix   grid %6d: 2 read streams %7.1f  nt %7.1f | + 8%% writes %7.1f  nt %7.1f GB/s\n", g,
                    24.0 * npairs / r0 / 1e6, 24.0 * npairs / r1 / 1e6, 26.0 * npairs / w0 / 1e6, 26.0 * npairs / w1 / 1e6);
         }

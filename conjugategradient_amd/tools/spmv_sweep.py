@@ -39,6 +39,8 @@ def main():
     variants = [("wg256 R128", 1, 128, 0, 0, 0, 0), ("wg256 R256", 1, 256, 0, 0, 0, 0),
                 ("wave R64", 1, 64, 0, 0, 0, 0), ("wave R64 nt", 1, 64, 1, 0, 0, 0), ("wave R32", 1, 32, 0, 0, 0, 0), ("wave R32 nt", 1, 32, 1, 0, 0, 0),
                 ("wave R32 g4096", 1, 32, 0, 4096, 0, 0), ("wave R64 g4096", 1, 64, 0, 4096, 0, 0),
+                ("wave R64 g2048", 1, 64, 0, 2048, 0, 0), ("wave R64 g3072", 1, 64, 0, 3072, 0, 0), ("wave R64 g5120", 1, 64, 0, 5120, 0, 0),
+                ("wave R64 g4096 nt", 1, 64, 1, 4096, 0, 0), ("wave R32 g6144", 1, 32, 0, 6144, 0, 0),
                 ("wave R64 band", 1, 64, 4, 0, 0, 0), ("wave R32 band", 1, 32, 4, 0, 0, 0), ("wave R32 band 8Lx8", 1, 32, 4, 0, 8 * n, 8),
                 ("wg256 band 64Lx1", 1, 128, 4, 0, 64 * n, 1), ("vector 4 lanes", 4, 128, 0, 0, 0, 0)]
     if a.variants:
