@@ -59,33 +59,39 @@ __device__ __forceinline__ EpiOperands epi_prefetch(const SpmvArgs& a, long long
     return o;
 }
 
+// The value the epilogue stores to y[row] (and the row's contribution to the fused dot product).
 template <int EPI>
-__device__ __forceinline__ void spmv_epilogue(const SpmvArgs& a, long long row, double acc, const EpiOperands& o, double& dotacc)
+__device__ __forceinline__ double spmv_epilogue_value(const SpmvArgs& a, double acc, const EpiOperands& o, double& dotacc)
 {
     if constexpr (EPI == EPI_AXPBY) {
-        if (a.ablate & 4) __builtin_nontemporal_store(a.alpha * acc, &a.y[row]);   // diagnostic: streaming store
-        else a.y[row] = a.alpha * acc;
+        return a.alpha * acc;
     } else if constexpr (EPI == EPI_AXPBY_BETA) {
         double v = a.alpha * acc;
         double t = a.beta * o.yold;
-        a.y[row] = v + t;
+        return v + t;
     } else if constexpr (EPI == EPI_DOT) {
-        a.y[row] = acc;
         double t = o.w * acc;
         dotacc += t;
+        return acc;
     } else if constexpr (EPI == EPI_RESIDUAL) {
-        a.y[row] = o.b - acc;
+        return o.b - acc;
     } else if constexpr (EPI == EPI_RESIDUAL_DOT) {
         double r = o.b - acc;
-        a.y[row] = r;
         double t = r * r;
         dotacc += t;
-    } else if constexpr (EPI == EPI_JACOBI) {
+        return r;
+    } else {   // EPI_JACOBI
         double res = o.b - acc;
         double t = o.dinv * res;
         double s = a.omega * t;
-        a.y[row] = o.w + s;
+        return o.w + s;
     }
+}
+
+template <int EPI>
+__device__ __forceinline__ void spmv_epilogue(const SpmvArgs& a, long long row, double acc, const EpiOperands& o, double& dotacc)
+{
+    a.y[row] = spmv_epilogue_value<EPI>(a, acc, o, dotacc);
 }
 
 // One pipeline stage: the first-pass loads of a row block (CH 16-byte chunks of column ids and values
@@ -228,6 +234,11 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs a, int nRow
         nxt.s = cur.s; nxt.e = cur.e;
         if (nTrips > 1) span_of(rb_of(1), nxt.s, nxt.e);
 
+        // The y store of a trip is issued in the NEXT trip, behind that trip's loads: vmcnt retires in issue
+        // order and counts stores, so a store issued before the loads would have to be acknowledged by
+        // memory before the gathers behind it can be waited for.
+        double pendVal = 0.0;
+        long long pendRow = -1;
         for (int t = 0; t < nTrips; ++t) {
             const long long rb = rb_of(t);
             const long long r0 = rb * R;
@@ -258,6 +269,8 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs a, int nRow
             const EpiOperands eo = epi_prefetch<EPI>(a, myRow);
             // (3) the next block's matrix stream goes in flight behind them (the last trip re-reads its own block)
             issue(nxt, t + 1 < nTrips ? rb_of(t + 1) : rb);
+            // (4) the previous trip's result
+            if (pendRow >= 0 && !(a.ablate & 1)) a.y[pendRow] = pendVal;
             // ---- products of the current block to LDS ----
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
@@ -312,12 +325,14 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs a, int nRow
                 const int hi = cur.my_e < tb + CAP ? cur.my_e : tb + CAP;
                 acc = reduce_row<CAP>(s_prod, lo, hi, tb, acc);
             }
-            if (a.ablate & 1) { if (acc == 1.2345e300 && tid < nr) a.y[r0 + tid] = acc; }   // diagnostic: no y store
-            else if (tid < nr) spmv_epilogue<EPI>(a, r0 + tid, acc, eo, dotacc);
+            pendRow = -1;
+            if (tid < nr) { pendVal = spmv_epilogue_value<EPI>(a, acc, eo, dotacc); pendRow = r0 + tid; }
+            if ((a.ablate & 1) && acc == 1.2345e300) pendRow = 0;     // diagnostic (no y store): keep acc alive
             __syncthreads();                                          // LDS is free for the next trip
             cur = nxt;
             nxt.s = s2; nxt.e = e2;
         }
+        if (pendRow >= 0 && !(a.ablate & 1)) a.y[pendRow] = pendVal;
     }
     if constexpr (EPI == EPI_DOT || EPI == EPI_RESIDUAL_DOT) {
         double t = wave_sum(dotacc);
