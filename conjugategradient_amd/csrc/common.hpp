@@ -98,7 +98,7 @@ struct MgcgSparse {
     mgcg::Workspace ws;
     mgcg::SpmvProfile prof;
     int kernel = 0;          // 0 auto
-    int rowsPerBlock = 128;
+    int rowsPerBlock = 64;
     int flags = 0;           // bit0 nt loads, bit1 xcd-contiguous mapping, bit2 banded schedule (periodRows)
     int gridBlocks = 0;
     int periodRows = 0;      // rows between strongly coupled windows (a grid plane); 0 = unknown
@@ -139,7 +139,7 @@ struct SpmvArgs {
     int ablate;              // diagnostics only (tools/spmv_sweep.py --ablate): bit0 skip the y store, bit1 gathers from L1
 };
 
-struct SpmvConfig { int kernel = 0; int rowsPerBlock = 128; int flags = 0; int gridBlocks = 0; int periodRows = 0; int tileRows = 0; int tilePlanes = 0; };
+struct SpmvConfig { int kernel = 0; int rowsPerBlock = 64; int flags = 0; int gridBlocks = 0; int periodRows = 0; int tileRows = 0; int tilePlanes = 0; };
 
 // Launches the SpMV; returns the number of partials written (grid size) for dot epilogues.
 int launch_spmv(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg);

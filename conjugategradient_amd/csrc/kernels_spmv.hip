@@ -384,7 +384,9 @@ static int resident_blocks_per_cu(K kernel, int block)
 {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, 0) != hipSuccess || n < 1) n = 4;
-    const int cap = 2048 / block;          // 32 waves per CU
+    // 32 waves per CU at most; single-wavefront workgroups measured fastest at 16 per CU on the 7-point
+    // 512^3 matrix (more resident waves only add cache pressure: tools/spmv_sweep.py, profiles/)
+    const int cap = block == 64 ? 16 : 2048 / block;
     if (n > cap) n = cap;
     return n;
 }
@@ -453,7 +455,7 @@ template <int EPI>
 static int launch_stream(hipStream_t s, const SpmvArgs& a, const SpmvConfig& cfg)
 {
     int R = cfg.rowsPerBlock;
-    if (R != 32 && R != 64 && R != 128 && R != 256) R = 128;
+    if (R != 32 && R != 64 && R != 128 && R != 256) R = 64;
     const int nRowBlocks = (int)(((long long)a.rowCount + R - 1) / R);
     int flags = cfg.flags;
     if ((flags & 2) && nRowBlocks < 8 * kNumXcd) flags &= ~2;    // XCD mapping needs enough row blocks
@@ -470,9 +472,9 @@ static int launch_stream(hipStream_t s, const SpmvArgs& a, const SpmvConfig& cfg
     // pass capacity 4*BLOCK*CH must cover R rows of a 7-point stencil plus <=31 nonzeros of alignment in one pass
     switch (R) {
     case 32:  return launch_stream_rc<EPI, 64, 32, 1>(s, a, flags, cfg, nRowBlocks, periodRb, aligned);     // 224+31 <= 256
-    case 64:  return launch_stream_rc<EPI, 64, 64, 2>(s, a, flags, cfg, nRowBlocks, periodRb, aligned);     // 448+31 <= 512
+    case 128: return launch_stream_rc<EPI, 256, 128, 1>(s, a, flags, cfg, nRowBlocks, periodRb, aligned);   // 896+31 <= 1024
     case 256: return launch_stream_rc<EPI, 256, 256, 2>(s, a, flags, cfg, nRowBlocks, periodRb, aligned);   // 1792+31 <= 2048
-    default:  return launch_stream_rc<EPI, 256, 128, 1>(s, a, flags, cfg, nRowBlocks, periodRb, aligned);   // 896+31 <= 1024
+    default:  return launch_stream_rc<EPI, 64, 64, 2>(s, a, flags, cfg, nRowBlocks, periodRb, aligned);     // 448+31 <= 512
     }
 }
 
