@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--solver", choices=["cg", "mgcg"], default="cg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=4, help="CG iterations of the CPU oracle sample")
+    ap.add_argument("--torch-first", action="store_true", help="import torch before the library even at N=1 (runtime-compat check)")
     ap.add_argument("--spmv-kernel", type=int, default=None)
     ap.add_argument("--spmv-rows", type=int, default=None)
     ap.add_argument("--spmv-flags", type=int, default=None)
@@ -103,6 +104,8 @@ def main():
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
 
     dist = None
+    if a.torch_first:
+        import torch  # noqa: F401
     if world > 1:
         # torch first: its bundled HIP runtime and RCCL then serve the whole process (one HIP, one RCCL).
         import torch  # noqa: F401

@@ -62,7 +62,7 @@ class DeviceCsr:
         _lib.check("CsrMV")
         out = vy.to_numpy(n)
         L.MgcgSetSpmvKernel(h.sparse, 0)
-        L.MgcgSetSpmvTuning(h.sparse, 128, 0, 0)
+        L.MgcgSetSpmvTuning(h.sparse, 64, 0, 0)
         L.MgcgSetSpmvPeriod(h.sparse, 0)
         L.MgcgSetSpmvTile(h.sparse, 0, 0)
         return out
