@@ -129,7 +129,7 @@ def main():
     if a.spmv_kernel is not None:
         L.MgcgSetSpmvKernel(cg.cusparse, a.spmv_kernel)
     if a.spmv_rows is not None or a.spmv_flags is not None or a.spmv_grid is not None:
-        L.MgcgSetSpmvTuning(cg.cusparse, a.spmv_rows or 256, a.spmv_flags or 0, a.spmv_grid or 0)
+        L.MgcgSetSpmvTuning(cg.cusparse, a.spmv_rows or 64, a.spmv_flags or 0, a.spmv_grid or 0)
     cg.InitializePoisson(n, n, n)
     L.MgcgDeviceSynchronize()
     _lib.check("setup")

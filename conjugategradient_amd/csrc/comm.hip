@@ -74,7 +74,7 @@ namespace mgcg {
 
 bool comm_allreduce_sum(MgcgComm* c, double* devPtr, int count, hipStream_t s)
 {
-    if (!c || c->nranks == 1) return true;
+    if (!c || c->comm == nullptr) return true;     // single rank without a communicator: the local sum is the sum
     Rccl* r = rccl();
     if (!r) return false;
     return nccl_ok(r->AllReduce(devPtr, devPtr, (size_t)count, NCCL_DOUBLE, NCCL_SUM, c->comm, s), "ncclAllReduce");
@@ -165,7 +165,7 @@ MgcgComm* MgcgCommInitRank(const void* id128, int nranks, int rank)
     MgcgComm* c = new MgcgComm();
     c->nranks = nranks; c->rank = rank; c->stream = d->stream;
     if (!MGCG_HIP(hipMalloc((void**)&c->scratch, 8 * sizeof(double)))) { delete c; return nullptr; }
-    if (nranks > 1) {
+    if (nranks > 1 || id128 != nullptr) {          // a unique id with nranks == 1 builds a real one-rank communicator
         Rccl* r = rccl();
         if (!r || !id128) { if (r) set_error("MgcgCommInitRank: null unique id"); (void)hipFree(c->scratch); delete c; return nullptr; }
         NcclUniqueId id;

@@ -1,0 +1,88 @@
+"""The C-ABI library: loads on a host without a GPU, exports every symbol include/MgcgGpu.h declares,
+and fails LOUDLY (no CPU fallback) when asked to compute without a device.  CPU only."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "MgcgGpu.h")
+
+REFERENCE_EXPORTS = [  # the 32 exports of MgcgGpu.dll
+    "GetDeviceCount", "SetDevice", "CreateBlas", "DestroyBlas", "CreateSparse", "DestroySparse", "CreateMatDescr", "DestroyMatDescr",
+    "Create_Double", "CopyToArray_Double", "CopyFromArray_Double", "Delete_Double", "ToRawPtr_Double", "CopyFromDevice_Double",
+    "Create_Int", "CopyToArray_Int", "CopyFromArray_Int", "Delete_Int", "ToRawPtr_Int",
+    "CsrMV", "Axpy", "Dot", "Scal", "Copy", "Initialize", "P2Host", "P2Device", "Solve0", "Solve1", "Solve2", "Solve3", "Solve",
+]
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#.*", "", text)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text)
+    skip = {"defined", "sizeof"}
+    return sorted({n for n in names if n not in skip})
+
+
+def test_header_declares_the_reference_exports():
+    names = declared_functions()
+    assert len(REFERENCE_EXPORTS) == 32
+    for n in REFERENCE_EXPORTS:
+        assert n in names, n
+
+
+def test_library_exports_every_declared_symbol(hiplib):
+    from conjugategradient_amd import _lib
+
+    names = declared_functions()
+    assert len(names) >= 60
+    for n in names:
+        assert hasattr(hiplib, n), f"{n} declared in include/MgcgGpu.h but not exported by libMgcgGpu.so"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in _lib.py"
+    # nothing but the C ABI leaks out of the shared object
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    assert exported == set(names), exported ^ set(names)
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "MgcgGpu.h"\nint main(void) { return MGCG_RULE_VIENNACL == 4 ? 0 : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "t.o")])
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="this check is for hosts without a GPU")
+def test_no_device_fails_loudly(hiplib):
+    """No HIP device: handles are NULL, value-returning ops return NaN, and the reason is reported --
+    the product never computes on the CPU."""
+    from conjugategradient_amd import _lib
+    from conjugategradient_amd.solver import ConjugateGradientSingleGpu
+
+    L = hiplib
+    assert L.GetDeviceCount() == 0
+    assert not L.CreateBlas()
+    assert "no HIP device" in _lib.last_error()
+    L.MgcgClearLastError()
+    assert not L.Create_Double(8)
+    L.MgcgClearLastError()
+    x = np.ones(4)
+    assert np.isnan(L.Dot(None, x.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), 4))
+    L.MgcgClearLastError()
+    with pytest.raises(_lib.MgcgError):
+        ConjugateGradientSingleGpu(10, 3, 0, 10, 1e-8)
+    with pytest.raises(_lib.MgcgError):
+        _lib.require_gpu()
+    assert L.MgcgPoissonNnz(512, 512, 512, 0, 512) == 937951232      # host-side arithmetic still answers
+    assert L.MgcgPoissonNnz(256, 256, 1, 0, 1) == 326656
+
+
+def test_missing_library_is_an_error(tmp_path, monkeypatch):
+    code = ("import sys; sys.path.insert(0, %r); from conjugategradient_amd import _lib; "
+            "_lib.LIB_PATH = %r; \ntry:\n _lib.lib()\nexcept _lib.MgcgError as e:\n print('raised', 'no CPU fallback' in str(e))") % (ROOT, str(tmp_path / "nope.so"))
+    out = subprocess.check_output([sys.executable, "-c", code]).decode()
+    assert "raised True" in out

@@ -1,0 +1,107 @@
+"""The one-rank-per-process driver over torch.distributed (gloo, CPU): partition, halo plan, SyncP as
+point-to-point exchange, resultsDot.Sum() as all-reduce.  The phase arithmetic is plugged in from the CPU
+oracle HERE (test infrastructure) so that the host/collective logic of conjugategradient_amd/parallel.py is
+exercised without a GPU; the GPU tests run the same driver with the HIP phases."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OraclePhases:
+    """Solve0..3 of Mgcg.cu:116-198 restated with the oracle's BLAS-1 for one rank's row slice."""
+
+    def __init__(self, system, part, O):
+        self.O, self.part = O, part
+        s = system
+        lo, hi = part.elementOffset, part.elementOffset + part.elementCount
+        self.e = np.ascontiguousarray(s.Elements[lo:hi])
+        self.c = np.ascontiguousarray(s.ColumnIndeces[lo:hi])
+        self.ro = np.ascontiguousarray(s.RowOffsets[part.offset: part.offset + part.count + 1] - lo).astype(np.int32)   # Mgcg.cu:73
+        self.x = s.x[part.offset: part.offset + part.count].copy()
+        self.b = s.b[part.offset: part.offset + part.count].copy()
+        self.p = np.zeros(s.Count)
+        self.p[part.offset: part.offset + part.count] = self.x                                                     # Mgcg.cu:80
+        self.r = np.zeros(part.count)
+        self.Ap = np.zeros(part.count)
+        part.minJ, part.maxJ = (int(self.c.min()), int(self.c.max())) if part.elementCount else (0, -1)
+
+    def get_p(self, begin, length):
+        return self.p[begin: begin + length].copy()
+
+    def set_p(self, begin, values):
+        self.p[begin: begin + len(values)] = values
+
+    def _sl(self):
+        return slice(self.part.offset, self.part.offset + self.part.count)
+
+    def solve0(self):
+        O = self.O
+        self.Ap = O.spmv(self.e, self.c, self.ro, self.p)
+        self.r = O.set_added(self.b, self.Ap, -1.0)
+        self.p[self._sl()] = self.r
+        return O.dot(self.r, self.r)
+
+    def solve1(self):
+        self.Ap = self.O.spmv(self.e, self.c, self.ro, self.p)
+        return self.O.dot(self.p[self._sl()].copy(), self.Ap)
+
+    def solve2(self, alpha):
+        O = self.O
+        self.x = O.set_added(self.x, self.p[self._sl()].copy(), alpha)
+        self.r = O.set_added(self.r, self.Ap, -alpha)
+        return O.dot(self.r, self.r)
+
+    def solve3(self, beta):
+        self.p[self._sl()] = self.O.set_added(self.r, self.p[self._sl()].copy(), beta)
+
+    def read_x(self):
+        return self.x
+
+
+def _worker(rank, world, port, which, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from conjugategradient_amd import problems
+    from conjugategradient_amd.parallel import PhasedRankSolver, RankPartition
+    from oracle import oracle as O
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    system = problems.mgcg_main(1203, 160) if which == "banded" else problems.random_spd(900, mean_upper=6.0, seed=11)
+    part = RankPartition.of(system.Count, world, rank, system.RowOffsets)
+    backend = OraclePhases(system, part, O)
+    solver = PhasedRankSolver(backend, part, 0, system.Count, 1e-8, dist=dist)
+    solver.Solve()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=backend.read_x(), iteration=solver.Iteration, residual=solver.Residual,
+             offset=part.offset, count=part.count, minJ=part.minJ, maxJ=part.maxJ)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,which", [(2, "banded"), (3, "banded"), (2, "unstructured")])
+def test_phased_rank_solver_matches_the_parallel_oracle(tmp_path, world, which):
+    import torch.multiprocessing as mp
+
+    from conjugategradient_amd import problems
+    from oracle import oracle as O
+
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, which, str(tmp_path)), nprocs=world, join=True)
+    system = problems.mgcg_main(1203, 160) if which == "banded" else problems.random_spd(900, mean_upper=6.0, seed=11)
+    ref = O.cg_parallel(system, world, allowable_residual=1e-8, min_iteration=0, max_iteration=system.Count)
+    x = np.zeros(system.Count)
+    for r in range(world):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        x[int(d["offset"]): int(d["offset"]) + int(d["count"])] = d["x"]
+        assert int(d["iteration"]) == ref["iteration"]
+        # gloo all-reduce adds the rank partials in an order of its own; everything else is bit-identical
+        assert abs(float(d["residual"]) - ref["residual"]) <= 1e-9 * ref["residual"]
+        lo, hi = O.minmax_column(system, int(d["offset"]), int(d["offset"]) + int(d["count"]))
+        assert (int(d["minJ"]), int(d["maxJ"])) == (lo, hi)
+    np.testing.assert_allclose(x, ref["x"], rtol=1e-10, atol=1e-12 * np.abs(ref["x"]).max())

@@ -1,0 +1,83 @@
+"""BASELINE.json sizes (7-point 256^3 and one 512^3 SpMV) through size-independent properties: the oracle
+cannot finish these in seconds, so the checks are a closed-form product (A.1 counts the missing neighbours),
+linearity, symmetry, and the recurrence residual against a recomputed b - A x."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conjugategradient_amd import _lib
+from conjugategradient_amd.parallel import ConjugateGradientRankGpu
+from conjugategradient_amd.solver import VectorDouble
+
+pytestmark = pytest.mark.gpu
+
+
+def _missing_neighbours(n):
+    i = np.arange(n)
+    edge = ((i == 0) | (i == n - 1)).astype(np.float64)
+    return (edge[None, None, :] + edge[None, :, None] + edge[:, None, None]).ravel()
+
+
+def _spmv(cg, xv, yv, N, nnz):
+    L = _lib.lib()
+    L.CsrMV(cg.cusparse, cg.matDescr, yv.ToRawPtr(), cg.vectorElements.ToRawPtr(), cg.vectorRowOffsets.ToRawPtr(),
+            cg.vectorColumnIndeces.ToRawPtr(), xv.ToRawPtr(), nnz, N, N, 1.0, 0.0)
+    _lib.check("CsrMV")
+
+
+@pytest.mark.parametrize("n", [256, 512])
+def test_spmv_closed_form(n):
+    """A.1 = 6 - (number of neighbours) = number of grid faces the cell touches: exact small integers."""
+    N = n**3
+    cg = ConjugateGradientRankGpu(N, 7, 0, 10, 1e-8, rank=0, world=1)
+    cg.InitializePoisson(n, n, n)
+    nnz = cg.part.elementCount
+    assert nnz == 7 * N - 6 * n * n
+    ones, y = VectorDouble(N), VectorDouble(N)
+    _lib.lib().MgcgFill(ones.Ptr, 1.0)
+    for period in (0, n * n):                       # plain and banded schedules give the same bits
+        _lib.lib().MgcgSetSpmvPeriod(cg.cusparse, period)
+        _spmv(cg, ones, y, N, nnz)
+        got = y.to_numpy()
+        assert np.array_equal(got, _missing_neighbours(n))
+    cg.Dispose()
+    ones.Dispose()
+    y.Dispose()
+
+
+def test_config2_linearity_symmetry_and_residual():
+    n = 256
+    N = n**3
+    L = _lib.lib()
+    cg = ConjugateGradientRankGpu(N, 7, 0, 100000, 1e-8, rank=0, world=1)
+    cg.InitializePoisson(n, n, n)
+    nnz = cg.part.elementCount
+    rng = np.random.default_rng(0)
+    u, v = rng.standard_normal(N), rng.standard_normal(N)
+    du, dv, dw, y1, y2, y3 = (VectorDouble(N) for _ in range(6))
+    du.CopyFrom(u, N)
+    dv.CopyFrom(v, N)
+    dw.CopyFrom(0.75 * u - 1.5 * v, N)
+    _spmv(cg, du, y1, N, nnz)
+    _spmv(cg, dv, y2, N, nnz)
+    _spmv(cg, dw, y3, N, nnz)
+    Au, Av, Aw = y1.to_numpy(), y2.to_numpy(), y3.to_numpy()
+    assert np.abs(Aw - (0.75 * Au - 1.5 * Av)).max() <= 1e-13 * np.abs(Aw).max()           # linearity
+    uAv = L.Dot(cg.cublas, du.ToRawPtr(), y2.ToRawPtr(), N)
+    vAu = L.Dot(cg.cublas, dv.ToRawPtr(), y1.ToRawPtr(), N)
+    assert abs(uAv - vAu) <= 1e-12 * abs(uAv)                                               # symmetry
+    assert L.Dot(cg.cublas, du.ToRawPtr(), y1.ToRawPtr(), N) > 0                            # positive definite
+    # 60 CG iterations: the recurrence residual the solver reports equals ||b - A x|| recomputed from x
+    res = cg.Steps(60, restart=True)
+    x = VectorDouble(N)
+    L.Copy(cg.cublas, x.ToRawPtr(), cg.vectorX.ToRawPtr(), N, 0, 0)
+    _spmv(cg, x, y1, N, nnz)
+    r = 1.0 - y1.to_numpy()
+    true_res = float(np.sqrt(np.dot(r, r)))
+    assert abs(true_res - res) <= 1e-9 * res
+    first = cg.Steps(1, restart=True)
+    assert res < first                                                                      # and it went down
+    for t in (du, dv, dw, y1, y2, y3, x):
+        t.Dispose()
+    cg.Dispose()

@@ -1,0 +1,111 @@
+"""One-process-per-GPU driver on the GPU box: the native SolveParallel loop (single rank), the RCCL binding
+(one-rank communicator), and the host-driven phases over torch.distributed with two processes sharing the GPU."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conjugategradient_amd import _lib, problems
+from conjugategradient_amd.parallel import ConjugateGradientRankGpu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rank_solver_single_rank_matches_oracle(oracle):
+    s = problems.mgcg_main(3001, 160)
+    ref = oracle.cg(s, rule=oracle.RULE_CSHARP, max_iteration=3001, trace=True)
+    cg = ConjugateGradientRankGpu(s.Count, 160, 0, 3001, 1e-8, rank=0, world=1).load(s)
+    cg.Initialize()
+    lo, hi = oracle.minmax_column(s, 0, s.Count)
+    assert (cg.part.minJ, cg.part.maxJ) == (lo, hi)
+    cg.Solve(trace=True)
+    cg.Read()
+    assert cg.Iteration == ref["iteration"]
+    assert np.abs(cg.x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
+    cg.Dispose()
+
+
+def test_rank_solver_on_device_generated_slab(oracle):
+    n = 24
+    s = problems.poisson(n, n, n)
+    ref = oracle.cg(s, rule=oracle.RULE_CSHARP, max_iteration=2000)
+    cg = ConjugateGradientRankGpu(s.Count, 7, 0, 2000, 1e-8, rank=0, world=1)
+    cg.InitializePoisson(n, n, n)
+    cg.Solve()
+    cg.Read()
+    assert cg.Iteration == ref["iteration"]
+    assert np.abs(cg.x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
+    # Steps(): k iterations without a stop test leave the same residual as the oracle's k-th trace entry
+    tr = oracle.cg(s, rule=oracle.RULE_CSHARP, min_iteration=10, max_iteration=2000, trace=True)["trace"]
+    cg2 = ConjugateGradientRankGpu(s.Count, 7, 0, 2000, 1e-8, rank=0, world=1)
+    cg2.InitializePoisson(n, n, n)
+    res = cg2.Steps(5, restart=True)
+    assert abs(res - tr[4]) <= 1e-10 * tr[4]
+    res = cg2.Steps(3, restart=False)
+    assert abs(res - tr[7]) <= 1e-10 * tr[7]
+    cg.Dispose()
+    cg2.Dispose()
+
+
+def test_rccl_binding_one_rank_communicator(oracle):
+    """dlopen of librccl + ncclCommInitRank/ncclAllReduce through the library (a real communicator of size 1)."""
+    L = _lib.lib()
+    L.SetDevice(0)
+    buf = (C.c_char * 128)()
+    assert L.MgcgCommGetUniqueId(buf) == 0, _lib.last_error()
+    comm = L.MgcgCommInitRank(buf, 1, 0)
+    assert comm, _lib.last_error()
+    assert L.MgcgCommSize(comm) == 1 and L.MgcgCommRank(comm) == 0
+    assert L.MgcgCommAllReduceSum(comm, 2.5) == 2.5
+    s = problems.poisson(12, 12, 12)
+    ref = oracle.cg(s, rule=oracle.RULE_CSHARP, max_iteration=500)
+    cg = ConjugateGradientRankGpu(s.Count, 7, 0, 500, 1e-8, rank=0, world=1, comm=comm).load(s)
+    cg.Initialize()
+    cg.Solve()            # every dot product goes through ncclAllReduce on the library's stream
+    cg.Read()
+    assert cg.Iteration == ref["iteration"]
+    assert np.abs(cg.x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
+    cg.Dispose()
+    L.MgcgCommDestroy(comm)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from conjugategradient_amd import problems as P
+    from conjugategradient_amd.parallel import HipPhases, PhasedRankSolver, RankPartition
+    from conjugategradient_amd.solver import SparseMatrix
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    system = P.mgcg_main(2400, 160)
+    part = RankPartition.of(system.Count, world, rank, system.RowOffsets)
+    backend = HipPhases(SparseMatrix.from_system(system), system.x, system.b, part, 160)
+    solver = PhasedRankSolver(backend, part, 0, system.Count, 1e-8, dist=dist)
+    solver.Solve()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=backend.read_x(), iteration=solver.Iteration, residual=solver.Residual,
+             offset=part.offset, count=part.count)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_phased_ranks_share_the_gpu_over_gloo(oracle, tmp_path):
+    """Two processes (the box has one GPU; both ranks use it), HIP phase functions, gloo collectives."""
+    import torch.multiprocessing as mp
+
+    world = 2
+    port = 29600 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    system = problems.mgcg_main(2400, 160)
+    ref = oracle.cg_parallel(system, world, max_iteration=system.Count)
+    x = np.zeros(system.Count)
+    for r in range(world):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        x[int(d["offset"]): int(d["offset"]) + int(d["count"])] = d["x"]
+        assert int(d["iteration"]) == ref["iteration"]
+    assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()

@@ -1,0 +1,92 @@
+"""Host-side logic that needs no device: partition arithmetic, halo plan, the class surface.  CPU only."""
+import numpy as np
+import pytest
+
+from conjugategradient_amd import problems
+from conjugategradient_amd.parallel import RankPartition, halo_plan
+from conjugategradient_amd.solver import ApplicationException, ConjugateGradient, LinerEquations, SparseMatrix
+
+
+def test_partition_matches_reference_formula():
+    # ConjugateGradientParallelGpu.cs:271-277: floor(N/ndev) each, remainder to the last device
+    assert problems.partition_offsets(207402, 4) == [0, 51850, 103700, 155550, 207402]
+    assert problems.partition_offsets(7, 3) == [0, 2, 4, 7]
+    assert problems.partition_offsets(5, 8) == [0, 0, 0, 0, 0, 0, 0, 0, 5]
+    for n, w in [(100, 1), (101, 7), (134217728, 8)]:
+        off = problems.partition_offsets(n, w)
+        assert off[0] == 0 and off[-1] == n and all(b >= a for a, b in zip(off, off[1:]))
+
+
+def test_rank_partition_halo_widths():
+    s = problems.mgcg_main(1000, 160)
+    ro = s.RowOffsets
+    parts = [RankPartition.of(s.Count, 4, r, ro) for r in range(4)]
+    assert sum(p.count for p in parts) == s.Count and sum(p.elementCount for p in parts) == s.nnz
+    for p in parts:
+        cols = s.ColumnIndeces[p.elementOffset: p.elementOffset + p.elementCount]
+        p.minJ, p.maxJ = int(cols.min()), int(cols.max())
+    # :397-398  lastCount = offset - minJ, nextCount = maxJ - (offset+count) + 1; edge devices have one side only
+    assert parts[0].lastCount == 0 and parts[0].nextCount == 79
+    assert parts[1].lastCount == 79 and parts[1].nextCount == 79
+    assert parts[3].lastCount == 79 and parts[3].nextCount == 0
+
+
+def test_halo_plan_banded_and_unstructured():
+    # banded: only adjacent ranks talk, widths = band half-width
+    meta = [(0, 250, 0, 328), (250, 250, 171, 578), (500, 250, 421, 828), (750, 250, 671, 999)]
+    sends, recvs = halo_plan(meta, 1)
+    assert recvs == [(0, 171, 79), (2, 500, 79)]
+    assert sends == [(0, 250, 79), (2, 421, 79)]
+    # every send of rank a to rank b is a recv of rank b from rank a with the same range
+    for a in range(4):
+        for (b, beg, ln) in halo_plan(meta, a)[0]:
+            assert (a, beg, ln) in halo_plan(meta, b)[1]
+    # unstructured: every rank needs everything -> all-gather pattern
+    meta = [(0, 30, 0, 99), (30, 30, 0, 99), (60, 40, 0, 99)]
+    sends, recvs = halo_plan(meta, 0)
+    assert recvs == [(1, 30, 30), (2, 60, 40)] and sends == [(1, 0, 30), (2, 0, 30)]
+    # an empty rank neither sends nor receives
+    meta = [(0, 10, 0, 9), (10, 0, 0, -1)]
+    assert halo_plan(meta, 1) == ([], [])
+    assert halo_plan(meta, 0) == ([], [])
+
+
+def test_class_surface():
+    le = LinerEquations(5, 3)
+    assert le.Count == 5 and le.x.shape == (5,) and le.b.shape == (5,) and le.A is None
+    m = SparseMatrix(4, 3)
+    assert m.Elements.shape == (12,) and np.all(m.ColumnIndeces == -1) and m.RowCount == 5   # RowOffsets.Length (sic)
+    m.Elements[:] = 1
+    m.Clear()
+    assert np.all(m.Elements == 0)
+
+    class Dummy(ConjugateGradient):
+        def Solve(self):
+            pass
+
+    cg = Dummy(5, 3, 2, 4, 1e-3)
+    cg.Residual = 0.0
+    cg.Iteration = 1
+    assert cg.IsConverged is False           # below MinIteration
+    cg.Iteration = 2
+    assert cg.IsConverged is True
+    cg.Residual = 1.0
+    cg.Iteration = 4
+    assert cg.IsConverged is False
+    cg.Iteration = 5
+    with pytest.raises(ApplicationException):
+        cg.IsConverged
+
+
+def test_problem_generators_shapes():
+    s = problems.poisson(256, 256, 1)
+    assert s.Count == 65536 and s.nnz == 326656                 # BASELINE config 1
+    assert problems.poisson_nnz(256, 256, 256) == 117047296       # config 2
+    assert problems.poisson_nnz(512, 512, 512) == 937951232       # config 3
+    r = problems.random_spd(2000, seed=3)
+    A = r.to_scipy()
+    assert abs(A - A.T).max() == 0
+    d = A.diagonal()
+    off = np.asarray(abs(A).sum(axis=1)).ravel() - abs(d)
+    assert np.all(d > off)                                        # strictly diagonally dominant => SPD
+    np.testing.assert_allclose(A @ np.ones(2000), r.b)
