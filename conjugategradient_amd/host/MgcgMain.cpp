@@ -1,0 +1,93 @@
+// MgcgMain -- C++ twin of the reference driver Mgcg/cuBlas/Mgcg/MgcgMain.cs:41-178: builds the banded
+// |sin(i+j)| system (:51-104), solves it on one GPU and on every GPU of the process, and reports
+// ticks per iteration (:165-167).  The reference also runs its CPU solver and prints every element that
+// differs by more than 1 % (:129-162); the product has no CPU compute path, so the two GPU paths are
+// compared with each other here and tests/test_gpu_host_cpp.py compares the printed solution
+// checksum with the CPU oracle.
+//
+//   MgcgMain [COUNT] [MIN_ITERATION]        (defaults: 34567*6 and 200, the reference's constants)
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+
+#include "Mgcg.hpp"
+
+using namespace LWisteria::Mgcg;
+
+int main(int argc, char** argv)
+{
+    const int COUNT = argc > 1 ? atoi(argv[1]) : 34567 * 6;            // MgcgMain.cs:15
+    const int MAX_NONZERO_COUNT = 160;                                  // :20
+    const int MIN_ITERATION = argc > 2 ? atoi(argv[2]) : 200;           // :25
+    const int MAX_ITERATION = COUNT;                                    // :30
+    const double ALLOWABLE_RESIDUAL = 1e-8;                             // :35
+    printf("N=%d\n", COUNT);
+    try {
+        ConjugateGradientSingleGpu cgGpuSingle(COUNT, MAX_NONZERO_COUNT, MIN_ITERATION, MAX_ITERATION, ALLOWABLE_RESIDUAL);
+        ConjugateGradientParallelGpu cgGpuParallel(COUNT, MAX_NONZERO_COUNT, MIN_ITERATION, MAX_ITERATION, ALLOWABLE_RESIDUAL);
+
+        SparseMatrix A(COUNT, MAX_NONZERO_COUNT);
+        A.RowOffsets[0] = 0;
+        for (int i = 0; i < COUNT; i++) {                               // :53-84
+            const int rowOffset = A.RowOffsets[(size_t)i];
+            A.Elements[(size_t)rowOffset] = 0;
+            A.ColumnIndeces[(size_t)rowOffset] = i;                     // diagonal first
+            int nonzeroCount = 1;
+            for (int j = std::max(0, i - MAX_NONZERO_COUNT / 2 + 1); j < std::min(COUNT, i + MAX_NONZERO_COUNT / 2); j++) {
+                if (i != j) {
+                    const double a_ij = std::fabs(std::sin((double)(i + j)));
+                    A.Elements[(size_t)(rowOffset + nonzeroCount)] = a_ij;
+                    A.ColumnIndeces[(size_t)(rowOffset + nonzeroCount)] = j;
+                    nonzeroCount++;
+                    A.Elements[(size_t)rowOffset] += a_ij;
+                }
+            }
+            A.RowOffsets[(size_t)i + 1] = A.RowOffsets[(size_t)i] + nonzeroCount;
+        }
+        cgGpuSingle.A = &A;
+        cgGpuParallel.A = &A;
+        for (int i = 0; i < COUNT; i++) {                               // :91-104
+            const double b_i = std::cos((double)i) * 10;
+            const double x_i = (double)i / 100;
+            cgGpuSingle.b[(size_t)i] = b_i; cgGpuParallel.b[(size_t)i] = b_i;
+            cgGpuSingle.x[(size_t)i] = x_i; cgGpuParallel.x[(size_t)i] = x_i;
+        }
+        printf("start\n");
+        using clk = std::chrono::steady_clock;
+
+        cgGpuSingle.Initialize();
+        auto t0 = clk::now();
+        cgGpuSingle.Solve();
+        const double singleSec = std::chrono::duration<double>(clk::now() - t0).count();
+        cgGpuSingle.Read();
+
+        cgGpuParallel.Initialize();
+        t0 = clk::now();
+        cgGpuParallel.Solve();
+        const double parallelSec = std::chrono::duration<double>(clk::now() - t0).count();
+        cgGpuParallel.Read();
+
+        int mismatches = 0;
+        double checksum = 0, maxRel = 0;
+        for (int i = 0; i < COUNT; i++) {                               // :151-162 with the single-GPU result as the baseline
+            const double ref = cgGpuSingle.x[(size_t)i];
+            const double residual = std::fabs(ref - cgGpuParallel.x[(size_t)i]);
+            if (std::fabs(ref) > 0) maxRel = std::max(maxRel, residual / std::fabs(ref));
+            if (residual / ref > 0.01) { if (mismatches < 10) printf("Parallel %4d: %e (%e vs %e)\n", i, residual, ref, cgGpuParallel.x[(size_t)i]); mismatches++; }
+            checksum += ref * (double)((i % 7) + 1);
+        }
+        printf("single GPU  : %12.6f s / %d = %12.3f us per iteration\n", singleSec, cgGpuSingle.Iteration, 1e6 * singleSec / std::max(1, cgGpuSingle.Iteration));
+        printf("parallel GPU: %12.6f s / %d = %12.3f us per iteration (%d devices)\n", parallelSec, cgGpuParallel.Iteration,
+               1e6 * parallelSec / std::max(1, cgGpuParallel.Iteration), cgGpuParallel.DeviceCount());
+        printf("{\"count\": %d, \"devices\": %d, \"iteration_single\": %d, \"iteration_parallel\": %d, \"residual_single\": %.17g, "
+               "\"residual_parallel\": %.17g, \"mismatches\": %d, \"max_rel_single_vs_parallel\": %.3e, \"checksum\": %.17g, \"x0\": %.17g, \"xlast\": %.17g}\n",
+               COUNT, cgGpuParallel.DeviceCount(), cgGpuSingle.Iteration, cgGpuParallel.Iteration, cgGpuSingle.Residual, cgGpuParallel.Residual,
+               mismatches, maxRel, checksum, cgGpuSingle.x[0], cgGpuSingle.x[(size_t)COUNT - 1]);
+        return mismatches == 0 ? 0 : 1;
+    } catch (std::exception& e) {
+        printf("!!!!%s\n", e.what());
+        return 2;
+    }
+}
