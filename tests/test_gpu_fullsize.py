@@ -76,8 +76,7 @@ def test_config2_linearity_symmetry_and_residual():
     r = 1.0 - y1.to_numpy()
     true_res = float(np.sqrt(np.dot(r, r)))
     assert abs(true_res - res) <= 1e-9 * res
-    first = cg.Steps(1, restart=True)
-    assert res < first                                                                      # and it went down
+    # (the 2-norm of the CG residual is not monotone -- with b = 1 it first grows -- so no ordering is asserted)
     for t in (du, dv, dw, y1, y2, y3, x):
         t.Dispose()
     cg.Dispose()
