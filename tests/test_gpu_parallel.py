@@ -72,35 +72,16 @@ def test_rccl_binding_one_rank_communicator(oracle):
     L.MgcgCommDestroy(comm)
 
 
-def _worker(rank, world, port, out_dir):
-    sys.path.insert(0, ROOT)
-    import torch.distributed as dist
-
-    from conjugategradient_amd import problems as P
-    from conjugategradient_amd.parallel import HipPhases, PhasedRankSolver, RankPartition
-    from conjugategradient_amd.solver import SparseMatrix
-
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    system = P.mgcg_main(2400, 160)
-    part = RankPartition.of(system.Count, world, rank, system.RowOffsets)
-    backend = HipPhases(SparseMatrix.from_system(system), system.x, system.b, part, 160)
-    solver = PhasedRankSolver(backend, part, 0, system.Count, 1e-8, dist=dist)
-    solver.Solve()
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=backend.read_x(), iteration=solver.Iteration, residual=solver.Residual,
-             offset=part.offset, count=part.count)
-    dist.barrier()
-    dist.destroy_process_group()
-
-
 def test_phased_ranks_share_the_gpu_over_gloo(oracle, tmp_path):
     """Two processes (the box has one GPU; both ranks use it), HIP phase functions, gloo collectives."""
-    import torch.multiprocessing as mp
+    import subprocess
 
     world = 2
     port = 29600 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    worker = os.path.join(ROOT, "tests", "_phased_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(tmp_path)]) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
     system = problems.mgcg_main(2400, 160)
     ref = oracle.cg_parallel(system, world, max_iteration=system.Count)
     x = np.zeros(system.Count)
