@@ -1,0 +1,20 @@
+#!/bin/bash
+# rocprofv3 evidence for bench.py (run on the GPU box from the repo root):
+#   1. --kernel-trace --stats of the bench command  -> per-kernel average durations
+#   2. two --pmc passes on the same command          -> HBM-side read / write request counts of the SpMV kernel
+# Usage: bash conjugategradient_amd/tools/profile_bench.sh OUTDIR [bench args...]
+set -u
+OUT=$1; shift
+ARGS="$*"
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+export PYTHONPATH=$GRAFT_REPO_ROOT
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline $ARGS"
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/stats" -- $BENCH) > "$OUT/stats.log" 2>&1
+echo "stats rc=$?"
+(cd /tmp && rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/pmc_rd" -- $BENCH) > "$OUT/pmc_rd.log" 2>&1
+echo "pmc_rd rc=$?"
+(cd /tmp && rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/pmc_wr" -- $BENCH) > "$OUT/pmc_wr.log" 2>&1
+echo "pmc_wr rc=$?"
+python3 conjugategradient_amd/tools/profile_summarize.py "$OUT" > "$OUT/summary.json"
+cat "$OUT/summary.json"

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Summarise a profile_bench.sh output directory: per-kernel stats (from --stats) and the HBM-side bytes per
+launch of the SpMV kernel from the PMC passes.  Byte formula (calibrated on gfx950 with a Dot of known size,
+see profiles/README.md): read bytes = 128*RDREQ_128B + 64*RDREQ_64B + 32*RDREQ_32B; write bytes =
+64*WRREQ_64B + 32*(WRREQ - WRREQ_64B).  (FETCH_SIZE itself tallies 128-byte requests as 64 bytes on gfx950.)"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def counters(root):
+    t = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                t[row["Kernel_Name"].split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return t
+
+
+def main(out):
+    res = {"kernels": [], "spmv": None}
+    for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                res["kernels"].append({"name": row.get("Name", "")[:110], "calls": int(row.get("Calls", 0)),
+                                       "total_ns": float(row.get("TotalDurationNs", 0)), "avg_ns": float(row.get("AverageNs", 0)),
+                                       "pct": float(row.get("Percentage", 0))})
+    res["kernels"].sort(key=lambda k: -k["total_ns"])
+    rd, wr = counters(os.path.join(out, "pmc_rd")), counters(os.path.join(out, "pmc_wr"))
+    for k in rd:
+        if "spmv_stream_kernel" in k and ("<1," in k or "<(mgcg::SpmvEpilogue)1" in k or True):
+            c = rd[k]
+            n = len(c.get("TCC_EA0_RDREQ_128B_sum", []))
+            if n == 0:
+                continue
+            mean = lambda name, d=c: sum(d.get(name, [0])) / max(len(d.get(name, [0])), 1)
+            read_b = 128 * mean("TCC_EA0_RDREQ_128B_sum") + 64 * mean("TCC_EA0_RDREQ_64B_sum") + 32 * mean("TCC_EA0_RDREQ_32B_sum")
+            w = wr.get(k, {})
+            wreq, w64 = mean("TCC_EA0_WRREQ_sum", w), mean("TCC_EA0_WRREQ_64B_sum", w)
+            write_b = 64 * w64 + 32 * (wreq - w64)
+            entry = {"kernel": k[:110], "launches": n, "read_bytes_per_launch": read_b, "write_bytes_per_launch": write_b,
+                     "hbm_bytes_per_launch": read_b + write_b,
+                     "tcc_hit": mean("TCC_HIT_sum", w), "tcc_miss": mean("TCC_MISS_sum", w)}
+            if res["spmv"] is None or n > res["spmv"]["launches"]:
+                res["spmv"] = entry
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
