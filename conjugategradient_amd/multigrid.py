@@ -44,6 +44,23 @@ class ConjugateGradientMgGpu(ConjugateGradientSingleGpu):
         super().Initialize()
         self.Setup()
 
+    def InitializePoisson(self, b_value: float = 1.0, x_value: float = 0.0):
+        """Generate the 5/7-point Poisson matrix of ``self.grid`` directly in HBM (no host arrays) and build
+        the hierarchy; the 512^3 system is 11.8 GB and is never materialised on the host."""
+        L = lib()
+        nx, ny, nz = self.grid
+        nnz = L.MgcgPoissonNnz(nx, ny, nz, 0, nz)
+        if self.vectorA.size < nnz:
+            raise MgcgError("construct with maxNonZeroCount >= 7 for the Poisson generator")
+        if L.MgcgGeneratePoisson(self.vectorA.Ptr, self.vectorRowOffsets.Ptr, self.vectorColumnIndeces.Ptr, nx, ny, nz, 0, nz) != 0:
+            check("MgcgGeneratePoisson")
+        L.MgcgFill(self.vectorB.Ptr, b_value)
+        L.MgcgFill(self.vectorX.Ptr, x_value)
+        L.MgcgSetSpmvPeriod(self.cusparse, nx * ny if nz > 1 else 0)
+        self.A = None
+        self._nnz = int(nnz)
+        self.Setup()
+
     def Setup(self):
         nx, ny, nz = self.grid
         nonzeroCount = int(self.A.RowOffsets[self.Count]) if self.A is not None else self._nnz

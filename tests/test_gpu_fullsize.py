@@ -80,3 +80,30 @@ def test_config2_linearity_symmetry_and_residual():
     for t in (du, dv, dw, y1, y2, y3, x):
         t.Dispose()
     cg.Dispose()
+
+
+def test_config5_like_irregular_rows(oracle):
+    """BASELINE.json config 5 in miniature: random SPD, ~30 nnz/row, irregular rows, unsorted columns -- every SpMV
+    kernel against the oracle, then the whole solve."""
+    import conjugategradient_amd.problems as problems
+    from conjugategradient_amd.solver import ConjugateGradientSingleGpu
+    from tests.gpu_util import DeviceCsr, Handles
+
+    s = problems.random_spd(200000, mean_upper=14.0, seed=12345)
+    assert 25 < s.nnz / s.Count < 35
+    x = np.cos(np.arange(s.Count) * 0.01)
+    ref = oracle.spmv(s.Elements, s.ColumnIndeces, s.RowOffsets, x)
+    h = Handles()
+    A = DeviceCsr(s)
+    assert np.array_equal(A.spmv(h, x, kernel=1), ref)                      # row-block kernel: multi-pass rows, bit-exact
+    for k in (0, 5, 6, 7):
+        np.testing.assert_allclose(A.spmv(h, x, kernel=k), ref, rtol=1e-13, atol=1e-13 * np.abs(ref).max())
+    h.close()
+    r = oracle.cg(s, rule=oracle.RULE_CSHARP, max_iteration=1000, trace=True)
+    cg = ConjugateGradientSingleGpu(s.Count, int(np.diff(s.RowOffsets).max()), 0, 1000, 1e-8, rule=_lib.RULE_CSHARP).load(s)
+    cg.Initialize()
+    cg.Solve()
+    cg.Read()
+    assert cg.Iteration == r["iteration"]
+    assert np.abs(cg.x - r["x"]).max() <= 1e-10 * np.abs(r["x"]).max()
+    np.testing.assert_allclose(cg.x, np.ones(s.Count), rtol=1e-7)             # b = A.1
