@@ -270,7 +270,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs a, int nRow
             // (3) the next block's matrix stream goes in flight behind them (the last trip re-reads its own block)
             issue(nxt, t + 1 < nTrips ? rb_of(t + 1) : rb);
             // (4) the previous trip's result
-            if (pendRow >= 0 && !(a.ablate & 1)) a.y[pendRow] = pendVal;
+            if (pendRow >= 0 && !(a.ablate & 1)) a.y[(a.ablate & 8) ? (pendRow & 0xFFFF) : pendRow] = pendVal;   // bit3: diagnostic, stores stay in L2
             // ---- products of the current block to LDS ----
 #pragma unroll
             for (int c = 0; c < CH; ++c) {

@@ -165,9 +165,11 @@ def random_spd(n: int, mean_upper: float = 14.0, seed: int = 12345, sort_columns
     rng = np.random.default_rng(seed)
     k = rng.poisson(mean_upper, size=n) + 1
     rows = np.repeat(np.arange(n, dtype=np.int64), k)
-    cols = rng.integers(0, n, size=rows.shape[0], dtype=np.int64)
-    keep = cols > rows
-    rows, cols = rows[keep], cols[keep]
+    # strictly-upper columns, uniform over (row, n); the last row has none
+    span = n - 1 - rows
+    cols = rows + 1 + np.floor(rng.random(rows.shape[0]) * np.maximum(span, 1)).astype(np.int64)
+    keep = span > 0
+    rows, cols = rows[keep], np.minimum(cols[keep], n - 1)
     vals = -rng.random(rows.shape[0])
     U = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
     U.sum_duplicates()

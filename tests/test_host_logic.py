@@ -84,6 +84,8 @@ def test_problem_generators_shapes():
     assert problems.poisson_nnz(256, 256, 256) == 117047296       # config 2
     assert problems.poisson_nnz(512, 512, 512) == 937951232       # config 3
     r = problems.random_spd(2000, seed=3)
+    assert 25 < r.nnz / r.Count < 35                              # config 5: ~30 nnz/row on average, irregular
+    assert np.diff(r.RowOffsets).min() >= 1 and np.diff(r.RowOffsets).max() > 40
     A = r.to_scipy()
     assert abs(A - A.T).max() == 0
     d = A.diagonal()
