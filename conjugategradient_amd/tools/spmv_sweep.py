@@ -62,7 +62,7 @@ def main():
         return L.MgcgEventElapsedMs(ev0, ev1) / a.reps
 
     if a.ablate:
-        base = [v for v in variants if v[0] in ("wg256 R128", "wave R64 g4096", "wave R64 band", "wg256 band 64Lx1")]
+        base = [v for v in variants if v[0] in ("wg256 R128", "wave R64 g4096", "wave R64 band", "wg256 band 64Lx1", "wave R64 g4096 nt")]
         for ab, tag in ((1, "no y store"), (2, "gathers from L1"), (3, "no store + L1 gathers"), (8, "y store confined to 512 KB")):
             for v in base:
                 variants.append((v[0] + " | " + tag,) + tuple(v[1:]) + (ab,))
