@@ -98,6 +98,9 @@ SIGNATURES = {
     "SolveMg": (_i, [_vp] * 13 + [_i, _i, _d, _i, _i, _i, _pi, _pd, _vp, _i]),
     "MgcgCommGetUniqueId": (_i, [_vp]),
     "MgcgCommInitRank": (_vp, [_vp, _i, _i]),
+    "MgcgLoopbackCreate": (_vp, [_i]),
+    "MgcgLoopbackDestroy": (None, [_vp]),
+    "MgcgCommInitLoopback": (_vp, [_vp, _i]),
     "MgcgCommDestroy": (None, [_vp]),
     "MgcgCommRank": (_i, [_vp]),
     "MgcgCommSize": (_i, [_vp]),

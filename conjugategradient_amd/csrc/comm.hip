@@ -5,6 +5,7 @@
 #include "common.hpp"
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <condition_variable>
 
 namespace mgcg {
 
@@ -62,19 +63,57 @@ static bool nccl_ok(ncclResult_t rc, const char* what)
 
 } // namespace mgcg
 
+// In-process loopback group: N ranks of ONE process (host threads, e.g. on MGCG_VIRTUAL_DEVICES of a single
+// GPU) exchange through host memory behind a barrier.  It exists so that the multi-rank logic of
+// SolveParallel / the distributed V-cycle can be tested on a one-GPU box where RCCL cannot form a
+// communicator (one device per rank); production ranks use RCCL.
+struct MgcgLoopback {
+    int nranks = 1;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    long long generation = 0;
+    std::vector<double> slots;                       // nranks * 8 doubles (all-reduce staging)
+    std::vector<long long> meta;                     // nranks * 4 (halo-plan all-gather)
+    std::vector<std::vector<double>> mailbox;        // [src * nranks + dst]
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const long long gen = generation;
+        if (++arrived == nranks) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen; });
+    }
+};
+
 struct MgcgComm {
-    mgcg::NcclComm comm = nullptr;
+    mgcg::NcclComm comm = nullptr;   // RCCL transport
+    MgcgLoopback* loop = nullptr;    // loopback transport
     int nranks = 1, rank = 0;
     hipStream_t stream = nullptr;
     double* scratch = nullptr;       // device, 8 doubles
-    long long* gathered = nullptr;   // host copy of every rank's (offset, count, minJ, maxJ)
 };
 
 namespace mgcg {
 
 bool comm_allreduce_sum(MgcgComm* c, double* devPtr, int count, hipStream_t s)
 {
-    if (!c || c->comm == nullptr) return true;     // single rank without a communicator: the local sum is the sum
+    if (!c) return true;
+    if (c->loop) {
+        if (count > 8) { set_error("loopback all-reduce: at most 8 values"); return false; }
+        MgcgLoopback* g = c->loop;
+        double mine[8];
+        bool ok = MGCG_HIP(hipMemcpyAsync(mine, devPtr, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s));
+        ok = ok && MGCG_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < count; ++i) g->slots[(size_t)c->rank * 8 + i] = ok ? mine[i] : NAN;
+        g->barrier();
+        double sum[8];
+        for (int i = 0; i < count; ++i) { double a = 0; for (int q = 0; q < g->nranks; ++q) a += g->slots[(size_t)q * 8 + i]; sum[i] = a; }   // rank order: same bits on every rank
+        g->barrier();
+        ok = ok && MGCG_HIP(hipMemcpyAsync(devPtr, sum, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s));
+        ok = ok && MGCG_HIP(hipStreamSynchronize(s));
+        return ok;
+    }
+    if (c->comm == nullptr) return true;             // single rank without a communicator: the local sum is the sum
     Rccl* r = rccl();
     if (!r) return false;
     return nccl_ok(r->AllReduce(devPtr, devPtr, (size_t)count, NCCL_DOUBLE, NCCL_SUM, c->comm, s), "ncclAllReduce");
@@ -89,25 +128,35 @@ struct HaloPlan {
 
 HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long long countLocal, int minJ, int maxJ)
 {
+    (void)count;
     HaloPlan* h = new HaloPlan();
     if (!c || c->nranks == 1) return h;
-    Rccl* r = rccl();
-    if (!r) { delete h; return nullptr; }
     const int n = c->nranks;
     h->nranks = n;
     // all-gather (offset, count, minJ, maxJ) of every rank
-    long long mine[4] = { offset, countLocal, (long long)minJ, (long long)maxJ };
-    long long* dAll = nullptr;
-    if (!MGCG_HIP(hipMalloc((void**)&dAll, sizeof(long long) * 4 * (size_t)n))) { delete h; return nullptr; }
-    bool ok = MGCG_HIP(hipMemcpyAsync(dAll + 4 * c->rank, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
-    ok = ok && MGCG_HIP(hipStreamSynchronize(c->stream));
-    // 4 int64 = 8 int32 per rank
-    ok = ok && nccl_ok(r->AllGather(dAll + 4 * c->rank, dAll, 8, NCCL_INT32, c->comm, c->stream), "ncclAllGather");
     std::vector<long long> all(4 * (size_t)n);
-    ok = ok && MGCG_HIP(hipMemcpyAsync(all.data(), dAll, sizeof(long long) * 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    ok = ok && MGCG_HIP(hipStreamSynchronize(c->stream));
-    (void)hipFree(dAll);
-    if (!ok) { delete h; return nullptr; }
+    if (c->loop) {
+        MgcgLoopback* g = c->loop;
+        g->meta[4 * (size_t)c->rank + 0] = offset; g->meta[4 * (size_t)c->rank + 1] = countLocal;
+        g->meta[4 * (size_t)c->rank + 2] = minJ;   g->meta[4 * (size_t)c->rank + 3] = maxJ;
+        g->barrier();
+        all = g->meta;
+        g->barrier();
+    } else {
+        Rccl* r = rccl();
+        if (!r) { delete h; return nullptr; }
+        long long mine[4] = { offset, countLocal, (long long)minJ, (long long)maxJ };
+        long long* dAll = nullptr;
+        if (!MGCG_HIP(hipMalloc((void**)&dAll, sizeof(long long) * 4 * (size_t)n))) { delete h; return nullptr; }
+        bool ok = MGCG_HIP(hipMemcpyAsync(dAll + 4 * c->rank, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
+        ok = ok && MGCG_HIP(hipStreamSynchronize(c->stream));
+        // 4 int64 = 8 int32 per rank, in place
+        ok = ok && nccl_ok(r->AllGather(dAll + 4 * c->rank, dAll, 8, NCCL_INT32, c->comm, c->stream), "ncclAllGather");
+        ok = ok && MGCG_HIP(hipMemcpyAsync(all.data(), dAll, sizeof(long long) * 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        ok = ok && MGCG_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(dAll);
+        if (!ok) { delete h; return nullptr; }
+    }
     h->sendBegin.assign(n, 0); h->sendCount.assign(n, 0); h->recvBegin.assign(n, 0); h->recvCount.assign(n, 0);
     auto clip = [](long long lo, long long hi, long long a, long long b, long long& begin, long long& cnt) {
         const long long s = lo > a ? lo : a, e = hi < b ? hi : b;
@@ -121,7 +170,6 @@ HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long 
         // what q needs from me: my rows inside [qMin, qMax]
         if (qCnt > 0 && qMax >= qMin) clip(qMin, qMax + 1, offset, offset + countLocal, h->sendBegin[q], h->sendCount[q]);
     }
-    (void)count;
     return h;
 }
 
@@ -130,6 +178,27 @@ void halo_plan_destroy(HaloPlan* h) { delete h; }
 bool halo_exchange(MgcgComm* c, HaloPlan* h, double* p, hipStream_t s)
 {
     if (!c || c->nranks == 1 || !h) return true;
+    if (c->loop) {
+        MgcgLoopback* g = c->loop;
+        bool ok = true;
+        for (int q = 0; q < h->nranks; ++q) {
+            std::vector<double>& box = g->mailbox[(size_t)c->rank * g->nranks + q];
+            box.resize((size_t)h->sendCount[q]);
+            if (h->sendCount[q] > 0) ok = ok && MGCG_HIP(hipMemcpyAsync(box.data(), p + h->sendBegin[q], sizeof(double) * (size_t)h->sendCount[q], hipMemcpyDeviceToHost, s));
+        }
+        ok = MGCG_HIP(hipStreamSynchronize(s)) && ok;
+        g->barrier();
+        for (int q = 0; q < h->nranks; ++q) {
+            const std::vector<double>& box = g->mailbox[(size_t)q * g->nranks + c->rank];
+            if (h->recvCount[q] > 0) {
+                if ((long long)box.size() != h->recvCount[q]) { set_error("loopback halo: rank %d sent %zu values, rank %d expected %lld", q, box.size(), c->rank, h->recvCount[q]); ok = false; continue; }
+                ok = ok && MGCG_HIP(hipMemcpyAsync(p + h->recvBegin[q], box.data(), sizeof(double) * box.size(), hipMemcpyHostToDevice, s));
+            }
+        }
+        ok = MGCG_HIP(hipStreamSynchronize(s)) && ok;
+        g->barrier();
+        return ok;
+    }
     Rccl* r = rccl();
     if (!r) return false;
     bool ok = nccl_ok(r->GroupStart(), "ncclGroupStart");
@@ -172,6 +241,30 @@ MgcgComm* MgcgCommInitRank(const void* id128, int nranks, int rank)
         memcpy(&id, id128, sizeof(id));
         if (!nccl_ok(r->CommInitRank(&c->comm, nranks, id, rank), "ncclCommInitRank")) { (void)hipFree(c->scratch); delete c; return nullptr; }
     }
+    return c;
+}
+
+MgcgLoopback* MgcgLoopbackCreate(int nranks)
+{
+    if (nranks < 1 || nranks > 64) { set_error("MgcgLoopbackCreate: bad rank count %d", nranks); return nullptr; }
+    MgcgLoopback* g = new MgcgLoopback();
+    g->nranks = nranks;
+    g->slots.assign((size_t)nranks * 8, 0.0);
+    g->meta.assign((size_t)nranks * 4, 0);
+    g->mailbox.resize((size_t)nranks * nranks);
+    return g;
+}
+
+void MgcgLoopbackDestroy(MgcgLoopback* g) { delete g; }
+
+MgcgComm* MgcgCommInitLoopback(MgcgLoopback* group, int rank)
+{
+    DeviceState* d = device_state();
+    if (!d) return nullptr;
+    if (!group || rank < 0 || rank >= group->nranks) { set_error("MgcgCommInitLoopback: bad argument"); return nullptr; }
+    MgcgComm* c = new MgcgComm();
+    c->nranks = group->nranks; c->rank = rank; c->stream = d->stream; c->loop = group;
+    if (!MGCG_HIP(hipMalloc((void**)&c->scratch, 8 * sizeof(double)))) { delete c; return nullptr; }
     return c;
 }
 

@@ -274,6 +274,13 @@ MgcgComm* MgcgCommInitRank(const void* id128, int nranks, int rank);
 void      MgcgCommDestroy(MgcgComm* comm);
 int       MgcgCommRank(const MgcgComm* comm);
 int       MgcgCommSize(const MgcgComm* comm);
+/* In-process loopback transport: N ranks of ONE process (host threads, e.g. MGCG_VIRTUAL_DEVICES on one GPU)
+ * exchange through host memory behind a barrier.  For testing the multi-rank logic where RCCL cannot form a
+ * communicator (it needs one device per rank); every rank must make the same sequence of solver calls. */
+typedef struct MgcgLoopback MgcgLoopback;
+MgcgLoopback* MgcgLoopbackCreate(int nranks);
+void          MgcgLoopbackDestroy(MgcgLoopback* group);
+MgcgComm*     MgcgCommInitLoopback(MgcgLoopback* group, int rank);
 /* sum of one double over all ranks (test / bootstrap helper; blocking). */
 double    MgcgCommAllReduceSum(MgcgComm* comm, double value);
 /* The whole multi-rank CG of ConjugateGradientParallelGpu.Solve (ConjugateGradientParallelGpu.cs:424-565)

@@ -90,3 +90,71 @@ def test_phased_ranks_share_the_gpu_over_gloo(oracle, tmp_path):
         x[int(d["offset"]): int(d["offset"]) + int(d["count"])] = d["x"]
         assert int(d["iteration"]) == ref["iteration"]
     assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
+
+
+def _run_ranks_in_threads(world, make_rank):
+    """world ranks of this process as host threads on MGCG_VIRTUAL_DEVICES of the one GPU, joined by the
+    library's loopback transport (RCCL needs one device per rank, so it cannot be used for this on the test box)."""
+    import threading
+
+    L = _lib.lib()
+    group = L.MgcgLoopbackCreate(world)
+    results, errors = [None] * world, [None] * world
+
+    def body(rank):
+        try:
+            L.SetDevice(rank)
+            comm = L.MgcgCommInitLoopback(group, rank)
+            assert comm, _lib.last_error()
+            results[rank] = make_rank(rank, comm)
+            L.MgcgCommDestroy(comm)
+        except BaseException as e:      # noqa: BLE001 -- report after join
+            errors[rank] = e
+            raise
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    L.MgcgLoopbackDestroy(group)
+    for e in errors:
+        if e is not None:
+            raise e
+    return results
+
+
+@pytest.mark.parametrize("world,which", [(2, "banded"), (4, "banded"), (3, "poisson"), (2, "unstructured")])
+def test_native_multirank_loop_over_loopback(oracle, monkeypatch, world, which):
+    """SolveParallel with N > 1: partition, halo plan + exchange, all-reduced dot products and the per-chunk stop
+    decision, against the multi-device oracle (ConjugateGradientParallelGpu.cs:424-565 restated)."""
+    monkeypatch.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    if which == "banded":
+        s = problems.mgcg_main(2403, 160)
+    elif which == "poisson":
+        s = problems.poisson(12, 10, 9)
+    else:
+        s = problems.random_spd(1500, mean_upper=6.0, seed=21)
+    ref = oracle.cg_parallel(s, world, max_iteration=s.Count, trace=True)
+    maxnz = int(np.diff(s.RowOffsets).max())
+
+    def make_rank(rank, comm):
+        cg = ConjugateGradientRankGpu(s.Count, maxnz, 0, s.Count, 1e-8, rank=rank, world=world, comm=comm, device=rank).load(s)
+        cg.Initialize()
+        lo, hi = oracle.minmax_column(s, cg.part.offset, cg.part.offset + cg.part.count)
+        assert (cg.part.minJ, cg.part.maxJ) == (lo, hi)
+        cg.Solve(trace=True)
+        cg.Read()
+        out = (cg.part.offset, cg.part.count, cg.x[cg.part.offset: cg.part.offset + cg.part.count].copy(), cg.Iteration, cg.Residual, cg.trace)
+        cg.Dispose()
+        return out
+
+    res = _run_ranks_in_threads(world, make_rank)
+    x = np.zeros(s.Count)
+    for off, cnt, xs, it, resid, tr in res:
+        x[off: off + cnt] = xs
+        assert it == ref["iteration"]
+        assert resid == res[0][4]                       # every rank holds the same all-reduced bits
+        from tests.gpu_util import assert_trace_close
+        assert_trace_close(tr, ref["trace"])
+    assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
