@@ -135,7 +135,9 @@ def test_native_multirank_loop_over_loopback(oracle, monkeypatch, world, which):
         s = problems.poisson(12, 10, 9)
     else:
         s = problems.random_spd(1500, mean_upper=6.0, seed=21)
+        s.b[:] = np.cos(np.arange(s.Count) * 0.7) * (1.0 + np.arange(s.Count) % 5)     # (b = A.1 would converge at once)
     ref = oracle.cg_parallel(s, world, max_iteration=s.Count, trace=True)
+    assert ref["iteration"] >= 5
     maxnz = int(np.diff(s.RowOffsets).max())
 
     def make_rank(rank, comm):
