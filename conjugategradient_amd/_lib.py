@@ -88,6 +88,7 @@ SIGNATURES = {
     "MgcgFill": (None, [_vp, _d]),
     "SolveEx": (_i, [_vp] * 11 + [_i, _i, _d, _i, _i, _i, _pi, _pd, _vp, _i]),
     "MgSetup": (_vp, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _i, _d]),
+    "MgSetupParallel": (_vp, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _d, _i, _i, _d]),
     "MgDestroy": (None, [_vp]),
     "MgLevels": (_i, [_vp]),
     "MgLevelRows": (_ll, [_vp, _i]),
@@ -96,6 +97,7 @@ SIGNATURES = {
     "MgLevelCopyDinv": (None, [_vp, _i, _vp]),
     "MgApply": (None, [_vp, _vp, _vp]),
     "SolveMg": (_i, [_vp] * 13 + [_i, _i, _d, _i, _i, _i, _pi, _pd, _vp, _i]),
+    "SolveMgParallel": (_i, [_vp] * 14 + [_i, _i, _i, _i, _i, _i, _d, _i, _i, _i, _pi, _pd, _vp, _i]),
     "MgcgCommGetUniqueId": (_i, [_vp]),
     "MgcgCommInitRank": (_vp, [_vp, _i, _i]),
     "MgcgLoopbackCreate": (_vp, [_i]),

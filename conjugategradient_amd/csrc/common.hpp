@@ -184,7 +184,7 @@ void launch_prolong_add(hipStream_t s, int nx, int ny, int nz, double* x, const 
 void launch_extract_dinv(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces,
                          long long n, long long rowBase, double* dinv);
 // Galerkin: count pass (elementsC == nullptr) writes per-row counts to countsC[I]; fill pass writes entries.
-void launch_galerkin(hipStream_t s, int nx, int ny, int nz, const double* elements, const int* rowOffsets, const int* columnIndeces,
+void launch_galerkin(hipStream_t s, int nx, int ny, int nz, int zBegin, int zEnd, const double* elements, const int* rowOffsets, const int* columnIndeces,
                      double sigma, const int* rowOffsetsC, int* countsC, double* elementsC, int* columnIndecesC, int* errFlag);
 void launch_poisson(hipStream_t s, int nx, int ny, int nz, int zBegin, int zEnd, double* elements, int* rowOffsets, int* columnIndeces);
 void launch_rebase(hipStream_t s, int* rowOffsets, long long n, int base);

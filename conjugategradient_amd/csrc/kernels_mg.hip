@@ -93,19 +93,24 @@ void launch_extract_dinv(hipStream_t s, const double* elements, const int* rowOf
     hipLaunchKernelGGL(extract_dinv_kernel, dim3(grid1(n)), dim3(kBlock), 0, s, elements, rowOffsets, columnIndeces, n, rowBase, dinv);
 }
 
-// sigma * P^T A P on the 27-slot neighbourhood, one lane per coarse row, same accumulation order as
-// oracle_mg_galerkin.  elementsC == nullptr: count pass (countsC[I] = touched slots).
-__global__ __launch_bounds__(kBlock) void galerkin_kernel(int nx, int ny, int nz, const double* __restrict__ elements, const int* __restrict__ rowOffsets,
+// sigma * P^T A P on the 27-slot neighbourhood, one lane per LOCAL coarse row (the rank's z-slab [zBegin, zEnd)
+// of the fine grid; fine rows are slab-local, column ids global), same accumulation order as oracle_mg_galerkin.
+// elementsC == nullptr: count pass (countsC[I] = touched slots).
+__global__ __launch_bounds__(kBlock) void galerkin_kernel(int nx, int ny, int nz, int zBegin, int zEnd,
+                                                          const double* __restrict__ elements, const int* __restrict__ rowOffsets,
                                                           const int* __restrict__ columnIndeces, double sigma, const int* __restrict__ rowOffsetsC,
                                                           int* __restrict__ countsC, double* __restrict__ elementsC, int* __restrict__ columnIndecesC, int* errFlag)
 {
     const int cx = nx > 1 ? 2 : 1, cy = ny > 1 ? 2 : 1, cz = nz > 1 ? 2 : 1;
-    const int NX = nx / cx, NY = ny / cy, NZ = nz / cz;
-    const long long NC = (long long)NX * NY * NZ;
+    const int NX = nx / cx, NY = ny / cy;
+    const int ZL = (zEnd - zBegin) / cz;              // local coarse planes
+    const int Z0 = zBegin / cz;
+    const long long NC = (long long)NX * NY * ZL;
     const long long sxy = (long long)nx * ny;
     const long long stride = (long long)gridDim.x * kBlock;
     for (long long I = (long long)blockIdx.x * kBlock + threadIdx.x; I < NC; I += stride) {
-        const int X = (int)(I % NX), Y = (int)((I / NX) % NY), Z = (int)(I / ((long long)NX * NY));
+        const int X = (int)(I % NX), Y = (int)((I / NX) % NY), Zl = (int)(I / ((long long)NX * NY));
+        const int Z = Z0 + Zl;
         double acc[27];
         unsigned touched = 0u;
 #pragma unroll
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void galerkin_kernel(int nx, int ny, int nz
         for (int dz = 0; dz < cz; ++dz)
             for (int dy = 0; dy < cy; ++dy)
                 for (int dx = 0; dx < cx; ++dx) {
-                    const long long i = ((long long)(Z * cz + dz) * ny + (Y * cy + dy)) * nx + (X * cx + dx);
+                    const long long i = ((long long)(Zl * cz + dz) * ny + (Y * cy + dy)) * nx + (X * cx + dx);   // slab-local fine row
                     for (int k = rowOffsets[i]; k < rowOffsets[i + 1]; ++k) {
                         const long long j = columnIndeces[k];
                         const int jx = (int)(j % nx), jy = (int)((j / nx) % ny), jz = (int)(j / sxy);
@@ -134,16 +139,16 @@ __global__ __launch_bounds__(kBlock) void galerkin_kernel(int nx, int ny, int nz
             if (!(touched & (1u << q))) continue;
             const int ox = q % 3 - 1, oy = (q / 3) % 3 - 1, oz = q / 9 - 1;
             elementsC[kout] = sigma * acc[q];
-            columnIndecesC[kout] = (int)(((long long)(Z + oz) * NY + (Y + oy)) * NX + (X + ox));
+            columnIndecesC[kout] = (int)(((long long)(Z + oz) * NY + (Y + oy)) * NX + (X + ox));   // global coarse column
             ++kout;
         }
     }
 }
-void launch_galerkin(hipStream_t s, int nx, int ny, int nz, const double* elements, const int* rowOffsets, const int* columnIndeces,
+void launch_galerkin(hipStream_t s, int nx, int ny, int nz, int zBegin, int zEnd, const double* elements, const int* rowOffsets, const int* columnIndeces,
                      double sigma, const int* rowOffsetsC, int* countsC, double* elementsC, int* columnIndecesC, int* errFlag)
 {
-    const long long NC = (long long)(nx > 1 ? nx / 2 : 1) * (ny > 1 ? ny / 2 : 1) * (nz > 1 ? nz / 2 : 1);
-    hipLaunchKernelGGL(galerkin_kernel, dim3(grid1(NC)), dim3(kBlock), 0, s, nx, ny, nz, elements, rowOffsets, columnIndeces,
+    const long long NC = (long long)(nx > 1 ? nx / 2 : 1) * (ny > 1 ? ny / 2 : 1) * (nz > 1 ? (zEnd - zBegin) / 2 : 1);
+    hipLaunchKernelGGL(galerkin_kernel, dim3(grid1(NC)), dim3(kBlock), 0, s, nx, ny, nz, zBegin, zEnd, elements, rowOffsets, columnIndeces,
                        sigma, rowOffsetsC, countsC, elementsC, columnIndecesC, errFlag);
 }
 

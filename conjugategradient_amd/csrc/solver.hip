@@ -13,15 +13,22 @@
 namespace mgcg {
 
 // ---------------------------------------------------------------- multigrid hierarchy
+// Every level lives on the rank's z-slab [z0, z1) of that level's grid: local CSR rows with GLOBAL column ids,
+// local rhs / residual / D^-1, and two FULL-length iterate buffers (like p in the CG loop) whose halo planes are
+// exchanged before every SpMV-shaped pass.  A single rank is the special case z0 = 0, z1 = nz.
 struct MgLevel {
-    int nx = 0, ny = 0, nz = 0;
-    long long n = 0, nnz = 0;
+    int nx = 0, ny = 0, nz = 0;            // global grid of the level
+    int z0 = 0, z1 = 0;                    // this rank's planes
+    long long n = 0, nnz = 0;              // local rows / nonzeros
+    long long nGlobal = 0, offset = 0;     // global rows, first local row
     double* elements = nullptr; int* rowOffsets = nullptr; int* columnIndeces = nullptr;
     bool ownsMatrix = false;
     double* dinv = nullptr;
-    double *xa = nullptr, *xb = nullptr;   // solution ping-pong (Jacobi is not in place)
-    double *b = nullptr, *r = nullptr;     // right-hand side (restricted residual), residual
+    double *xa = nullptr, *xb = nullptr;   // iterate ping-pong, full length (Jacobi is not in place)
+    double *b = nullptr, *r = nullptr;     // right-hand side (restricted residual), residual; local
     SpmvConfig cfg;                        // per level: kernel picked from its nnz/row, banded period = nx*ny
+    HaloPlan* halo = nullptr;              // multi-rank: planes of the iterate owned by the neighbours
+    int minJ = 0, maxJ = -1;
 };
 
 } // namespace mgcg
@@ -32,6 +39,8 @@ struct MgcgMg {
     std::vector<mgcg::MgLevel> lv;
     mgcg::SpmvConfig cfg;
     hipStream_t stream = nullptr;
+    MgcgComm* comm = nullptr;              // not owned
+    int nranks = 1;
 };
 
 namespace mgcg {
@@ -42,59 +51,80 @@ static SpmvConfig cfg_of(const MgcgSparse* h)
     return c;
 }
 
-static void mg_jacobi(MgcgMg* mg, MgLevel& L, const double* b, const double* xin, double* xout, const int* done)
+static bool mg_halo(MgcgMg* mg, MgLevel& L, double* xfull)
 {
+    if (mg->nranks == 1) return true;
+    return halo_exchange(mg->comm, L.halo, xfull, mg->stream);
+}
+
+// xout_loc = xin_loc + omega * (dinv * (b - A xin)); xin / xout are full-length buffers
+static bool mg_jacobi(MgcgMg* mg, MgLevel& L, const double* b, double* xin, double* xout, const int* done)
+{
+    if (!mg_halo(mg, L, xin)) return false;
     SpmvArgs a{};
-    a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = xin; a.y = xout;
-    a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.n;
-    a.w = xin; a.b = b; a.dinv = L.dinv; a.omega = mg->omega; a.doneFlag = done;
+    a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = xin; a.y = xout + L.offset;
+    a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal;
+    a.w = xin + L.offset; a.b = b; a.dinv = L.dinv; a.omega = mg->omega; a.doneFlag = done;
     launch_spmv(mg->stream, EPI_JACOBI, a, L.cfg);
+    return true;
 }
 
 // `sweeps` Jacobi sweeps on level L for right-hand side b.  first: the first sweep starts from zero.
-// cur is the buffer holding the iterate (ignored when first); returns the buffer holding the result.
-static double* mg_smooth(MgcgMg* mg, MgLevel& L, const double* b, double* cur, double* other, int sweeps, bool first, const int* done)
+// cur is the buffer holding the iterate (ignored when first); *result receives the buffer holding the result.
+static bool mg_smooth(MgcgMg* mg, MgLevel& L, const double* b, double* cur, double* other, int sweeps, bool first, const int* done, double** result)
 {
     for (int sIdx = 0; sIdx < sweeps; ++sIdx) {
         if (first && sIdx == 0) {
-            launch_jacobi_first(mg->stream, L.n, mg->omega, L.dinv, b, cur, done);
+            launch_jacobi_first(mg->stream, L.n, mg->omega, L.dinv, b, cur + L.offset, done);
         } else {
-            mg_jacobi(mg, L, b, cur, other, done);
+            if (!mg_jacobi(mg, L, b, cur, other, done)) return false;
             double* t = cur; cur = other; other = t;
         }
     }
-    return cur;
+    *result = cur;
+    return true;
 }
 
-// One V(nu,nu) cycle on level l for right-hand side b; x0/x1 are that level's two iterate buffers.
-// Returns the buffer that holds the result.  Mirrors vcycle() of oracle/mg_oracle.c.
-static double* mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1, const int* done)
+// One V(nu,nu) cycle on level l for right-hand side b (local); x0/x1 are that level's two full-length iterate
+// buffers.  *result receives the buffer that holds the answer.  Mirrors vcycle() of oracle/mg_oracle.c.
+static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1, const int* done, double** result)
 {
     MgLevel& L = mg->lv[l];
-    if (l == mg->levels - 1) return mg_smooth(mg, L, b, x0, x1, mg->nuCoarse, true, done);
+    if (l == mg->levels - 1) return mg_smooth(mg, L, b, x0, x1, mg->nuCoarse, true, done, result);
     MgLevel& C = mg->lv[l + 1];
-    double* cur = mg_smooth(mg, L, b, x0, x1, mg->nu, true, done);
+    double* cur = nullptr;
+    if (!mg_smooth(mg, L, b, x0, x1, mg->nu, true, done, &cur)) return false;
     double* other = (cur == x0) ? x1 : x0;
+    if (!mg_halo(mg, L, cur)) return false;
     SpmvArgs a{};
     a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = cur; a.y = L.r;
-    a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.n; a.b = b; a.doneFlag = done;
-    launch_spmv(mg->stream, EPI_RESIDUAL, a, L.cfg);                          // r = b - A x
-    launch_restrict(mg->stream, L.nx, L.ny, L.nz, L.r, C.b, done);            // b_c = P^T r
-    double* e = mg_vcycle(mg, l + 1, C.b, C.xa, C.xb, done);
-    launch_prolong_add(mg->stream, L.nx, L.ny, L.nz, cur, e, done);           // x += P e
-    return mg_smooth(mg, L, b, cur, other, mg->nu, false, done);
+    a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal; a.b = b; a.doneFlag = done;
+    launch_spmv(mg->stream, EPI_RESIDUAL, a, L.cfg);                                          // r = b - A x
+    launch_restrict(mg->stream, L.nx, L.ny, L.z1 - L.z0, L.r, C.b, done);                     // b_c = P^T r (slab-local)
+    double* e = nullptr;
+    if (!mg_vcycle(mg, l + 1, C.b, C.xa, C.xb, done, &e)) return false;
+    launch_prolong_add(mg->stream, L.nx, L.ny, L.z1 - L.z0, cur + L.offset, e + C.offset, done);   // x += P e (slab-local)
+    return mg_smooth(mg, L, b, cur, other, mg->nu, false, done, result);
 }
 
-// z = M^-1 r.  Level 0 iterates ping-pong between z and lv[0].xa so that the result lands in z.
-static void mg_apply(MgcgMg* mg, const double* r, double* z, const int* done)
+// z = M^-1 r (both local).  A single rank ping-pongs level 0 between z itself and lv[0].xa so that the result
+// lands in z; with several ranks the iterates must be full length, so the result is copied out of lv[0].xa/xb.
+static bool mg_apply(MgcgMg* mg, const double* r, double* z, const int* done)
 {
     MgLevel& L0 = mg->lv[0];
-    // swaps on level 0: (nu-1) pre + nu post, or (nuCoarse-1) when there is a single level
-    const int swaps = (mg->levels == 1) ? (mg->nuCoarse - 1) : (2 * mg->nu - 1);
-    double* start = (swaps % 2 == 0) ? z : L0.xa;
-    double* other = (start == z) ? L0.xa : z;
-    double* res = mg_vcycle(mg, 0, r, start, other, done);
-    if (res != z) launch_copy(mg->stream, z, res, L0.n);   // not reached for the buffer choice above
+    double* res = nullptr;
+    if (mg->nranks == 1) {
+        // swaps on level 0: (nu-1) pre + nu post, or (nuCoarse-1) when there is a single level
+        const int swaps = (mg->levels == 1) ? (mg->nuCoarse - 1) : (2 * mg->nu - 1);
+        double* start = (swaps % 2 == 0) ? z : L0.xa;
+        double* other = (start == z) ? L0.xa : z;
+        if (!mg_vcycle(mg, 0, r, start, other, done, &res)) return false;
+        if (res != z) launch_copy(mg->stream, z, res, L0.n);       // not reached for the buffer choice above
+        return true;
+    }
+    if (!mg_vcycle(mg, 0, r, L0.xa, L0.xb, done, &res)) return false;
+    launch_copy(mg->stream, z, res + L0.offset, L0.n);
+    return true;
 }
 
 // ---------------------------------------------------------------- the CG loop
@@ -153,7 +183,7 @@ static bool cg_enqueue_init(CgRun& R)
     launch_spmv(s, EPI_RESIDUAL, a, R.cfg);                                          // r = b - A x   (Mgcg.cu:225-226)
     int n;
     if (R.mg) {
-        mg_apply(R.mg, R.r, R.z, nullptr);                                           // z = M^-1 r
+        if (!mg_apply(R.mg, R.r, R.z, nullptr)) return false;                        // z = M^-1 r
         launch_copy(s, pLoc, R.z, R.nLocal);                                         // p = z
         n = launch_dot_partials(s, R.r, R.z, R.nLocal, R.ws->partials);              // rz = r.z
     } else {
@@ -199,7 +229,7 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
         launch_finalize(s, R.ws->partials, pInf, n, true, f);                        // residual, stop test, beta  (:251-266)
     }
     if (R.mg) {
-        mg_apply(R.mg, R.r, R.z, done);                                              // z = M^-1 r
+        if (!mg_apply(R.mg, R.r, R.z, done)) return false;                           // z = M^-1 r
         n = launch_dot_partials(s, R.r, R.z, R.nLocal, R.ws->partials);
         if (R.nranks > 1) {
             launch_reduce_to(s, R.ws->partials, n, &sc->rzNew, done);
@@ -406,40 +436,56 @@ double MgcgProfileSpmvMs(MgcgSparse* h, int* launches)
 }
 
 // ---------------------------------------------------------------- multigrid
-MgcgMg* MgSetup(MgcgBlas* cublas, MgcgSparse* cusparse,
-                Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
-                int elementsCount, int nx, int ny, int nz,
-                int levels, double omega, int nu, int nuCoarse, double sigma)
+MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
+                        Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+                        int elementsCount, int nx, int ny, int nz, int zBegin, int zEnd,
+                        int levels, double omega, int nu, int nuCoarse, double sigma)
 {
     DeviceState* d = device_state();
     if (!d) return nullptr;
     if (!cublas || !cusparse || !elementsVector || !rowOffsetsVector || !columnIndecesVector) { set_error("MgSetup: null argument"); return nullptr; }
-    const long long n0 = (long long)nx * ny * nz;
-    if (nx < 1 || ny < 1 || nz < 1 || levels < 1 || nu < 1 || nuCoarse < 1 || n0 > 0x7fffffffLL) { set_error("MgSetup: bad parameters"); return nullptr; }
-    if (rowOffsetsVector->size < n0 + 1 || elementsVector->size < elementsCount || columnIndecesVector->size < elementsCount) { set_error("MgSetup: matrix vectors too small"); return nullptr; }
+    const long long nGlobal0 = (long long)nx * ny * nz;
+    const int nranks = MgcgCommSize(comm);
+    if (nx < 1 || ny < 1 || nz < 1 || levels < 1 || nu < 1 || nuCoarse < 1 || nGlobal0 > 0x7fffffffLL || zBegin < 0 || zEnd > nz || zBegin >= zEnd) { set_error("MgSetup: bad parameters"); return nullptr; }
+    const long long nLocal0 = (long long)nx * ny * (zEnd - zBegin);
+    if (rowOffsetsVector->size < nLocal0 + 1 || elementsVector->size < elementsCount || columnIndecesVector->size < elementsCount) { set_error("MgSetup: matrix vectors too small"); return nullptr; }
+    if (nranks > 1 && (nz % nranks != 0 || (zEnd - zBegin) != nz / nranks || zBegin != MgcgCommRank(comm) * (nz / nranks))) {
+        set_error("MgSetup: with several ranks the grid must be split into equal z-slabs in rank order"); return nullptr;
+    }
     hipStream_t s = d->stream;
     MgcgMg* mg = new MgcgMg();
     mg->omega = omega; mg->nu = nu; mg->nuCoarse = nuCoarse; mg->sigma = sigma; mg->stream = s; mg->cfg = cfg_of(cusparse);
     mg->cfg.kernel = 0;   // every level picks its kernel from its own nnz/row
+    mg->comm = comm; mg->nranks = nranks;
     int* dErr = nullptr;
-    bool ok = MGCG_HIP(hipMalloc((void**)&dErr, sizeof(int))) && MGCG_HIP(hipMemsetAsync(dErr, 0, sizeof(int), s));
+    int* dmm = nullptr;
+    bool ok = MGCG_HIP(hipMalloc((void**)&dErr, sizeof(int))) && MGCG_HIP(hipMemsetAsync(dErr, 0, sizeof(int), s)) && MGCG_HIP(hipMalloc((void**)&dmm, 2 * sizeof(int)));
     for (int l = 0; ok && l < levels; ++l) {
         MgLevel L;
         if (l == 0) {
-            L.nx = nx; L.ny = ny; L.nz = nz; L.n = n0; L.nnz = elementsCount;
+            L.nx = nx; L.ny = ny; L.nz = nz; L.z0 = zBegin; L.z1 = zEnd; L.nnz = elementsCount;
             L.elements = elementsVector->data; L.rowOffsets = rowOffsetsVector->data; L.columnIndeces = columnIndecesVector->data;
         } else {
             const MgLevel& F = mg->lv[l - 1];
             if ((F.nx > 1 && F.nx % 2) || (F.ny > 1 && F.ny % 2) || (F.nz > 1 && F.nz % 2)) break;   // cannot coarsen an odd extent
             if (F.nx == 1 && F.ny == 1 && F.nz == 1) break;
+            // the slab must stay aligned: every rank sees the same answer because the slabs are equal
+            if (F.nz > 1 && ((F.z0 % 2) || (F.z1 % 2))) break;
+            if (nranks > 1 && F.nz == 1) break;
             L.nx = F.nx > 1 ? F.nx / 2 : 1; L.ny = F.ny > 1 ? F.ny / 2 : 1; L.nz = F.nz > 1 ? F.nz / 2 : 1;
-            L.n = (long long)L.nx * L.ny * L.nz;
+            L.z0 = F.nz > 1 ? F.z0 / 2 : 0; L.z1 = F.nz > 1 ? F.z1 / 2 : 1;
+        }
+        L.nGlobal = (long long)L.nx * L.ny * L.nz;
+        L.n = (long long)L.nx * L.ny * (L.z1 - L.z0);
+        L.offset = (long long)L.nx * L.ny * L.z0;
+        if (l > 0) {
+            const MgLevel& F = mg->lv[l - 1];
             L.ownsMatrix = true;
             int* counts = nullptr;
             ok = ok && MGCG_HIP(hipMalloc((void**)&L.rowOffsets, sizeof(int) * (size_t)(L.n + 1)));
             ok = ok && MGCG_HIP(hipMalloc((void**)&counts, sizeof(int) * (size_t)L.n));
             if (!ok) break;
-            launch_galerkin(s, F.nx, F.ny, F.nz, F.elements, F.rowOffsets, F.columnIndeces, sigma, nullptr, counts, nullptr, nullptr, dErr);
+            launch_galerkin(s, F.nx, F.ny, F.nz, F.z0, F.z1, F.elements, F.rowOffsets, F.columnIndeces, sigma, nullptr, counts, nullptr, nullptr, dErr);
             std::vector<int> h((size_t)L.n + 1);
             ok = ok && MGCG_HIP(hipMemcpyAsync(h.data() + 1, counts, sizeof(int) * (size_t)L.n, hipMemcpyDeviceToHost, s));
             int err = 0;
@@ -456,27 +502,47 @@ MgcgMg* MgSetup(MgcgBlas* cublas, MgcgSparse* cusparse,
             ok = ok && MGCG_HIP(hipMalloc((void**)&L.elements, sizeof(double) * (size_t)(L.nnz > 0 ? L.nnz : 1)));
             ok = ok && MGCG_HIP(hipMalloc((void**)&L.columnIndeces, sizeof(int) * (size_t)(L.nnz > 0 ? L.nnz : 1)));
             if (!ok) break;
-            launch_galerkin(s, F.nx, F.ny, F.nz, F.elements, F.rowOffsets, F.columnIndeces, sigma, L.rowOffsets, nullptr, L.elements, L.columnIndeces, dErr);
+            launch_galerkin(s, F.nx, F.ny, F.nz, F.z0, F.z1, F.elements, F.rowOffsets, F.columnIndeces, sigma, L.rowOffsets, nullptr, L.elements, L.columnIndeces, dErr);
             ok = ok && MGCG_HIP(hipStreamSynchronize(s));   // h must outlive the copy
         }
         ok = ok && MGCG_HIP(hipMalloc((void**)&L.dinv, sizeof(double) * (size_t)L.n));
-        ok = ok && MGCG_HIP(hipMalloc((void**)&L.xa, sizeof(double) * (size_t)L.n));
+        ok = ok && MGCG_HIP(hipMalloc((void**)&L.xa, sizeof(double) * (size_t)L.nGlobal));
         ok = ok && MGCG_HIP(hipMalloc((void**)&L.r, sizeof(double) * (size_t)L.n));
-        if (l > 0) {
-            ok = ok && MGCG_HIP(hipMalloc((void**)&L.xb, sizeof(double) * (size_t)L.n));
-            ok = ok && MGCG_HIP(hipMalloc((void**)&L.b, sizeof(double) * (size_t)L.n));
+        if (l > 0 || nranks > 1) ok = ok && MGCG_HIP(hipMalloc((void**)&L.xb, sizeof(double) * (size_t)L.nGlobal));
+        if (l > 0) ok = ok && MGCG_HIP(hipMalloc((void**)&L.b, sizeof(double) * (size_t)L.n));
+        if (ok && nranks > 1) {   // halo entries that no neighbour owns (outside the global range) are never read; the rest must start defined
+            ok = ok && MGCG_HIP(hipMemsetAsync(L.xa, 0, sizeof(double) * (size_t)L.nGlobal, s)) && MGCG_HIP(hipMemsetAsync(L.xb, 0, sizeof(double) * (size_t)L.nGlobal, s));
         }
-        if (ok) launch_extract_dinv(s, L.elements, L.rowOffsets, L.columnIndeces, L.n, 0, L.dinv);
+        if (ok) launch_extract_dinv(s, L.elements, L.rowOffsets, L.columnIndeces, L.n, L.offset, L.dinv);
         L.cfg = mg->cfg;
         L.cfg.periodRows = (L.nz > 1) ? L.nx * L.ny : 0;       // far band of a 3-D stencil = one grid plane
         if (L.cfg.periodRows > 0) L.cfg.flags |= 4; else L.cfg.flags &= ~4;
+        if (ok && nranks > 1) {
+            int init[2] = { 0x7fffffff, (int)0x80000000 }, out[2] = { 0, -1 };
+            ok = ok && MGCG_HIP(hipMemcpyAsync(dmm, init, sizeof(init), hipMemcpyHostToDevice, s));
+            if (ok && L.nnz > 0) launch_minmax_int(s, L.columnIndeces, L.nnz, dmm);
+            ok = ok && MGCG_HIP(hipMemcpyAsync(out, dmm, sizeof(out), hipMemcpyDeviceToHost, s));
+            ok = ok && MGCG_HIP(hipStreamSynchronize(s));
+            L.minJ = out[0]; L.maxJ = out[1];
+            if (ok) { L.halo = halo_plan_create(comm, L.nGlobal, L.offset, L.n, L.minJ, L.maxJ); ok = L.halo != nullptr; }
+        }
         mg->lv.push_back(L);
         mg->levels = (int)mg->lv.size();
     }
     ok = ok && MGCG_HIP(hipStreamSynchronize(s));
     if (dErr) (void)hipFree(dErr);
+    if (dmm) (void)hipFree(dmm);
     if (!ok || mg->levels == 0) { MgDestroy(mg); return nullptr; }
     return mg;
+}
+
+MgcgMg* MgSetup(MgcgBlas* cublas, MgcgSparse* cusparse,
+                Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+                int elementsCount, int nx, int ny, int nz,
+                int levels, double omega, int nu, int nuCoarse, double sigma)
+{
+    return MgSetupParallel(nullptr, cublas, cusparse, elementsVector, rowOffsetsVector, columnIndecesVector, elementsCount,
+                           nx, ny, nz, 0, nz, levels, omega, nu, nuCoarse, sigma);
 }
 
 void MgDestroy(MgcgMg* mg)
@@ -490,6 +556,7 @@ void MgDestroy(MgcgMg* mg)
         if (L.xb) (void)hipFree(L.xb);
         if (L.b) (void)hipFree(L.b);
         if (L.r) (void)hipFree(L.r);
+        if (L.halo) halo_plan_destroy(L.halo);
     }
     delete mg;
 }
@@ -518,8 +585,40 @@ void MgApply(MgcgMg* mg, const double* r, double* z)
 {
     if (!device_state()) return;
     if (!mg || !r || !z) { set_error("MgApply: null argument"); return; }
-    mg_apply(mg, r, z, nullptr);
+    (void)mg_apply(mg, r, z, nullptr);
     (void)MGCG_HIP(hipGetLastError());
+}
+
+int SolveMgParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr, MgcgMg* mg,
+                    Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+                    Vector* xVector, Vector* bVector, Vector* ApVector, Vector* pVector, Vector* rVector, Vector* zVector,
+                    int count, int countForDevice, int offsetForDevice, int elementsCountForDevice, int minJ, int maxJ,
+                    double allowableResidual, int minIteration, int maxIteration, int rule,
+                    int* iteration, double* residual, double* residualTrace, int traceCapacity)
+{
+    (void)matDescr;
+    if (!device_state()) return MGCG_ERROR;
+    if (!cublas || !cusparse || !mg || !zVector) { set_error("SolveMg: null handle"); return MGCG_ERROR; }
+    if (!check_vectors("SolveMg", elementsVector, rowOffsetsVector, columnIndecesVector, xVector, bVector, ApVector, pVector, rVector,
+                       elementsCountForDevice, countForDevice, count)) return MGCG_ERROR;
+    if (zVector->size < countForDevice || mg->lv[0].n != countForDevice || mg->lv[0].nGlobal != count || mg->lv[0].offset != offsetForDevice) {
+        set_error("SolveMg: z vector or hierarchy does not match the problem"); return MGCG_ERROR;
+    }
+    if (mg->nranks != MgcgCommSize(comm)) { set_error("SolveMg: the hierarchy was built for %d rank(s)", mg->nranks); return MGCG_ERROR; }
+    if (rule == MGCG_RULE_HANDMADECL || rule == MGCG_RULE_VIENNACL) { set_error("SolveMg supports the 2-norm absolute rules only"); return MGCG_ERROR; }
+    CgRun R;
+    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.mg = mg; R.comm = comm; R.nranks = MgcgCommSize(comm);
+    R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCountForDevice;
+    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data; R.z = zVector->data;
+    R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice;
+    R.tol = allowableResidual; R.minIt = minIteration; R.maxIt = maxIteration; R.rule = rule;
+    if (R.nranks > 1) {
+        R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ);
+        if (!R.halo) return MGCG_ERROR;
+    }
+    const int st = cg_solve(R, iteration, residual, residualTrace, traceCapacity);
+    if (R.halo) halo_plan_destroy(R.halo);
+    return st;
 }
 
 int SolveMg(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr, MgcgMg* mg,
@@ -529,19 +628,9 @@ int SolveMg(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr, Mgcg
             double allowableResidual, int minIteration, int maxIteration, int rule,
             int* iteration, double* residual, double* residualTrace, int traceCapacity)
 {
-    (void)matDescr;
-    if (!device_state()) return MGCG_ERROR;
-    if (!cublas || !cusparse || !mg || !zVector) { set_error("SolveMg: null handle"); return MGCG_ERROR; }
-    if (!check_vectors("SolveMg", elementsVector, rowOffsetsVector, columnIndecesVector, xVector, bVector, ApVector, pVector, rVector, elementsCount, count, count)) return MGCG_ERROR;
-    if (zVector->size < count || mg->lv[0].n != count) { set_error("SolveMg: z vector or hierarchy does not match the problem"); return MGCG_ERROR; }
-    if (rule == MGCG_RULE_HANDMADECL || rule == MGCG_RULE_VIENNACL) { set_error("SolveMg supports the 2-norm absolute rules only"); return MGCG_ERROR; }
-    CgRun R;
-    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.mg = mg;
-    R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCount;
-    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data; R.z = zVector->data;
-    R.count = count; R.nLocal = count; R.offset = 0;
-    R.tol = allowableResidual; R.minIt = minIteration; R.maxIt = maxIteration; R.rule = rule;
-    return cg_solve(R, iteration, residual, residualTrace, traceCapacity);
+    return SolveMgParallel(nullptr, cublas, cusparse, matDescr, mg, elementsVector, rowOffsetsVector, columnIndecesVector,
+                           xVector, bVector, ApVector, pVector, rVector, zVector, count, count, 0, elementsCount, 0, count - 1,
+                           allowableResidual, minIteration, maxIteration, rule, iteration, residual, residualTrace, traceCapacity);
 }
 
 } // extern "C"

@@ -245,6 +245,85 @@ class ConjugateGradientRankGpu(ConjugateGradientGpu):
         self.vectorX.CopyTo(self.x, self.part.count, self.part.offset)
 
 
+class ConjugateGradientMgRankGpu(ConjugateGradientRankGpu):
+    """One rank of the row-partitioned MGCG (BASELINE.json config 4): the rank's z-slab of the grid, per-level halo
+    planes over the communicator, V-cycle + PCG inside the library (MgSetupParallel / SolveMgParallel)."""
+
+    def __init__(self, count, maxNonZeroCount, _minIteration, _maxIteration, allowableResidual, grid,
+                 rank: int = 0, world: int = 1, comm=None, rule=_lib.RULE_CSHARP, device: int | None = None,
+                 levels: int = 3, omega: float | None = None, nu: int = 1, nuCoarse: int = 4, sigma: float = 0.5):
+        super().__init__(count, maxNonZeroCount, _minIteration, _maxIteration, allowableResidual, rank=rank, world=world,
+                         comm=comm, rule=rule, device=device)
+        self.grid = tuple(int(g) for g in grid)
+        nx, ny, nz = self.grid
+        if nx * ny * nz != count:
+            raise MgcgError("grid does not match count")
+        self.levels_requested = levels
+        self.omega = (6.0 / 7.0 if nz > 1 else 4.0 / 5.0) if omega is None else float(omega)
+        self.nu, self.nuCoarse, self.sigma = int(nu), int(nuCoarse), float(sigma)
+        self.vectorZ = VectorDouble(self.part.count)
+        self.mg = None
+
+    def Dispose(self):
+        if getattr(self, "mg", None):
+            lib().MgDestroy(self.mg)
+            self.mg = None
+        if getattr(self, "vectorZ", None) is not None:
+            self.vectorZ.Dispose()
+        super().Dispose()
+
+    def Setup(self):
+        """Build the hierarchy on this rank's slab (call after Initialize / InitializePoisson; collective)."""
+        self._ensure_comm()
+        nx, ny, nz = self.grid
+        p = self.part
+        sxy = nx * ny
+        if p.offset % sxy or p.count % sxy:
+            raise MgcgError("the row partition does not fall on z-plane boundaries")
+        self.mg = lib().MgSetupParallel(self.comm, self.cublas, self.cusparse,
+                                        self.vectorElements.Ptr, self.vectorRowOffsets.Ptr, self.vectorColumnIndeces.Ptr,
+                                        p.elementCount, nx, ny, nz, p.offset // sxy, (p.offset + p.count) // sxy,
+                                        self.levels_requested, self.omega, self.nu, self.nuCoarse, self.sigma)
+        check("MgSetupParallel")
+        if not self.mg:
+            raise MgcgError("MgSetupParallel returned NULL")
+        self.levels = lib().MgLevels(self.mg)
+
+    def Apply(self, r_local: np.ndarray) -> np.ndarray:
+        """z = M^-1 r on the local rows (test helper; collective)."""
+        n = self.part.count
+        vr, vz = VectorDouble(n), VectorDouble(n)
+        vr.CopyFrom(np.ascontiguousarray(r_local, dtype=np.float64), n)
+        lib().MgApply(self.mg, vr.ToRawPtr(), vz.ToRawPtr())
+        check("MgApply")
+        z = vz.to_numpy()
+        vr.Dispose()
+        vz.Dispose()
+        return z
+
+    def Solve(self, trace: bool = False):
+        self._ensure_comm()
+        p = self.part
+        iteration, residual = C.c_int(0), C.c_double(0.0)
+        cap = max(self.MaxIteration, self.MinIteration) + 8 if trace else 0
+        tr = np.zeros(max(cap, 1)) if trace else None
+        st = lib().SolveMgParallel(self.comm, self.cublas, self.cusparse, self.matDescr, self.mg,
+                                   self.vectorElements.Ptr, self.vectorRowOffsets.Ptr, self.vectorColumnIndeces.Ptr,
+                                   self.vectorX.Ptr, self.vectorB.Ptr, self.vectorAp.Ptr, self.vectorP.Ptr, self.vectorR.Ptr, self.vectorZ.Ptr,
+                                   self.Count, p.count, p.offset, p.elementCount, p.minJ, p.maxJ,
+                                   self.AllowableResidual, self.MinIteration, self.MaxIteration, self.rule,
+                                   C.byref(iteration), C.byref(residual), _ptr(tr) if trace else None, cap)
+        self.Iteration, self.Residual, self.status = iteration.value, residual.value, st
+        if trace:
+            self.trace = tr[: self.Iteration + 1].copy()
+        if st == _lib.MAXIT_EXCEEDED:
+            lib().MgcgClearLastError()
+            raise ApplicationException(f"MGCG did not converge within MaxIteration={self.MaxIteration}")
+        if st != _lib.OK:
+            check("SolveMgParallel")
+            raise MgcgError(f"SolveMgParallel failed with status {st}")
+
+
 # --------------------------------------------------------------------------- host-driven phases over torch.distributed
 class HipPhases:
     """The reference's per-device phase calls (Mgcg.cu:57-198) for ONE rank, through the C ABI."""

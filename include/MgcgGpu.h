@@ -246,6 +246,14 @@ MgcgMg* MgSetup(MgcgBlas* cublas, MgcgSparse* cusparse,
                 Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
                 int elementsCount, int nx, int ny, int nz,
                 int levels, double omega, int nu, int nuCoarse, double sigma);
+/* The same on this rank's z-slab [zBegin, zEnd) of the grid (equal slabs in rank order; the vectors hold the local
+ * rows with global column ids, as Initialize lays them out).  Every level keeps the slab aligned; per-level halo
+ * planes travel over `comm` before each smoothing / residual pass.  comm == NULL: one rank. */
+typedef struct MgcgComm MgcgComm;
+MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
+                        Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+                        int elementsCount, int nx, int ny, int nz, int zBegin, int zEnd,
+                        int levels, double omega, int nu, int nuCoarse, double sigma);
 void    MgDestroy(MgcgMg* mg);
 int     MgLevels(const MgcgMg* mg);
 /* rows / nnz / grid of level l; copy level l's CSR and D^-1 to host arrays (for tests). */
@@ -266,7 +274,6 @@ int     SolveMg(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr, 
                 double* residualTrace, int traceCapacity);
 
 /* ---- one process per GPU: RCCL over xGMI ---- */
-typedef struct MgcgComm MgcgComm;
 /* 128-byte RCCL unique id created on one rank and handed to every rank by the launcher
  * (torch.distributed store / MPI / a file). Returns 0 on success. */
 int       MgcgCommGetUniqueId(void* id128);
@@ -297,6 +304,14 @@ int SolveParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMa
                   double allowableResidual, int minIteration, int maxIteration, int rule,
                   int* iteration, double* residual,
                   double* residualTrace, int traceCapacity);
+
+/* Multi-rank preconditioned CG: SolveParallel with the V-cycle of an MgSetupParallel hierarchy (zVector: local work vector). */
+int SolveMgParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr, MgcgMg* mg,
+                    Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+                    Vector* xVector, Vector* bVector, Vector* ApVector, Vector* pVector, Vector* rVector, Vector* zVector,
+                    int count, int countForDevice, int offsetForDevice, int elementsCountForDevice, int minJ, int maxJ,
+                    double allowableResidual, int minIteration, int maxIteration, int rule,
+                    int* iteration, double* residual, double* residualTrace, int traceCapacity);
 
 /* Fixed number of CG iterations with no stop test and no host synchronisation inside (bench.py's
  * "steps"): runs `steps` more iterations of the recurrence held in x,r,p (call with restart != 0 first
