@@ -125,7 +125,14 @@ def main():
     if world > 1 and n % world:
         raise SystemExit("grid extent must be divisible by the number of GPUs (z-slab partition)")
 
-    cg = ConjugateGradientRankGpu(N, 7, 0, 10**9, 1e-8, rank=rank, world=world, device=local_rank)
+    if a.solver == "mgcg":
+        from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu
+
+        # fixed-length runs: rule NATIVE with an infinite tolerance stops exactly at index minIteration
+        cg = ConjugateGradientMgRankGpu(N, 7, 0, 10**9, 1e300, (n, n, n), rank=rank, world=world, device=local_rank,
+                                        rule=_lib.RULE_NATIVE, levels=3, nu=1, nuCoarse=4)
+    else:
+        cg = ConjugateGradientRankGpu(N, 7, 0, 10**9, 1e-8, rank=rank, world=world, device=local_rank)
     if a.spmv_kernel is not None:
         L.MgcgSetSpmvKernel(cg.cusparse, a.spmv_kernel)
     if a.spmv_rows is not None or a.spmv_flags is not None or a.spmv_grid is not None:
@@ -136,12 +143,18 @@ def main():
     nnz_local = cg.part.elementCount
     rows_local = cg.part.count
 
-    mg_info = None
-    if a.solver == "mgcg":
-        raise SystemExit("--solver mgcg is reported by tools/bench_mgcg.py in this round; bench.py's metric is the CG iteration")
+    def run_steps(k, restart):
+        if a.solver == "mgcg":          # init (r = b - A x, z = M^-1 r) is inside: about one extra V-cycle per call
+            L.MgcgFill(cg.vectorX.Ptr, 0.0)
+            cg.MinIteration = k - 1
+            cg.Solve()
+            return cg.Residual
+        return cg.Steps(k, restart=restart)
 
-    # warm-up (also builds the RCCL communicator and the halo plan)
-    cg.Steps(max(a.warmup, 1), restart=True)
+    if a.solver == "mgcg":
+        cg.Setup()
+    # warm-up (also builds the RCCL communicator and the halo plans)
+    run_steps(max(a.warmup, 1), True)
 
     def barrier():
         if dist is not None:
@@ -151,7 +164,7 @@ def main():
     barrier()
     L.MgcgDeviceSynchronize()
     t0 = time.perf_counter()
-    res = cg.Steps(a.steps, restart=False)      # synchronises the stream before returning
+    res = run_steps(a.steps, False)             # synchronises the stream before returning
     L.MgcgDeviceSynchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -183,7 +196,8 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "CG iterations/sec (7-pt Poisson 512^3); SpMV achieved HBM GB/s in roofline",
+            "metric": ("CG iterations/sec (7-pt Poisson 512^3); SpMV achieved HBM GB/s in roofline" if a.solver == "cg"
+                       else "MGCG iterations/sec (3-level V(1,1) Jacobi, 7-pt Poisson 512^3)"),
             "value": a.steps / dt,
             "unit": "iterations/s",
             "n_gpus": world,
@@ -195,7 +209,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"unpreconditioned CG iteration, 7-point Poisson {n}^3 CSR (fp64 values, int32 indices), "
+            "config": {"workload": ("unpreconditioned CG iteration" if a.solver == "cg" else "MGCG iteration (V-cycle + CG)") + f", 7-point Poisson {n}^3 CSR (fp64 values, int32 indices), "
                                    f"b=1, x0=0, {world} z-slab partition(s)",
                        "rows": N, "nnz": nnz_total, "parallelism": f"row-range dp{world}"},
             "iteration_algorithmic_gbps": iter_bytes / (dt / a.steps) / 1e9,
