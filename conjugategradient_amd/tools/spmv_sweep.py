@@ -42,7 +42,8 @@ def main():
                 ("wave R64 g2048", 1, 64, 0, 2048, 0, 0), ("wave R64 g3072", 1, 64, 0, 3072, 0, 0), ("wave R64 g5120", 1, 64, 0, 5120, 0, 0),
                 ("wave R64 g4096 nt", 1, 64, 1, 4096, 0, 0), ("wave R32 g6144", 1, 32, 0, 6144, 0, 0),
                 ("wave R64 band", 1, 64, 4, 0, 0, 0), ("wave R32 band", 1, 32, 4, 0, 0, 0), ("wave R32 band 8Lx8", 1, 32, 4, 0, 8 * n, 8),
-                ("wg256 band 64Lx1", 1, 128, 4, 0, 64 * n, 1), ("vector 4 lanes", 4, 128, 0, 0, 0, 0)]
+                ("wg256 band 64Lx1", 1, 128, 4, 0, 64 * n, 1), ("vector 4 lanes", 4, 128, 0, 0, 0, 0),
+                ("DOT wave R64 g4096", 1, 64, 0, 4096, 0, 0), ("DOT wave R64 band", 1, 64, 4, 0, 0, 0), ("DOT wg256 R128", 1, 128, 0, 0, 0, 0)]
     if a.variants:
         keep = set(a.variants.split(","))
         variants = [v for v in variants if v[0] in keep]
@@ -57,7 +58,10 @@ def main():
         L.MgcgSetSpmvTile(sparse, v[5], v[6])
         L.MgcgEventRecord(ev0)
         for _ in range(a.reps):
-            L.CsrMV(sparse, descr, y.ToRawPtr(), e.ToRawPtr(), r.ToRawPtr(), c.ToRawPtr(), x.ToRawPtr(), nnz, N, N, 1.0, 0.0)
+            if v[0].startswith("DOT"):      # the fused variant of the CG loop: y = A x and sum x_i y_i (blocking scalar read included)
+                L.CsrMVDot(blas, sparse, y.ToRawPtr(), e.ToRawPtr(), r.ToRawPtr(), c.ToRawPtr(), x.ToRawPtr(), x.ToRawPtr(), nnz, N, N)
+            else:
+                L.CsrMV(sparse, descr, y.ToRawPtr(), e.ToRawPtr(), r.ToRawPtr(), c.ToRawPtr(), x.ToRawPtr(), nnz, N, N, 1.0, 0.0)
         L.MgcgEventRecord(ev1)
         return L.MgcgEventElapsedMs(ev0, ev1) / a.reps
 
