@@ -517,8 +517,7 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
         }
         if (ok) launch_extract_dinv(s, L.elements, L.rowOffsets, L.columnIndeces, L.n, L.offset, L.dinv);
         L.cfg = mg->cfg;
-        L.cfg.periodRows = (L.nz > 1) ? L.nx * L.ny : 0;       // far band of a 3-D stencil = one grid plane
-        if (L.cfg.periodRows > 0) L.cfg.flags |= 4; else L.cfg.flags &= ~4;
+        L.cfg.periodRows = (L.nz > 1) ? L.nx * L.ny : 0;       // far band of a 3-D stencil = one grid plane (used only if the caller switched the banded schedule on)
         if (ok && nranks > 1) {
             int init[2] = { 0x7fffffff, (int)0x80000000 }, out[2] = { 0, -1 };
             ok = ok && MGCG_HIP(hipMemcpyAsync(dmm, init, sizeof(init), hipMemcpyHostToDevice, s));

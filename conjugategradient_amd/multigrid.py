@@ -56,7 +56,6 @@ class ConjugateGradientMgGpu(ConjugateGradientSingleGpu):
             check("MgcgGeneratePoisson")
         L.MgcgFill(self.vectorB.Ptr, b_value)
         L.MgcgFill(self.vectorX.Ptr, x_value)
-        L.MgcgSetSpmvPeriod(self.cusparse, nx * ny if nz > 1 else 0)
         self.A = None
         self._nnz = int(nnz)
         self.Setup()

@@ -206,7 +206,6 @@ class ConjugateGradientRankGpu(ConjugateGradientGpu):
         if L.MgcgMinMaxColumn(self.vectorColumnIndeces.Ptr, nnz, C.byref(mn), C.byref(mx)) != 0:
             check("MgcgMinMaxColumn")
         p.elementCount, p.elementOffset, p.minJ, p.maxJ = int(nnz), 0, mn.value, mx.value
-        L.MgcgSetSpmvPeriod(self.cusparse, sxy if nz > 1 else 0)      # far band of the stencil = one grid plane
 
     def Solve(self, trace: bool = False):
         self._ensure_comm()
