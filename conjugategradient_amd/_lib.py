@@ -80,6 +80,9 @@ SIGNATURES = {
     "MgcgSetSpmvTuning": (None, [_vp, _i, _i, _i]),
     "MgcgSetSpmvPeriod": (None, [_vp, _i]),
     "MgcgSetSpmvTile": (None, [_vp, _i, _i]),
+    "MgcgSetMatrixCompression": (None, [_vp, _i]),
+    "MgcgAnalysisClear": (None, [_vp]),
+    "MgcgAnalysisInfo": (_i, [_vp, _i, _pi, _pi, C.POINTER(_ll), C.POINTER(_ll)]),
     "MgcgProfileSpmv": (None, [_vp, _i]),
     "MgcgProfileSpmvMs": (_d, [_vp, _pi]),
     "MgcgPoissonNnz": (_ll, [_i, _i, _i, _i, _i]),

@@ -87,6 +87,26 @@ struct Workspace {
 
 struct MgcgBlas   { mgcg::Workspace ws; };
 namespace mgcg {
+// Dictionary-compressed CSR (kernels_dcsr.hip): what the kernel sees ...
+struct DcsrView {
+    const unsigned char* colCode;    // code of (col - row) per nonzero
+    const unsigned char* valCode;    // code of the value per nonzero, or nullptr (values stay fp64 in `elements`)
+    const int* deltaDict;
+    const double* valueDict;
+    int nDelta, nValue;
+    long long rowBase;               // global index of local row 0
+};
+// ... and what the handle caches per analysed matrix (keyed by the CSR pointers and sizes).
+struct DcsrMatrix {
+    const double* elements = nullptr; const int* rowOffsets = nullptr; const int* columnIndeces = nullptr;
+    long long rows = 0, nnz = 0, rowBase = 0;
+    unsigned char* colCode = nullptr; unsigned char* valCode = nullptr;
+    int* deltaDict = nullptr; double* valueDict = nullptr;
+    int nDelta = 0, nValue = 0;
+    bool usable = false;
+    void release();
+    DcsrView view() const { DcsrView v; v.colCode = colCode; v.valCode = valCode; v.deltaDict = deltaDict; v.valueDict = valueDict; v.nDelta = nDelta; v.nValue = nValue; v.rowBase = rowBase; return v; }
+};
 // Optional per-launch timing of the SpMV inside the CG loop (bench.py's roofline figure).
 struct SpmvProfile {
     bool enabled = false;
@@ -103,6 +123,8 @@ struct MgcgSparse {
     int gridBlocks = 0;
     int periodRows = 0;      // rows between strongly coupled windows (a grid plane); 0 = unknown
     int tileRows = 0, tilePlanes = 0;   // banded schedule tile (0 = default)
+    bool compression = false;           // opt-in: analyse matrices into the dictionary-compressed form
+    std::vector<mgcg::DcsrMatrix*> analysed;
 };
 struct MgcgMatDescr { int type = 0; int base = 0; };
 struct Vector    { double* data = nullptr; long long size = 0; int device = -1; };
@@ -143,6 +165,15 @@ struct SpmvConfig { int kernel = 0; int rowsPerBlock = 64; int flags = 0; int gr
 
 // Launches the SpMV; returns the number of partials written (grid size) for dot epilogues.
 int launch_spmv(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg);
+// The same on the dictionary-compressed form of the matrix (a.elements / a.columnIndeces still serve array tails and long rows).
+int launch_spmv_dcsr(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView& m, int gridReq);
+bool dcsr_build(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces,
+                long long rows, long long nnz, long long rowBase, DcsrMatrix* out);
+// Cached analysis of a matrix on a handle (nullptr: compression off, not applicable, or the build failed).
+const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* rowOffsets, const int* columnIndeces,
+                              long long rows, long long nnz, long long rowBase);
+// CSR or compressed, whichever the handle has for this matrix.
+int launch_spmv_auto(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg, const DcsrMatrix* dc);
 
 // ---------------------------------------------------------------- BLAS-1 and fused CG updates
 void launch_axpy(hipStream_t s, double* y, const double* x, long long n, double alpha);

@@ -101,6 +101,27 @@ bool Workspace::ensure_trace(int cap)
     return true;
 }
 
+const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* rowOffsets, const int* columnIndeces,
+                              long long rows, long long nnz, long long rowBase)
+{
+    if (!h || !h->compression) return nullptr;
+    for (const DcsrMatrix* m : h->analysed)
+        if (m->elements == elements && m->rowOffsets == rowOffsets && m->columnIndeces == columnIndeces && m->rows == rows && m->nnz == nnz && m->rowBase == rowBase)
+            return m->usable ? m : nullptr;
+    // the wide paths need 16-byte aligned values; short average rows only (one pass per 64-row block)
+    if ((((uintptr_t)elements) & 15) != 0 || rows <= 0 || (double)nnz / (double)rows > 7.75) return nullptr;
+    DcsrMatrix* m = new DcsrMatrix();
+    if (!dcsr_build(h->ws.stream, elements, rowOffsets, columnIndeces, rows, nnz, rowBase, m)) { m->release(); m->elements = elements; m->rowOffsets = rowOffsets; m->columnIndeces = columnIndeces; m->rows = rows; m->nnz = nnz; m->rowBase = rowBase; }
+    h->analysed.push_back(m);
+    return m->usable ? m : nullptr;
+}
+
+int launch_spmv_auto(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg, const DcsrMatrix* dc)
+{
+    if (dc != nullptr && dc->usable && a.elementsCount >= 8) return launch_spmv_dcsr(s, epilogue, a, dc->view(), cfg.gridBlocks);
+    return launch_spmv(s, epilogue, a, cfg);
+}
+
 } // namespace mgcg
 
 using namespace mgcg;
@@ -181,10 +202,37 @@ MgcgSparse* CreateSparse(void)
     const char* g = getenv("MGCG_SPMV_GRID");         if (g) h->gridBlocks = atoi(g);
     const char* tr = getenv("MGCG_SPMV_TILE_ROWS");   if (tr) h->tileRows = atoi(tr);
     const char* tp = getenv("MGCG_SPMV_TILE_PLANES"); if (tp) h->tilePlanes = atoi(tp);
+    const char* cm = getenv("MGCG_COMPRESSION");      if (cm) h->compression = atoi(cm) != 0;
     const char* p = getenv("MGCG_SPMV_PERIOD");       if (p) { h->periodRows = atoi(p); if (h->periodRows > 0) h->flags |= 4; }
     return h;
 }
-void DestroySparse(MgcgSparse* h) { if (!h) return; h->ws.destroy(); delete h; }
+void DestroySparse(MgcgSparse* h)
+{
+    if (!h) return;
+    for (auto* m : h->analysed) { m->release(); delete m; }
+    h->ws.destroy();
+    delete h;
+}
+
+void MgcgSetMatrixCompression(MgcgSparse* h, int enable) { if (h) h->compression = enable != 0; }
+void MgcgAnalysisClear(MgcgSparse* h)
+{
+    if (!h) return;
+    DeviceState* d = device_state();
+    if (d) (void)hipStreamSynchronize(d->stream);
+    for (auto* m : h->analysed) { m->release(); delete m; }
+    h->analysed.clear();
+}
+int MgcgAnalysisInfo(MgcgSparse* h, int index, int* distinctOffsets, int* distinctValues, long long* rows, long long* nnz)
+{
+    if (!h || index < 0 || index >= (int)h->analysed.size()) return -1;
+    const mgcg::DcsrMatrix* m = h->analysed[(size_t)index];
+    if (distinctOffsets) *distinctOffsets = m->nDelta;
+    if (distinctValues) *distinctValues = m->nValue;
+    if (rows) *rows = m->rows;
+    if (nnz) *nnz = m->nnz;
+    return m->usable ? (m->valCode ? 2 : 1) : 0;      // bytes-per-nonzero class: 2 = offsets+values coded, 1 = offsets coded, 0 = plain CSR
+}
 
 MgcgMatDescr* CreateMatDescr(void) { return new MgcgMatDescr(); }
 void DestroyMatDescr(MgcgMatDescr* d) { delete d; }

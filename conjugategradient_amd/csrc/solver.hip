@@ -27,6 +27,7 @@ struct MgLevel {
     double *xa = nullptr, *xb = nullptr;   // iterate ping-pong, full length (Jacobi is not in place)
     double *b = nullptr, *r = nullptr;     // right-hand side (restricted residual), residual; local
     SpmvConfig cfg;                        // per level: kernel picked from its nnz/row, banded period = nx*ny
+    const DcsrMatrix* dcsr = nullptr;      // compressed form (owned by the MgcgSparse handle's cache)
     HaloPlan* halo = nullptr;              // multi-rank: planes of the iterate owned by the neighbours
     int minJ = 0, maxJ = -1;
 };
@@ -65,7 +66,7 @@ static bool mg_jacobi(MgcgMg* mg, MgLevel& L, const double* b, double* xin, doub
     a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = xin; a.y = xout + L.offset;
     a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal;
     a.w = xin + L.offset; a.b = b; a.dinv = L.dinv; a.omega = mg->omega; a.doneFlag = done;
-    launch_spmv(mg->stream, EPI_JACOBI, a, L.cfg);
+    launch_spmv_auto(mg->stream, EPI_JACOBI, a, L.cfg, L.dcsr);
     return true;
 }
 
@@ -99,7 +100,7 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
     SpmvArgs a{};
     a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = cur; a.y = L.r;
     a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal; a.b = b; a.doneFlag = done;
-    launch_spmv(mg->stream, EPI_RESIDUAL, a, L.cfg);                                          // r = b - A x
+    launch_spmv_auto(mg->stream, EPI_RESIDUAL, a, L.cfg, L.dcsr);                             // r = b - A x
     launch_restrict(mg->stream, L.nx, L.ny, L.z1 - L.z0, L.r, C.b, done);                     // b_c = P^T r (slab-local)
     double* e = nullptr;
     if (!mg_vcycle(mg, l + 1, C.b, C.xa, C.xb, done, &e)) return false;
@@ -142,6 +143,8 @@ struct CgRun {
     double tol = 0; int minIt = 0, maxIt = 0, rule = 0;
     bool wantInf = false;
     SpmvProfile* prof = nullptr;
+    const DcsrMatrix* dcsr = nullptr;      // compressed form of the matrix if the handle has one
+    MgcgSparse* cusparse = nullptr;
 };
 
 static void prof_mark(CgRun& R, bool begin)
@@ -172,6 +175,7 @@ __global__ void clear_done_kernel(CgScalars* sc) { sc->done = 0; sc->status = 0;
 static bool cg_enqueue_init(CgRun& R)
 {
     hipStream_t s = R.ws->stream;
+    if (R.cusparse) R.dcsr = dcsr_lookup(R.cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset);
     CgScalars* sc = R.ws->scalars;
     double* pLoc = R.p + R.offset;
     if (R.rule == MGCG_RULE_SIMPLE) launch_fill(s, R.x, 0.0, R.nLocal);             // SimpleConjugateGradient.cu:53
@@ -180,7 +184,7 @@ static bool cg_enqueue_init(CgRun& R)
     SpmvArgs a{};
     a.elements = R.elements; a.rowOffsets = R.rowOffsets; a.columnIndeces = R.columnIndeces; a.x = R.p; a.y = R.r;
     a.elementsCount = R.elementsCount; a.rowCount = (int)R.nLocal; a.columnCount = (int)R.count; a.b = R.b;
-    launch_spmv(s, EPI_RESIDUAL, a, R.cfg);                                          // r = b - A x   (Mgcg.cu:225-226)
+    launch_spmv_auto(s, EPI_RESIDUAL, a, R.cfg, R.dcsr);                             // r = b - A x   (Mgcg.cu:225-226)
     int n;
     if (R.mg) {
         if (!mg_apply(R.mg, R.r, R.z, nullptr)) return false;                        // z = M^-1 r
@@ -211,7 +215,7 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
     a.elementsCount = R.elementsCount; a.rowCount = (int)R.nLocal; a.columnCount = (int)R.count;
     a.w = pLoc; a.partials = R.ws->partials; a.doneFlag = done;
     prof_mark(R, true);
-    int n = launch_spmv(s, EPI_DOT, a, R.cfg);                                       // Ap = A p ; p.Ap   (Mgcg.cu:244-245)
+    int n = launch_spmv_auto(s, EPI_DOT, a, R.cfg, R.dcsr);                          // Ap = A p ; p.Ap   (Mgcg.cu:244-245)
     prof_mark(R, false);
     launch_reduce_to(s, R.ws->partials, n, &sc->pAp, done);
     if (R.nranks > 1 && !comm_allreduce_sum(R.comm, &sc->pAp, 1, s)) return false;   // (:499)
@@ -331,7 +335,7 @@ int SolveEx(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr,
     if (!cublas || !cusparse) { set_error("SolveEx: null handle"); return MGCG_ERROR; }
     if (!check_vectors("SolveEx", elementsVector, rowOffsetsVector, columnIndecesVector, xVector, bVector, ApVector, pVector, rVector, elementsCount, count, count)) return MGCG_ERROR;
     CgRun R;
-    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof;
+    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse;
     R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCount;
     R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data;
     R.count = count; R.nLocal = count; R.offset = 0;
@@ -370,7 +374,7 @@ int SolveParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMa
                        elementsCountForDevice, countForDevice, count)) return MGCG_ERROR;
     if (offsetForDevice < 0 || (long long)offsetForDevice + countForDevice > count) { set_error("SolveParallel: bad partition"); return MGCG_ERROR; }
     CgRun R;
-    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.comm = comm; R.nranks = MgcgCommSize(comm);
+    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse; R.comm = comm; R.nranks = MgcgCommSize(comm);
     R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCountForDevice;
     R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data;
     R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice;
@@ -395,7 +399,7 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     if (!check_vectors("CgSteps", elementsVector, rowOffsetsVector, columnIndecesVector, xVector, bVector, ApVector, pVector, rVector,
                        elementsCountForDevice, countForDevice, count)) return NAN;
     CgRun R;
-    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.comm = comm; R.nranks = MgcgCommSize(comm);
+    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse; R.comm = comm; R.nranks = MgcgCommSize(comm);
     R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCountForDevice;
     R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data;
     R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice; R.rule = MGCG_RULE_NATIVE;
@@ -403,6 +407,7 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     R.ws->trace = nullptr; R.ws->traceCap = 0;
     bool ok = true;
     if (R.nranks > 1) { R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ); ok = R.halo != nullptr; }
+    R.dcsr = dcsr_lookup(cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset);
     if (ok && restart) ok = cg_enqueue_init(R);
     else if (ok) hipLaunchKernelGGL(clear_done_kernel, dim3(1), dim3(1), 0, R.ws->stream, R.ws->scalars);
     for (int k = 0; ok && k < steps; ++k) ok = cg_enqueue_iteration(R, false);
@@ -516,6 +521,7 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
             ok = ok && MGCG_HIP(hipMemsetAsync(L.xa, 0, sizeof(double) * (size_t)L.nGlobal, s)) && MGCG_HIP(hipMemsetAsync(L.xb, 0, sizeof(double) * (size_t)L.nGlobal, s));
         }
         if (ok) launch_extract_dinv(s, L.elements, L.rowOffsets, L.columnIndeces, L.n, L.offset, L.dinv);
+        if (ok) L.dcsr = dcsr_lookup(cusparse, L.elements, L.rowOffsets, L.columnIndeces, L.n, L.nnz, L.offset);
         L.cfg = mg->cfg;
         L.cfg.periodRows = (L.nz > 1) ? L.nx * L.ny : 0;       // far band of a 3-D stencil = one grid plane (used only if the caller switched the banded schedule on)
         if (ok && nranks > 1) {
@@ -608,7 +614,7 @@ int SolveMgParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, Mgcg
     if (mg->nranks != MgcgCommSize(comm)) { set_error("SolveMg: the hierarchy was built for %d rank(s)", mg->nranks); return MGCG_ERROR; }
     if (rule == MGCG_RULE_HANDMADECL || rule == MGCG_RULE_VIENNACL) { set_error("SolveMg supports the 2-norm absolute rules only"); return MGCG_ERROR; }
     CgRun R;
-    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.mg = mg; R.comm = comm; R.nranks = MgcgCommSize(comm);
+    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse; R.mg = mg; R.comm = comm; R.nranks = MgcgCommSize(comm);
     R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCountForDevice;
     R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data; R.z = zVector->data;
     R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice;

@@ -43,6 +43,7 @@ def main():
                 ("wave R64 g4096 nt", 1, 64, 1, 4096, 0, 0), ("wave R32 g6144", 1, 32, 0, 6144, 0, 0),
                 ("wave R64 band", 1, 64, 4, 0, 0, 0), ("wave R32 band", 1, 32, 4, 0, 0, 0), ("wave R32 band 8Lx8", 1, 32, 4, 0, 8 * n, 8),
                 ("wg256 band 64Lx1", 1, 128, 4, 0, 64 * n, 1), ("vector 4 lanes", 4, 128, 0, 0, 0, 0),
+                ("dcsr", 1, 64, 0, 0, 0, 0), ("dcsr g2048", 1, 64, 0, 2048, 0, 0), ("dcsr g8192", 1, 64, 0, 8192, 0, 0), ("DOT dcsr", 1, 64, 0, 0, 0, 0),
                 ("DOT wave R64 g4096", 1, 64, 0, 4096, 0, 0), ("DOT wave R64 band", 1, 64, 4, 0, 0, 0), ("DOT wg256 R128", 1, 128, 0, 0, 0, 0)]
     if a.variants:
         keep = set(a.variants.split(","))
@@ -52,6 +53,7 @@ def main():
 
     def run(v):
         os.environ["MGCG_SPMV_ABLATE"] = str(v[7]) if len(v) > 7 else "0"
+        L.MgcgSetMatrixCompression(sparse, 1 if "dcsr" in v[0] else 0)
         L.MgcgSetSpmvKernel(sparse, v[1])
         L.MgcgSetSpmvTuning(sparse, v[2], v[3], v[4])
         L.MgcgSetSpmvPeriod(sparse, n * n if (v[3] & 4) else 0)
@@ -66,7 +68,7 @@ def main():
         return L.MgcgEventElapsedMs(ev0, ev1) / a.reps
 
     if a.ablate:
-        base = [v for v in variants if v[0] in ("wg256 R128", "wave R64 g4096", "wave R64 band", "wg256 band 64Lx1", "wave R64 g4096 nt")]
+        base = [v for v in variants if v[0] in ("wg256 R128", "wave R64 g4096", "wave R64 band", "wg256 band 64Lx1", "wave R64 g4096 nt", "dcsr")]
         for ab, tag in ((1, "no y store"), (2, "gathers from L1"), (3, "no store + L1 gathers"), (8, "y store confined to 512 KB")):
             for v in base:
                 variants.append((v[0] + " | " + tag,) + tuple(v[1:]) + (ab,))

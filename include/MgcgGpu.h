@@ -197,6 +197,17 @@ void   MgcgSetSpmvPeriod(MgcgSparse* cusparse, int periodRows);
  * per XCD at a time (0, 0 = the library's default).  Pure scheduling: results do not change. */
 void   MgcgSetSpmvTile(MgcgSparse* cusparse, int tileRows, int tilePlanes);
 
+/* Opt-in analysis (the role cuSPARSE's csrmv analysis plays in the reference's stack): with compression enabled the
+ * Solve-family, MgSetup and CsrMV/CsrMVDot on this handle re-encode a matrix ONCE into a lossless dictionary form
+ * when it has <= 256 distinct column offsets col-row (and, if also <= 256 distinct values, 2 bytes per nonzero
+ * instead of 12) and use it for every later SpMV on the same arrays.  Results are bit-identical to the CSR kernels.
+ * The cache is keyed by the array pointers and sizes: a caller that rewrites a matrix in place must call
+ * MgcgAnalysisClear.  MgcgAnalysisInfo(index) reports a cached analysis: returns 2 / 1 / 0 (offsets+values coded /
+ * offsets coded / not compressible), -1 past the end. */
+void   MgcgSetMatrixCompression(MgcgSparse* cusparse, int enable);
+void   MgcgAnalysisClear(MgcgSparse* cusparse);
+int    MgcgAnalysisInfo(MgcgSparse* cusparse, int index, int* distinctOffsets, int* distinctValues, long long* rows, long long* nnz);
+
 /* Per-launch HIP-event timing of the SpMV kernel inside the Solve.. / CgSteps calls on this handle's stream:
  * enable, run, then read the summed milliseconds and the number of launches timed. */
 void   MgcgProfileSpmv(MgcgSparse* cusparse, int enable);

@@ -1,0 +1,130 @@
+"""Opt-in dictionary-compressed CSR (MgcgSetMatrixCompression): a lossless re-encoding, so every result must be
+bit-identical to the CSR kernels / the oracle -- SpMV, every fused epilogue through the V-cycle, whole solves,
+one rank and several."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conjugategradient_amd import _lib, problems
+from conjugategradient_amd.multigrid import ConjugateGradientMgGpu
+from conjugategradient_amd.solver import ConjugateGradientSingleGpu
+from tests.gpu_util import DeviceCsr, Handles
+
+pytestmark = pytest.mark.gpu
+
+
+def _info(sparse, idx=0):
+    L = _lib.lib()
+    d, v, r, n = C.c_int(), C.c_int(), C.c_longlong(), C.c_longlong()
+    cls = L.MgcgAnalysisInfo(sparse, idx, C.byref(d), C.byref(v), C.byref(r), C.byref(n))
+    return cls, d.value, v.value, r.value, n.value
+
+
+def _scaled_poisson(dims, seed=4):
+    import scipy.sparse as sp
+    s = problems.poisson(*dims)
+    rng = np.random.default_rng(seed)
+    d = sp.diags(1.0 + rng.random(s.Count))
+    A = (d @ s.to_scipy() @ d).tocsr()
+    A.sort_indices()
+    return problems.LinearSystem(A.data.copy(), A.indices.astype(np.int32), A.indptr.astype(np.int32), np.zeros(s.Count), np.ones(s.Count), "scaled", grid=s.grid)
+
+
+@pytest.mark.parametrize("name,builder,expect_class,expect_offsets,expect_values", [
+    ("poisson7", lambda: problems.poisson(20, 17, 13), 2, 7, 2),
+    ("poisson5", lambda: problems.poisson(37, 29, 1), 2, 5, 2),
+    ("tridiagonal", lambda: problems.tridiagonal(1003), 2, 3, 2),               # unsorted columns: diag, left, right
+    ("scaled poisson", lambda: _scaled_poisson((12, 11, 10)), 1, 7, None),      # every value distinct: offsets coded only
+    ("narrow band", lambda: problems.mgcg_main(3000, 8), 1, 7, None),           # diagonal first, |sin(i+j)| values
+    ("random", lambda: problems.random_spd(4000, mean_upper=2.5, seed=9), 0, None, None),   # > 256 distinct offsets: stays CSR
+    ("tiny", lambda: problems.poisson(2, 1, 1), 0, None, None),                 # fewer than 8 nonzeros: not encoded
+])
+def test_compressed_spmv_is_bit_exact(oracle, name, builder, expect_class, expect_offsets, expect_values):
+    L = _lib.lib()
+    s = builder()
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(s.Count)
+    ref = oracle.spmv(s.Elements, s.ColumnIndeces, s.RowOffsets, x)
+    h = Handles()
+    A = DeviceCsr(s)
+    plain = A.spmv(h, x, kernel=1)
+    L.MgcgSetMatrixCompression(h.sparse, 1)
+    got = A.spmv(h, x)
+    assert np.array_equal(plain, ref) and np.array_equal(got, ref)
+    cls, nd, nv, rows, nnz = _info(h.sparse)
+    assert cls == expect_class, (cls, nd, nv)
+    if expect_offsets is not None:
+        assert nd == expect_offsets
+    if expect_values is not None:
+        assert nv == expect_values
+    # alpha/beta epilogue and a second call (cache hit) give the same bits
+    y0 = rng.standard_normal(s.Count)
+    assert np.array_equal(A.spmv(h, x, alpha=-1.5, beta=0.25, y0=y0), -1.5 * ref + 0.25 * y0)
+    assert _info(h.sparse, 1)[0] == -1          # still one cached analysis
+    L.MgcgAnalysisClear(h.sparse)
+    assert _info(h.sparse, 0)[0] == -1
+    h.close()
+
+
+def test_compressed_solves_match_plain_bits(oracle):
+    """CG and MGCG with compression on: x, iteration count and the whole residual trace equal the uncompressed run
+    bit for bit (same kernels' arithmetic, same reduction grids)."""
+    for s, mg in [(problems.poisson(24, 20, 16), False), (problems.poisson(16, 16, 16), True), (_scaled_poisson((16, 12, 8)), True)]:
+        runs = []
+        for comp in (0, 1):
+            if mg:
+                cg = ConjugateGradientMgGpu(s.Count, 7, 0, 1000, 1e-9, s.grid, rule=_lib.RULE_CSHARP).load(s)
+            else:
+                cg = ConjugateGradientSingleGpu(s.Count, 7, 0, 1000, 1e-9, rule=_lib.RULE_CSHARP).load(s)
+            _lib.lib().MgcgSetMatrixCompression(cg.cusparse, comp)
+            cg.Initialize()
+            cg.Solve(trace=True)
+            cg.Read()
+            if comp:
+                assert _info(cg.cusparse, 0)[0] >= 1
+                if mg:
+                    assert _info(cg.cusparse, 2)[0] >= 1      # every level analysed
+            runs.append((cg.x.copy(), cg.Iteration, cg.trace.copy()))
+            cg.Dispose()
+        assert runs[0][1] == runs[1][1]
+        assert np.array_equal(runs[0][2], runs[1][2])
+        assert np.array_equal(runs[0][0], runs[1][0])
+    # and against the oracle's V-cycle: still bit-identical
+    s = problems.poisson(16, 16, 16)
+    cg = ConjugateGradientMgGpu(s.Count, 7, 0, 500, 1e-8, s.grid).load(s)
+    _lib.lib().MgcgSetMatrixCompression(cg.cusparse, 1)
+    cg.Initialize()
+    r = np.random.default_rng(1).standard_normal(s.Count)
+    assert np.array_equal(cg.Apply(r), oracle.Multigrid(s).apply(r))
+    cg.Dispose()
+
+
+def test_compressed_multirank(oracle, monkeypatch):
+    """Row slices with a non-zero row base (col - row uses the GLOBAL row) through the loopback transport."""
+    from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu
+    from tests.test_gpu_parallel import _run_ranks_in_threads
+
+    world = 2
+    monkeypatch.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    s = problems.poisson(8, 8, 16)
+    s.b[:] = np.random.default_rng(3).standard_normal(s.Count)
+    ref = oracle.Multigrid(s).pcg(rule=oracle.RULE_CSHARP, max_iteration=400)
+
+    def make_rank(rank, comm):
+        cg = ConjugateGradientMgRankGpu(s.Count, 7, 0, 400, 1e-8, s.grid, rank=rank, world=world, comm=comm, device=rank).load(s)
+        _lib.lib().MgcgSetMatrixCompression(cg.cusparse, 1)
+        cg.Initialize()
+        cg.Setup()
+        cg.Solve()
+        cg.Read()
+        assert _info(cg.cusparse, 0)[0] == 2
+        out = (cg.part.offset, cg.part.count, cg.x[cg.part.offset: cg.part.offset + cg.part.count].copy(), cg.Iteration)
+        cg.Dispose()
+        return out
+
+    x = np.zeros(s.Count)
+    for off, cnt, xs, it in _run_ranks_in_threads(world, make_rank):
+        x[off: off + cnt] = xs
+        assert it == ref["iteration"]
+    assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
