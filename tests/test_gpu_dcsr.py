@@ -37,7 +37,7 @@ def _scaled_poisson(dims, seed=4):
     ("tridiagonal", lambda: problems.tridiagonal(1003), 2, 3, 2),               # unsorted columns: diag, left, right
     ("scaled poisson", lambda: _scaled_poisson((12, 11, 10)), 1, 7, None),      # every value distinct: offsets coded only
     ("narrow band", lambda: problems.mgcg_main(3000, 8), 1, 7, None),           # diagonal first, |sin(i+j)| values
-    ("random", lambda: problems.random_spd(4000, mean_upper=2.5, seed=9), 0, None, None),   # > 256 distinct offsets: stays CSR
+    ("random", lambda: problems.random_spd(4000, mean_upper=2.0, seed=9), 0, None, None),   # > 256 distinct offsets: stays CSR
     ("tiny", lambda: problems.poisson(2, 1, 1), 0, None, None),                 # fewer than 8 nonzeros: not encoded
 ])
 def test_compressed_spmv_is_bit_exact(oracle, name, builder, expect_class, expect_offsets, expect_values):
@@ -53,6 +53,10 @@ def test_compressed_spmv_is_bit_exact(oracle, name, builder, expect_class, expec
     got = A.spmv(h, x)
     assert np.array_equal(plain, ref) and np.array_equal(got, ref)
     cls, nd, nv, rows, nnz = _info(h.sparse)
+    if expect_class == 0:
+        assert cls in (0, -1), (cls, nd, nv)      # analysed and rejected, or not even a candidate (long average rows)
+        h.close()
+        return
     assert cls == expect_class, (cls, nd, nv)
     if expect_offsets is not None:
         assert nd == expect_offsets
