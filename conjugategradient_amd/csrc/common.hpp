@@ -166,7 +166,7 @@ struct SpmvConfig { int kernel = 0; int rowsPerBlock = 64; int flags = 0; int gr
 // Launches the SpMV; returns the number of partials written (grid size) for dot epilogues.
 int launch_spmv(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg);
 // The same on the dictionary-compressed form of the matrix (a.elements / a.columnIndeces still serve array tails and long rows).
-int launch_spmv_dcsr(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView& m, int gridReq);
+int launch_spmv_rows(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView* m, int gridReq);   // m == nullptr: plain CSR
 bool dcsr_build(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces,
                 long long rows, long long nnz, long long rowBase, DcsrMatrix* out);
 // Cached analysis of a matrix on a handle (nullptr: compression off, not applicable, or the build failed).

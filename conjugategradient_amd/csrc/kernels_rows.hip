@@ -1,0 +1,273 @@
+// Row-block SpMV, "stage raw, multiply by row" form (gfx950): one wavefront owns 64 consecutive rows per trip.
+//   1. all 64 lanes stream the rows' contiguous nonzero span with whole-line loads (CSR: column ids + values,
+//      12 B/nnz; DCSR: one or two code bytes per nonzero, see kernels_dcsr.hip) and park the RAW entries in LDS;
+//   2. lane r then walks row r: reads its entries from LDS in stored order, gathers x and accumulates
+//      acc += value * x[col] (product rounded, then added: bit-identical to Mgcg/cuBlas/Mgcg/SparseMatrix.cs:68-88).
+// Compared with spmv_stream_kernel (products parked in LDS, then reduced) the gathers are issued per diagonal:
+// in gather j the 64 lanes address x[row + offset_j], i.e. 64 nearly consecutive doubles (4-5 cache lines) instead
+// of a mix of all diagonals (10+ lines), and the compressed formats need no row search (lane == row).
+// Same software pipeline as the stream kernel: gathers(t) -> epilogue operands(t) -> raw loads(t+1) -> y store(t-1),
+// so every wait is a counted vmcnt that leaves the prefetch and the store in flight.
+#include "common.hpp"
+
+namespace mgcg {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+
+enum { FMT_CSR = 0, FMT_DCSR8 = 1, FMT_DCSR64 = 2 };   // DCSR8: offset + value codes; DCSR64: offset codes + fp64 values
+
+constexpr int kRR = 64;            // rows per trip (one per lane)
+constexpr int kRCap = 512;         // nonzeros staged per pass (8 per lane)
+constexpr int kRAlign = 32;        // spans are read from a 32-nonzero boundary (128 B of column ids / 32 B of codes)
+constexpr int kRDict = 256;
+
+struct RowsEpi { double w, b, dinv, yold; };
+
+template <int EPI>
+__device__ __forceinline__ RowsEpi rows_epi_prefetch(const SpmvArgs& a, long long row)
+{
+    RowsEpi o; o.w = 0.0; o.b = 0.0; o.dinv = 0.0; o.yold = 0.0;
+    if constexpr (EPI == EPI_AXPBY_BETA) o.yold = a.y[row];
+    if constexpr (EPI == EPI_DOT) o.w = a.w[row];
+    if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_DOT) o.b = a.b[row];
+    if constexpr (EPI == EPI_JACOBI) { o.b = a.b[row]; o.dinv = a.dinv[row]; o.w = a.w[row]; }
+    return o;
+}
+
+template <int EPI>
+__device__ __forceinline__ double rows_epilogue_value(const SpmvArgs& a, double acc, const RowsEpi& o, double& dotacc)
+{
+    if constexpr (EPI == EPI_AXPBY) return a.alpha * acc;
+    else if constexpr (EPI == EPI_AXPBY_BETA) { double v = a.alpha * acc; double t = a.beta * o.yold; return v + t; }
+    else if constexpr (EPI == EPI_DOT) { double t = o.w * acc; dotacc += t; return acc; }
+    else if constexpr (EPI == EPI_RESIDUAL) return o.b - acc;
+    else if constexpr (EPI == EPI_RESIDUAL_DOT) { double r = o.b - acc; double t = r * r; dotacc += t; return r; }
+    else { double res = o.b - acc; double t = o.dinv * res; double s = a.omega * t; return o.w + s; }
+}
+
+// Raw data of one pass held in registers between the prefetch and the LDS staging.
+template <int FMT>
+struct RowsStage {
+    i2 col[4];          // FMT_CSR: 8 column ids (4 x int2, one per 128-nonzero quarter)
+    d2 val[4];          // FMT_CSR / FMT_DCSR64: 8 values
+    u2 cc, vc;          // DCSR: 8 offset codes, 8 value codes
+    int my_s, my_e;     // nonzero range of this lane's row
+    int s, e;           // nonzero span of the row block (wave-uniform)
+};
+
+// Lane layout of a pass (512 nonzeros from tb): CSR and DCSR64 values: quarter q (128 nonzeros) lane t owns 128q+2t, +1
+// (whole 1 KiB / 512 B lines per wave-instruction); codes: lane t owns 8t..8t+7 (one 8-byte load).
+template <int EPI, int FMT>
+__global__ __launch_bounds__(64) void spmv_rows_kernel(SpmvArgs a, DcsrView m, int nRowBlocks)
+{
+    __shared__ __attribute__((aligned(16))) double s_val[(FMT == FMT_DCSR8) ? 2 : kRCap];
+    __shared__ __attribute__((aligned(16))) int s_col[(FMT == FMT_CSR) ? kRCap : 4];
+    __shared__ __attribute__((aligned(16))) unsigned char s_cc[(FMT == FMT_CSR) ? 16 : kRCap];
+    __shared__ __attribute__((aligned(16))) unsigned char s_vc[(FMT == FMT_DCSR8) ? kRCap : 16];
+    __shared__ double s_vD[(FMT == FMT_DCSR8) ? kRDict : 1];
+    __shared__ int s_dD[(FMT == FMT_CSR) ? 1 : kRDict];
+
+    if (a.doneFlag != nullptr && *a.doneFlag != 0) return;
+    const int tid = threadIdx.x;
+    if constexpr (FMT != FMT_CSR) {
+        for (int i = tid; i < kRDict; i += 64) {
+            s_dD[i] = i < m.nDelta ? m.deltaDict[i] : 0;
+            if constexpr (FMT == FMT_DCSR8) s_vD[i] = i < m.nValue ? m.valueDict[i] : 0.0;
+        }
+        __syncthreads();
+    }
+
+    const long long lastRow = (long long)a.rowCount - 1;
+    const int nTrips = ((long long)nRowBlocks > (long long)blockIdx.x) ? (int)(((long long)nRowBlocks - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
+    auto rb_of = [&](int t) -> long long { return (long long)blockIdx.x + (long long)t * gridDim.x; };
+    auto span_of = [&](long long rb, int& s, int& e) {
+        const long long r0 = rb * kRR;
+        const long long r1 = (r0 + kRR < (long long)a.rowCount) ? r0 + kRR : (long long)a.rowCount;
+        s = a.rowOffsets[r0]; e = a.rowOffsets[r1];
+    };
+    // clamps for the unconditional wide loads (host guarantees elementsCount >= 8)
+    const int kMaxPair = (a.elementsCount - 2) & ~1;
+    const int kMaxOct = (a.elementsCount - 8) & ~7;
+
+    // issue the raw loads of the pass that starts at nonzero tb (a multiple of 8)
+    auto load_pass = [&](RowsStage<FMT>& st, int tb) {
+        if constexpr (FMT == FMT_CSR || FMT == FMT_DCSR64) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int k = tb + q * 128 + 2 * tid;
+                k = k < kMaxPair ? k : kMaxPair;
+                if constexpr (FMT == FMT_CSR) st.col[q] = *(const i2*)(a.columnIndeces + k);
+                st.val[q] = *(const d2*)(a.elements + k);
+            }
+        }
+        if constexpr (FMT != FMT_CSR) {
+            int k = tb + 8 * tid;
+            k = k < kMaxOct ? k : kMaxOct;
+            st.cc = *(const u2*)(m.colCode + k);
+            if constexpr (FMT == FMT_DCSR8) st.vc = *(const u2*)(m.valCode + k);
+        }
+    };
+    auto issue = [&](RowsStage<FMT>& st, long long rb) {
+        const long long r0 = rb * kRR;
+        long long row = r0 + tid;
+        const bool live = row <= lastRow;
+        row = live ? row : lastRow;
+        const int ms = a.rowOffsets[row], me = a.rowOffsets[row + 1];
+        st.my_s = live ? ms : st.e;
+        st.my_e = live ? me : st.e;
+        load_pass(st, st.s & ~(kRAlign - 1));
+    };
+    // park the raw pass in LDS; entries past the arrays' end are re-read with guards (they were clamped in load_pass)
+    auto stage_pass = [&](const RowsStage<FMT>& st, int tb, int e) {
+        if constexpr (FMT == FMT_CSR || FMT == FMT_DCSR64) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o = q * 128 + 2 * tid;
+                const int k = tb + o;
+                if (k <= kMaxPair) {
+                    if constexpr (FMT == FMT_CSR) *(i2*)(s_col + o) = st.col[q];
+                    *(d2*)(s_val + o) = st.val[q];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (k + j < e) { if constexpr (FMT == FMT_CSR) s_col[o + j] = a.columnIndeces[k + j]; s_val[o + j] = a.elements[k + j]; }
+                }
+            }
+        }
+        if constexpr (FMT != FMT_CSR) {
+            const int o = 8 * tid;
+            const int k = tb + o;
+            if (k <= kMaxOct) {
+                *(u2*)(s_cc + o) = st.cc;
+                if constexpr (FMT == FMT_DCSR8) *(u2*)(s_vc + o) = st.vc;
+            } else {
+                for (int j = 0; j < 8; ++j)
+                    if (k + j < e) { s_cc[o + j] = m.colCode[k + j]; if constexpr (FMT == FMT_DCSR8) s_vc[o + j] = m.valCode[k + j]; }
+            }
+        }
+    };
+
+    double dotacc = 0.0;
+    if (nTrips > 0) {
+        RowsStage<FMT> cur, nxt;
+        span_of(rb_of(0), cur.s, cur.e);
+        issue(cur, rb_of(0));
+        nxt.s = cur.s; nxt.e = cur.e;
+        if (nTrips > 1) span_of(rb_of(1), nxt.s, nxt.e);
+        double pendVal = 0.0;
+        long long pendRow = -1;
+        for (int t = 0; t < nTrips; ++t) {
+            const long long rb = rb_of(t);
+            const long long r0 = rb * kRR;
+            const long long left = (long long)a.rowCount - r0;
+            const int nr = (int)(left < kRR ? left : kRR);
+            int s2 = nxt.s, e2 = nxt.e;
+            if (t + 2 < nTrips) span_of(rb_of(t + 2), s2, e2);
+            const int e = cur.e;
+            const int tb0 = cur.s & ~(kRAlign - 1);
+            const long long myRowGlobal = m.rowBase + r0 + tid;       // DCSR: col = global row + offset
+
+            // ---- first pass: stage, then 8 entries of my row ----
+            stage_pass(cur, tb0, e);
+            __syncthreads();
+            double acc = 0.0;
+            int k = cur.my_s;                                          // next entry of my row
+            const int passEnd0 = tb0 + kRCap;
+            double xg[8], vv[8];
+            int cnt = cur.my_e - k; cnt = cnt < 8 ? cnt : 8;
+            { const int room = passEnd0 - k; cnt = cnt < room ? cnt : room; cnt = cnt > 0 ? cnt : 0; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int idx = k + j - tb0;
+                idx = (j < cnt) ? idx : 0;                            // masked lanes read slot 0 (a real entry of the block)
+                long long col;
+                if constexpr (FMT == FMT_CSR) { col = s_col[idx]; vv[j] = s_val[idx]; }
+                else {
+                    col = myRowGlobal + s_dD[s_cc[idx]];
+                    if constexpr (FMT == FMT_DCSR8) vv[j] = s_vD[s_vc[idx]]; else vv[j] = s_val[idx];
+                }
+                if (j >= cnt) col = 0;                                // masked: any valid column
+                if (a.ablate & 2) col &= 1023;
+                xg[j] = a.x[col];
+            }
+            long long myRow = r0 + tid;
+            myRow = myRow <= lastRow ? myRow : lastRow;
+            const RowsEpi eo = rows_epi_prefetch<EPI>(a, myRow);
+            // the next block's raw stream goes in flight behind the gathers, then the previous trip's result
+            issue(nxt, t + 1 < nTrips ? rb_of(t + 1) : rb);
+            if (pendRow >= 0 && !(a.ablate & 1)) a.y[pendRow] = pendVal;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const double p = vv[j] * xg[j]; acc += (j < cnt) ? p : 0.0; }
+            k += cnt;
+            // ---- the rest of a long row inside this pass, then further passes (not pipelined) ----
+            int tb = tb0;
+            while (true) {
+                const int passEnd = tb + kRCap;
+                const int stop = cur.my_e < passEnd ? cur.my_e : passEnd;
+                for (; k < stop; ++k) {
+                    const int idx = k - tb;
+                    long long col; double v;
+                    if constexpr (FMT == FMT_CSR) { col = s_col[idx]; v = s_val[idx]; }
+                    else { col = myRowGlobal + s_dD[s_cc[idx]]; if constexpr (FMT == FMT_DCSR8) v = s_vD[s_vc[idx]]; else v = s_val[idx]; }
+                    const double p = v * a.x[col];
+                    acc += p;
+                }
+                tb += kRCap;
+                if (tb >= e) break;                                   // wave-uniform
+                __syncthreads();
+                RowsStage<FMT> more;
+                more.s = cur.s; more.e = cur.e; more.my_s = cur.my_s; more.my_e = cur.my_e;
+                load_pass(more, tb);
+                stage_pass(more, tb, e);
+                __syncthreads();
+            }
+            pendRow = -1;
+            if (tid < nr) { pendVal = rows_epilogue_value<EPI>(a, acc, eo, dotacc); pendRow = r0 + tid; }
+            if ((a.ablate & 1) && acc == 1.2345e300) pendRow = 0;
+            __syncthreads();                                          // LDS is free for the next trip
+            cur = nxt;
+            nxt.s = s2; nxt.e = e2;
+        }
+        if (pendRow >= 0 && !(a.ablate & 1)) a.y[pendRow] = pendVal;
+    }
+    if constexpr (EPI == EPI_DOT || EPI == EPI_RESIDUAL_DOT) {
+        double v = dotacc;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (tid == 0) a.partials[blockIdx.x] = v;
+    }
+}
+
+template <int EPI>
+static int launch_rows_epi(hipStream_t s, const SpmvArgs& a, const DcsrView* m, int gridReq)
+{
+    const int nRowBlocks = (int)(((long long)a.rowCount + kRR - 1) / kRR);
+    DeviceState* d = device_state();
+    int grid = gridReq > 0 ? gridReq : 16 * (d ? d->numCu : kNumCu);
+    if (grid > kMaxPartials) grid = kMaxPartials;
+    if (grid > nRowBlocks) grid = nRowBlocks;
+    if (grid < 1) grid = 1;
+    DcsrView none{};
+    if (m == nullptr) hipLaunchKernelGGL((spmv_rows_kernel<EPI, FMT_CSR>), dim3(grid), dim3(64), 0, s, a, none, nRowBlocks);
+    else if (m->valCode != nullptr) hipLaunchKernelGGL((spmv_rows_kernel<EPI, FMT_DCSR8>), dim3(grid), dim3(64), 0, s, a, *m, nRowBlocks);
+    else hipLaunchKernelGGL((spmv_rows_kernel<EPI, FMT_DCSR64>), dim3(grid), dim3(64), 0, s, a, *m, nRowBlocks);
+    return grid;
+}
+
+// m == nullptr: plain CSR.  Requires 16-byte aligned elements, 8-byte aligned columnIndeces and elementsCount >= 8.
+int launch_spmv_rows(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView* m, int gridReq)
+{
+    if (a.rowCount <= 0) return 0;
+    switch (epilogue) {
+    case EPI_AXPBY:        return a.beta != 0.0 ? launch_rows_epi<EPI_AXPBY_BETA>(s, a, m, gridReq) : launch_rows_epi<EPI_AXPBY>(s, a, m, gridReq);
+    case EPI_DOT:          return launch_rows_epi<EPI_DOT>(s, a, m, gridReq);
+    case EPI_RESIDUAL:     return launch_rows_epi<EPI_RESIDUAL>(s, a, m, gridReq);
+    case EPI_RESIDUAL_DOT: return launch_rows_epi<EPI_RESIDUAL_DOT>(s, a, m, gridReq);
+    case EPI_JACOBI:       return launch_rows_epi<EPI_JACOBI>(s, a, m, gridReq);
+    }
+    return 0;
+}
+
+} // namespace mgcg

@@ -501,6 +501,11 @@ static int launch_spmv_epi(hipStream_t s, const SpmvArgs& a, const SpmvConfig& c
         else if (avg <= 96.0) kernel = 7;   // 32 lanes per row
         else kernel = 8;                    // one wavefront per row
     }
+    if (kernel == 9) {      // row-block kernel, "stage raw, multiply by row" form; same alignment needs as the stream kernel's wide path
+        const bool ok = (((uintptr_t)a.elements & 15) == 0) && (((uintptr_t)a.columnIndeces & 7) == 0) && a.elementsCount >= 8;
+        if (ok) return launch_spmv_rows(s, EPI == EPI_AXPBY_BETA ? (int)EPI_AXPBY : (int)EPI, a, nullptr, cfg.gridBlocks);
+        kernel = 1;
+    }
     switch (kernel) {
     case 1: return launch_stream<EPI>(s, a, cfg);
     case 3: return launch_vector_l<EPI, 2>(s, a, cfg);

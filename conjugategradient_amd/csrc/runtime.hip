@@ -118,7 +118,7 @@ const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* 
 
 int launch_spmv_auto(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg, const DcsrMatrix* dc)
 {
-    if (dc != nullptr && dc->usable && a.elementsCount >= 8) return launch_spmv_dcsr(s, epilogue, a, dc->view(), cfg.gridBlocks);
+    if (dc != nullptr && dc->usable && a.elementsCount >= 8) { const DcsrView v = dc->view(); return launch_spmv_rows(s, epilogue, a, &v, cfg.gridBlocks); }
     return launch_spmv(s, epilogue, a, cfg);
 }
 

@@ -43,6 +43,7 @@ def main():
                 ("wave R64 g4096 nt", 1, 64, 1, 4096, 0, 0), ("wave R32 g6144", 1, 32, 0, 6144, 0, 0),
                 ("wave R64 band", 1, 64, 4, 0, 0, 0), ("wave R32 band", 1, 32, 4, 0, 0, 0), ("wave R32 band 8Lx8", 1, 32, 4, 0, 8 * n, 8),
                 ("wg256 band 64Lx1", 1, 128, 4, 0, 64 * n, 1), ("vector 4 lanes", 4, 128, 0, 0, 0, 0),
+                ("rows", 9, 64, 0, 0, 0, 0), ("rows g2048", 9, 64, 0, 2048, 0, 0), ("rows g5120", 9, 64, 0, 5120, 0, 0), ("DOT rows", 9, 64, 0, 0, 0, 0),
                 ("dcsr", 1, 64, 0, 0, 0, 0), ("dcsr g2048", 1, 64, 0, 2048, 0, 0), ("dcsr g8192", 1, 64, 0, 8192, 0, 0), ("DOT dcsr", 1, 64, 0, 0, 0, 0),
                 ("DOT wave R64 g4096", 1, 64, 0, 4096, 0, 0), ("DOT wave R64 band", 1, 64, 4, 0, 0, 0), ("DOT wg256 R128", 1, 128, 0, 0, 0, 0)]
     if a.variants:
@@ -68,7 +69,7 @@ def main():
         return L.MgcgEventElapsedMs(ev0, ev1) / a.reps
 
     if a.ablate:
-        base = [v for v in variants if v[0] in ("wg256 R128", "wave R64 g4096", "wave R64 band", "wg256 band 64Lx1", "wave R64 g4096 nt", "dcsr")]
+        base = [v for v in variants if v[0] in ("wg256 R128", "wave R64 g4096", "wave R64 band", "wg256 band 64Lx1", "wave R64 g4096 nt", "dcsr", "rows")]
         for ab, tag in ((1, "no y store"), (2, "gathers from L1"), (3, "no store + L1 gathers"), (8, "y store confined to 512 KB")):
             for v in base:
                 variants.append((v[0] + " | " + tag,) + tuple(v[1:]) + (ab,))

@@ -38,6 +38,8 @@ def test_csrmv_stream_kernel_is_bit_exact(h, oracle, system):
     for tuning in [(256, 0, 0), (128, 0, 0), (64, 0, 0), (32, 0, 0), (32, 1, 24), (64, 2, 0), (256, 1, 0), (256, 2, 0), (256, 3, 0), (256, 0, 16)]:
         y = A.spmv(h, x, kernel=1, tuning=tuning)
         assert np.array_equal(y, ref), f"tuning {tuning}"
+    for grid in (0, 7, 4096):                          # "stage raw, multiply by row" form of the row-block kernel
+        assert np.array_equal(A.spmv(h, x, kernel=9, tuning=(64, 0, grid)), ref), f"rows kernel grid {grid}"
     y = A.spmv(h, x)                                   # auto selection
     np.testing.assert_allclose(y, ref, rtol=1e-13, atol=1e-13 * np.abs(ref).max())
 
@@ -91,9 +93,11 @@ def test_csrmv_alpha_beta_and_edges(h, oracle):
     M.sort_indices()
     sysm = problems.LinearSystem(M.data.astype(np.float64), M.indices.astype(np.int32), M.indptr.astype(np.int32), np.zeros(400), np.zeros(400), "holes")
     xv = rng.standard_normal(400)
-    for k in (1, 5, 8):
+    for k in (1, 5, 8, 9):
         assert np.allclose(DeviceCsr(sysm).spmv(h, xv, kernel=k), oracle.spmv(sysm.Elements, sysm.ColumnIndeces, sysm.RowOffsets, xv), rtol=1e-13, atol=1e-15)
     assert np.array_equal(DeviceCsr(sysm).spmv(h, xv, kernel=1), oracle.spmv(sysm.Elements, sysm.ColumnIndeces, sysm.RowOffsets, xv))
+    assert np.array_equal(DeviceCsr(sysm).spmv(h, xv, kernel=9), oracle.spmv(sysm.Elements, sysm.ColumnIndeces, sysm.RowOffsets, xv))
+    assert np.array_equal(A.spmv(h, x, alpha=2.5, beta=-0.75, y0=y0, kernel=9), 2.5 * Ax + (-0.75) * y0)
     empty = problems.LinearSystem(np.zeros(0), np.zeros(0, np.int32), np.zeros(6, np.int32), np.zeros(5), np.zeros(5), "empty")
     assert np.array_equal(DeviceCsr(empty).spmv(h, np.ones(5), kernel=1, y0=np.full(5, 7.0)), np.zeros(5))
 
