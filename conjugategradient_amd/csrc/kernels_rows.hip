@@ -245,7 +245,9 @@ static int launch_rows_epi(hipStream_t s, const SpmvArgs& a, const DcsrView* m, 
 {
     const int nRowBlocks = (int)(((long long)a.rowCount + kRR - 1) / kRR);
     DeviceState* d = device_state();
-    int grid = gridReq > 0 ? gridReq : 16 * (d ? d->numCu : kNumCu);
+    // resident wavefronts per CU measured best on the 7-point 512^3 matrix: 8 for CSR (HBM-bound), 16 for the compressed
+    // forms (latency-bound decode); more only adds cache pressure (profiles/r1/spmv_sweep_rows_dcsr_512.log)
+    int grid = gridReq > 0 ? gridReq : (m == nullptr ? 8 : 16) * (d ? d->numCu : kNumCu);
     if (grid > kMaxPartials) grid = kMaxPartials;
     if (grid > nRowBlocks) grid = nRowBlocks;
     if (grid < 1) grid = 1;

@@ -496,7 +496,7 @@ static int launch_spmv_epi(hipStream_t s, const SpmvArgs& a, const SpmvConfig& c
     int kernel = cfg.kernel;
     if (kernel == 0) {
         const double avg = a.rowCount > 0 ? (double)a.elementsCount / (double)a.rowCount : 0.0;
-        if (avg <= 24.0) kernel = 1;
+        if (avg <= 24.0) kernel = 9;        // short rows: row-block kernel (falls back to the stream form for unaligned arrays)
         else if (avg <= 48.0) kernel = 6;   // 16 lanes per row
         else if (avg <= 96.0) kernel = 7;   // 32 lanes per row
         else kernel = 8;                    // one wavefront per row
