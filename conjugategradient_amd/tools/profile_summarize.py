@@ -31,7 +31,7 @@ def main(out):
     res["kernels"].sort(key=lambda k: -k["total_ns"])
     rd, wr = counters(os.path.join(out, "pmc_rd")), counters(os.path.join(out, "pmc_wr"))
     for k in rd:
-        if "spmv_stream_kernel" in k and ("<1," in k or "<(mgcg::SpmvEpilogue)1" in k or True):
+        if "spmv_" in k:
             c = rd[k]
             n = len(c.get("TCC_EA0_RDREQ_128B_sum", []))
             if n == 0:
