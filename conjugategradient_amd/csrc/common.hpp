@@ -56,7 +56,7 @@ struct CgScalars {
     int iteration;    // index of the iteration being executed
     int done;         // set by the finalisation kernel; every later kernel exits at once
     int status;
-    int pad;
+    int pad;          // "x pending": set by the finalisation kernel for update_xp, cleared when no iteration ran
 };
 
 // What the host polls (pinned, device-written).
@@ -194,6 +194,9 @@ int  launch_update_xr(hipStream_t s, const CgScalars* sc, double* x, double* r, 
                       long long n, double* partials, double* partialsInf);
 // p = z + beta p with beta = sc->beta ; skipped when sc->done
 void launch_update_p(hipStream_t s, const CgScalars* sc, double* p, const double* z, long long n);
+// the loop's own split: r -= alpha Ap (+ r.r), then x += alpha p and p = z + beta p in one pass over p
+int  launch_update_r(hipStream_t s, CgScalars* sc, double* r, const double* Ap, long long n, double* partials, double* partialsInf);
+void launch_update_xp(hipStream_t s, const CgScalars* sc, double* x, double* p, const double* z, long long n);
 
 struct FinalizeArgs {
     CgScalars* sc;

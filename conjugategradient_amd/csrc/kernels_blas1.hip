@@ -263,6 +263,82 @@ int launch_update_xr(hipStream_t s, const CgScalars* sc, double* x, double* r, c
     return grid;
 }
 
+// The device-resident loop splits the reference's update (ConjugateGradientCpu.cs:72-74,94) differently from the
+// reference's phase functions: r first (its norm decides the stop test), then x and p together, so that p is read
+// once for both x += alpha p and p = z + beta p  (64N bytes per iteration instead of 72N).
+// alpha = rr / pAp ; r = r + (-alpha)*Ap ; partial r.r [, partial max|r|]
+template <bool V2, bool INF>
+__global__ __launch_bounds__(kBlock) void update_r_kernel(CgScalars* __restrict__ sc, double* __restrict__ r, const double* __restrict__ Ap, long long n,
+                                                          double* __restrict__ partials, double* __restrict__ partialsInf)
+{
+    __shared__ double s_red[4];
+    __shared__ double s_red2[4];
+    if (sc->done != 0) return;
+    const double alpha = sc->rr / sc->pAp;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;      // for update_xp of this iteration
+    const double malpha = -alpha;
+    double acc = 0.0, mx = 0.0;
+    grid_stride<V2>(n,
+        [&](long long i) {
+            d2 av = *(const d2*)(Ap + i); d2 rv = *(d2*)(r + i);
+            double u0 = malpha * av.x; double u1 = malpha * av.y; rv.x = rv.x + u0; rv.y = rv.y + u1; *(d2*)(r + i) = rv;
+            double q0 = rv.x * rv.x; double q1 = rv.y * rv.y; acc += q0; acc += q1;
+            if (INF) { double a0 = fabs(rv.x); double a1 = fabs(rv.y); mx = a0 > mx ? a0 : mx; mx = a1 > mx ? a1 : mx; }
+        },
+        [&](long long i) {
+            double u = malpha * Ap[i]; double rv = r[i] + u; r[i] = rv;
+            double q = rv * rv; acc += q;
+            if (INF) { double a0 = fabs(rv); mx = a0 > mx ? a0 : mx; }
+        });
+    const double t = block_sum(acc, s_red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    if (INF) {
+        const double m = block_max(mx, s_red2);
+        if (threadIdx.x == 0) partialsInf[blockIdx.x] = m;
+    }
+}
+int launch_update_r(hipStream_t s, CgScalars* sc, double* r, const double* Ap, long long n, double* partials, double* partialsInf)
+{
+    const bool v2 = al16(r) && al16(Ap);
+    const int grid = grid_for(n, v2 ? 4 : 2);
+    const bool inf = partialsInf != nullptr;
+#define GO(V, I) hipLaunchKernelGGL((update_r_kernel<V, I>), dim3(grid), dim3(kBlock), 0, s, sc, r, Ap, n, partials, partialsInf)
+    if (v2) { if (inf) GO(true, true); else GO(true, false); }
+    else { if (inf) GO(false, true); else GO(false, false); }
+#undef GO
+    return grid;
+}
+
+// x = x + alpha*p (whenever the iteration ran: sc->pad is the finalisation kernel's "x pending" mark) and, unless the
+// stop test fired, p = z + beta*p.
+template <bool V2>
+__global__ __launch_bounds__(kBlock) void update_xp_kernel(const CgScalars* __restrict__ sc, double* __restrict__ x, double* __restrict__ p,
+                                                           const double* __restrict__ z, long long n)
+{
+    if (sc->pad == 0) return;                   // this iteration did not run (the loop had already stopped)
+    const double alpha = sc->alpha, beta = sc->beta;
+    if (sc->done != 0) {                        // the iteration that stopped the loop: x only
+        grid_stride<V2>(n,
+            [&](long long i) { d2 pv = *(const d2*)(p + i); d2 xv = *(d2*)(x + i); double t0 = alpha * pv.x; double t1 = alpha * pv.y; xv.x = xv.x + t0; xv.y = xv.y + t1; *(d2*)(x + i) = xv; },
+            [&](long long i) { double t = alpha * p[i]; x[i] = x[i] + t; });
+        return;
+    }
+    grid_stride<V2>(n,
+        [&](long long i) {
+            d2 pv = *(d2*)(p + i); d2 xv = *(d2*)(x + i); d2 zv = *(const d2*)(z + i);
+            double t0 = alpha * pv.x; double t1 = alpha * pv.y; xv.x = xv.x + t0; xv.y = xv.y + t1; *(d2*)(x + i) = xv;
+            double u0 = beta * pv.x; double u1 = beta * pv.y; pv.x = zv.x + u0; pv.y = zv.y + u1; *(d2*)(p + i) = pv;
+        },
+        [&](long long i) { const double pv = p[i]; double t = alpha * pv; x[i] = x[i] + t; double u = beta * pv; p[i] = z[i] + u; });
+}
+void launch_update_xp(hipStream_t s, const CgScalars* sc, double* x, double* p, const double* z, long long n)
+{
+    if (n <= 0) return;
+    const bool v2 = al16(x) && al16(p) && al16(z);
+    if (v2) hipLaunchKernelGGL(update_xp_kernel<true>, dim3(grid_for(n, 2)), dim3(kBlock), 0, s, sc, x, p, z, n);
+    else hipLaunchKernelGGL(update_xp_kernel<false>, dim3(grid_for(n, 1)), dim3(kBlock), 0, s, sc, x, p, z, n);
+}
+
 // p = z + beta*p   (ConjugateGradientCpu.cs:94 with z = r; the preconditioned loop passes z = M^-1 r)
 template <bool V2>
 __global__ __launch_bounds__(kBlock) void update_p_kernel(const CgScalars* __restrict__ sc, double* __restrict__ p, const double* __restrict__ z, long long n)
@@ -291,7 +367,7 @@ __global__ __launch_bounds__(kBlock) void init_scalars_kernel(const double* __re
     if (threadIdx.x == 0) {
         if (!reduceFirst) rr = sc->rr;
         sc->rr = rr; sc->rr0 = rr; sc->pAp = 0; sc->rrNew = 0; sc->rzNew = 0; sc->residual = 0; sc->nrmInf = 0;
-        sc->beta = 0; sc->alpha = 0; sc->iteration = 0; sc->done = 0; sc->status = 0;
+        sc->beta = 0; sc->alpha = 0; sc->iteration = 0; sc->done = 0; sc->status = 0; sc->pad = 0;
         (void)rule;
         mirror->residual = 0; mirror->iteration = 0; mirror->status = 0; mirror->done = 0;
     }
@@ -308,7 +384,7 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const double* __restri
     __shared__ double s_red[4];
     __shared__ double s_red2[4];
     CgScalars* sc = f.sc;
-    if (sc->done != 0) return;
+    if (sc->done != 0) { if (threadIdx.x == 0) sc->pad = 0; return; }     // no iteration ran: nothing pending for update_xp
     double rrNew = 0.0, inf = 0.0;
     if (reduceFirst) {
         rrNew = reduce_partials_block(partials, n, s_red, 0);
@@ -333,6 +409,7 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const double* __restri
     if (!stop && !(res == res && fabs(res) <= 1.79e308)) { stop = true; status = MGCG_NONFINITE; }
     if (f.trace != nullptr && it < f.traceCap) f.trace[it] = shown;
     sc->rrNew = rrNew; sc->residual = res; sc->nrmInf = inf;
+    sc->pad = 1;                                 // this iteration's x += alpha p is still to be done (update_xp)
     if (stop) {
         sc->done = 1; sc->status = status;
         f.mirror->residual = res; f.mirror->iteration = it; f.mirror->status = status;

@@ -220,7 +220,7 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
     launch_reduce_to(s, R.ws->partials, n, &sc->pAp, done);
     if (R.nranks > 1 && !comm_allreduce_sum(R.comm, &sc->pAp, 1, s)) return false;   // (:499)
     double* pInf = R.wantInf ? R.ws->partials + kMaxPartials : nullptr;
-    n = launch_update_xr(s, sc, R.x, R.r, pLoc, R.Ap, R.nLocal, R.ws->partials, pInf);   // x += a p ; r -= a Ap ; r.r  (:246-248)
+    n = launch_update_r(s, sc, R.r, R.Ap, R.nLocal, R.ws->partials, pInf);           // r -= a Ap ; r.r  (:247-248); x += a p rides with the p update below
     FinalizeArgs f{};
     f.sc = sc; f.mirror = R.ws->mirror; f.trace = R.ws->trace; f.traceCap = R.ws->traceCap;
     f.tol = R.tol; f.minIt = R.minIt; f.maxIt = R.maxIt; f.rule = R.rule; f.preconditioned = R.mg ? 1 : 0;
@@ -242,9 +242,9 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
         } else {
             launch_finalize_precond(s, R.ws->partials, n, true, sc);                 // beta = rzNew / rz
         }
-        launch_update_p(s, sc, pLoc, R.z, R.nLocal);                                 // p = z + beta p
+        launch_update_xp(s, sc, R.x, pLoc, R.z, R.nLocal);                           // x += a p (:246) ; p = z + beta p
     } else {
-        launch_update_p(s, sc, pLoc, R.r, R.nLocal);                                 // p = r + beta p   (:265)
+        launch_update_xp(s, sc, R.x, pLoc, R.r, R.nLocal);                           // x += a p (:246) ; p = r + beta p   (:265)
     }
     return MGCG_HIP(hipGetLastError());
 }
