@@ -180,3 +180,30 @@ def test_phase_functions_leave_reference_state(oracle):
     assert np.array_equal(vp.to_numpy(), rnew + (rr2 / rr) * p)
     _lib.check("phases")
     h.close()
+
+
+def test_other_front_ends(oracle):
+    """ViennaCL's ComputerGpu (relative rule) and HandmadeCL's max-norm solver on the same library (rows a13/a14)."""
+    from conjugategradient_amd.frontends import ComputerGpu, ConjugateGradientCLGpu
+
+    s = problems.mgcg_main(1800, 160)
+    s.x[:] = 0.0
+    ref = oracle.cg(s, rule=oracle.RULE_VIENNACL, allowable_residual=1e-4, min_iteration=0, max_iteration=1800, hard_cap=2000)
+    gpu = ComputerGpu(s.Count)
+    gpu.Write(s.Elements, s.RowOffsets.astype(np.uint32), s.ColumnIndeces.astype(np.uint32), s.x, s.b)
+    gpu.Solve(1e-4, 0, 1800)                       # MgcgCL.cs: tolerance 1e-4 relative
+    x = np.zeros(s.Count)
+    gpu.Read(x)
+    assert gpu.Iteration() == ref["iteration"] + 1
+    assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
+    gpu.Dispose()
+
+    ref = oracle.cg(s, rule=oracle.RULE_HANDMADECL, allowable_residual=1e-4, min_iteration=50, max_iteration=1800)   # MgcgCLMain.cs:25,35
+    cl = ConjugateGradientCLGpu(s.Count, 160, 50, 1800, 1e-4).load(s)
+    cl.Initialize()
+    cl.Solve()
+    cl.Read()
+    assert cl.Iteration == ref["iteration"] == 50
+    assert abs(cl.Residual - ref["residual"]) <= 1e-3 * ref["residual"] + 1e-12      # round-off level max-norm after 50 forced iterations
+    assert np.abs(cl.x - ref["x"]).max() <= 1e-9 * np.abs(ref["x"]).max()
+    cl.Dispose()
