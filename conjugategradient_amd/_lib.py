@@ -112,6 +112,7 @@ SIGNATURES = {
     "MgcgCommAllReduceSum": (_d, [_vp, _d]),
     "SolveParallel": (_i, [_vp] * 12 + [_i, _i, _i, _i, _i, _i, _d, _i, _i, _i, _pi, _pd, _vp, _i]),
     "CgSteps": (_d, [_vp] * 11 + [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "MgcgLastOverlap": (_i, [_vp]),
 }
 
 RULE_NATIVE, RULE_CSHARP, RULE_SIMPLE, RULE_HANDMADECL, RULE_VIENNACL = range(5)

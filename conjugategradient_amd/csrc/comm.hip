@@ -91,6 +91,8 @@ struct MgcgComm {
     int nranks = 1, rank = 0;
     hipStream_t stream = nullptr;
     double* scratch = nullptr;       // device, 8 doubles
+    hipStream_t haloStream = nullptr;                 // the halo travels here while interior rows are multiplied on `stream`
+    hipEvent_t evReady = nullptr, evHalo = nullptr;
 };
 
 namespace mgcg {
@@ -210,6 +212,28 @@ bool halo_exchange(MgcgComm* c, HaloPlan* h, double* p, hipStream_t s)
     return ok;
 }
 
+// Overlapped form: ready(main) marks the point where p is final; run() exchanges on the communicator's own stream
+// behind that mark; wait(main) makes the main stream wait for the halo.  Kernels enqueued on the main stream
+// between ready and wait (the interior rows) run while the halo is in flight.
+bool halo_overlap_available(MgcgComm* c)
+{
+    if (!c || c->nranks == 1) return false;
+    if (c->haloStream) return true;
+    if (!MGCG_HIP(hipStreamCreateWithFlags(&c->haloStream, hipStreamNonBlocking))) { c->haloStream = nullptr; return false; }
+    if (!MGCG_HIP(hipEventCreateWithFlags(&c->evReady, hipEventDisableTiming)) || !MGCG_HIP(hipEventCreateWithFlags(&c->evHalo, hipEventDisableTiming))) {
+        (void)hipStreamDestroy(c->haloStream); c->haloStream = nullptr; return false;
+    }
+    return true;
+}
+bool halo_overlap_ready(MgcgComm* c, hipStream_t mainStream) { return MGCG_HIP(hipEventRecord(c->evReady, mainStream)); }
+bool halo_overlap_run(MgcgComm* c, HaloPlan* h, double* p)
+{
+    bool ok = MGCG_HIP(hipStreamWaitEvent(c->haloStream, c->evReady, 0));
+    ok = ok && halo_exchange(c, h, p, c->haloStream);
+    return ok && MGCG_HIP(hipEventRecord(c->evHalo, c->haloStream));
+}
+bool halo_overlap_wait(MgcgComm* c, hipStream_t mainStream) { return MGCG_HIP(hipStreamWaitEvent(mainStream, c->evHalo, 0)); }
+
 } // namespace mgcg
 
 using namespace mgcg;
@@ -273,6 +297,9 @@ void MgcgCommDestroy(MgcgComm* c)
     if (!c) return;
     if (c->comm) { Rccl* r = rccl(); if (r && r->CommDestroy) (void)r->CommDestroy(c->comm); }
     if (c->scratch) (void)hipFree(c->scratch);
+    if (c->evReady) (void)hipEventDestroy(c->evReady);
+    if (c->evHalo) (void)hipEventDestroy(c->evHalo);
+    if (c->haloStream) (void)hipStreamDestroy(c->haloStream);
     delete c;
 }
 

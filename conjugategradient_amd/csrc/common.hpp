@@ -174,6 +174,10 @@ const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* 
                               long long rows, long long nnz, long long rowBase);
 // CSR or compressed, whichever the handle has for this matrix.
 int launch_spmv_auto(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg, const DcsrMatrix* dc);
+// Rows [r0, r1) of the same matrix (a describes the WHOLE local matrix; y, w, b, dinv are shifted here); partials for
+// dot epilogues go to `partials`, at most maxGrid of them.
+int launch_spmv_range(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg, const DcsrMatrix* dc,
+                      long long r0, long long r1, double* partials, int maxGrid);
 
 // ---------------------------------------------------------------- BLAS-1 and fused CG updates
 void launch_axpy(hipStream_t s, double* y, const double* x, long long n, double alpha);
@@ -224,6 +228,7 @@ void launch_poisson(hipStream_t s, int nx, int ny, int nz, int zBegin, int zEnd,
 void launch_rebase(hipStream_t s, int* rowOffsets, long long n, int base);
 long long poisson_nnz_host(int nx, int ny, int nz, int zBegin, int zEnd);
 void launch_minmax_int(hipStream_t s, const int* v, long long n, int* out2 /* device int[2] */);
+void launch_halo_rows(hipStream_t s, const int* rowOffsets, const int* columnIndeces, long long n, long long offset, int* out2 /* {0, n} */);
 
 // ---------------------------------------------------------------- RCCL (dlopen'ed)
 struct CommImpl;
@@ -232,5 +237,10 @@ struct HaloPlan;  // per-peer contiguous send/recv ranges of p
 HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long long countLocal, int minJ, int maxJ);
 void halo_plan_destroy(HaloPlan* h);
 bool halo_exchange(MgcgComm* c, HaloPlan* h, double* p, hipStream_t s);
+// halo in flight on the communicator's own stream while the main stream multiplies the interior rows
+bool halo_overlap_available(MgcgComm* c);
+bool halo_overlap_ready(MgcgComm* c, hipStream_t mainStream);
+bool halo_overlap_run(MgcgComm* c, HaloPlan* h, double* p);
+bool halo_overlap_wait(MgcgComm* c, hipStream_t mainStream);
 
 } // namespace mgcg

@@ -249,4 +249,33 @@ void launch_minmax_int(hipStream_t s, const int* v, long long n, int* out2)
     hipLaunchKernelGGL(minmax_kernel, dim3(grid1(n)), dim3(kBlock), 0, s, v, n, out2);
 }
 
+// Which local rows touch columns outside [offset, offset+n)?  out2[0] = 1 + last row that references a column below the
+// slice (0 if none), out2[1] = first row that references a column above it (n if none); pre-set by the caller to {0, n}.
+__global__ __launch_bounds__(kBlock) void halo_rows_kernel(const int* __restrict__ rowOffsets, const int* __restrict__ columnIndeces,
+                                                           long long n, long long offset, int* out2)
+{
+    int lowNeed = 0, highNeed = 0x7fffffff;
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        bool below = false, above = false;
+        for (int k = rowOffsets[i]; k < rowOffsets[i + 1]; ++k) {
+            const long long c = columnIndeces[k];
+            below = below || c < offset;
+            above = above || c >= offset + n;
+        }
+        if (below) lowNeed = (int)i + 1;                 // i grows along the loop
+        if (above && (int)i < highNeed) highNeed = (int)i;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        int l2 = __shfl_down(lowNeed, off, 64), h2 = __shfl_down(highNeed, off, 64);
+        lowNeed = l2 > lowNeed ? l2 : lowNeed; highNeed = h2 < highNeed ? h2 : highNeed;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&out2[0], lowNeed); atomicMin(&out2[1], highNeed); }
+}
+void launch_halo_rows(hipStream_t s, const int* rowOffsets, const int* columnIndeces, long long n, long long offset, int* out2)
+{
+    hipLaunchKernelGGL(halo_rows_kernel, dim3(grid1(n)), dim3(kBlock), 0, s, rowOffsets, columnIndeces, n, offset, out2);
+}
+
 } // namespace mgcg

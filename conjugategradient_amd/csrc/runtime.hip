@@ -122,6 +122,35 @@ int launch_spmv_auto(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvC
     return launch_spmv(s, epilogue, a, cfg);
 }
 
+int launch_spmv_range(hipStream_t s, int epilogue, const SpmvArgs& whole, const SpmvConfig& cfg, const DcsrMatrix* dc,
+                      long long r0, long long r1, double* partials, int maxGrid)
+{
+    if (r1 <= r0) return 0;
+    SpmvArgs a = whole;
+    a.rowOffsets += r0; a.y += r0; a.rowCount = (int)(r1 - r0); a.partials = partials;   // offsets stay absolute into elements / columnIndeces
+    if (a.w) a.w += r0;
+    if (a.b) a.b += r0;
+    if (a.dinv) a.dinv += r0;
+    const bool compressed = dc != nullptr && dc->usable && whole.elementsCount >= 8;
+    SpmvConfig c = cfg;
+    c.flags &= ~6;                                       // the XCD / banded maps assume the whole matrix
+    if (maxGrid > 0) {
+        const int numCu = device_state() ? device_state()->numCu : kNumCu;
+        int g = c.gridBlocks > 0 ? c.gridBlocks : (compressed ? 16 : 8) * numCu;
+        c.gridBlocks = g < maxGrid ? g : maxGrid;
+    }
+    if (compressed) {
+        DcsrView v = dc->view();
+        v.rowBase += r0;
+        return launch_spmv_rows(s, epilogue, a, &v, c.gridBlocks);
+    }
+    if (c.kernel == 0) {                                 // the kernel choice follows the whole matrix, not the slice
+        const double avg = whole.rowCount > 0 ? (double)whole.elementsCount / (double)whole.rowCount : 0.0;
+        c.kernel = avg <= 24.0 ? 9 : avg <= 48.0 ? 6 : avg <= 96.0 ? 7 : 8;
+    }
+    return launch_spmv(s, epilogue, a, c);
+}
+
 } // namespace mgcg
 
 using namespace mgcg;

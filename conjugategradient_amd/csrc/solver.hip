@@ -30,6 +30,8 @@ struct MgLevel {
     const DcsrMatrix* dcsr = nullptr;      // compressed form (owned by the MgcgSparse handle's cache)
     HaloPlan* halo = nullptr;              // multi-rank: planes of the iterate owned by the neighbours
     int minJ = 0, maxJ = -1;
+    bool overlap = false;                  // interior rows [interior0, interior1) are multiplied while the halo travels
+    long long interior0 = 0, interior1 = 0;
 };
 
 } // namespace mgcg
@@ -52,22 +54,60 @@ static SpmvConfig cfg_of(const MgcgSparse* h)
     return c;
 }
 
+// Can the halo of a row slice hide behind its interior rows?  (several ranks, most rows reference local columns only).
+// MGCG_OVERLAP: 0 off, 1 (default) when it pays, 2 whenever an interior exists (tests).
+static bool plan_overlap(hipStream_t s, MgcgComm* comm, int nranks, const int* rowOffsets, const int* columnIndeces,
+                         long long n, long long offset, bool* active, long long* i0, long long* i1)
+{
+    *active = false; *i0 = 0; *i1 = 0;
+    int mode = 1;
+    if (const char* e = getenv("MGCG_OVERLAP")) mode = atoi(e);
+    if (nranks <= 1 || mode == 0 || (mode == 1 && n < 4096)) return true;
+    int* d2 = nullptr;
+    if (!MGCG_HIP(hipMalloc((void**)&d2, 2 * sizeof(int)))) return false;
+    int h2[2] = { 0, (int)n };
+    bool ok = MGCG_HIP(hipMemcpyAsync(d2, h2, sizeof(h2), hipMemcpyHostToDevice, s));
+    if (ok) launch_halo_rows(s, rowOffsets, columnIndeces, n, offset, d2);
+    ok = ok && MGCG_HIP(hipMemcpyAsync(h2, d2, sizeof(h2), hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
+    (void)hipFree(d2);
+    if (!ok) return false;
+    const long long lo = h2[0], hi = h2[1] < n ? h2[1] : n;
+    if (hi > lo && (mode == 2 || 2 * (hi - lo) >= n) && halo_overlap_available(comm)) { *active = true; *i0 = lo; *i1 = hi; }
+    return true;
+}
+
 static bool mg_halo(MgcgMg* mg, MgLevel& L, double* xfull)
 {
     if (mg->nranks == 1) return true;
     return halo_exchange(mg->comm, L.halo, xfull, mg->stream);
 }
 
+// Halo of the full-length iterate a.x, then the SpMV-shaped pass; interior rows first when the level overlaps.
+static bool mg_spmv(MgcgMg* mg, MgLevel& L, int epilogue, const SpmvArgs& a, double* xfull)
+{
+    hipStream_t s = mg->stream;
+    if (!L.overlap) {
+        if (!mg_halo(mg, L, xfull)) return false;
+        launch_spmv_auto(s, epilogue, a, L.cfg, L.dcsr);
+        return true;
+    }
+    if (!halo_overlap_ready(mg->comm, s)) return false;
+    launch_spmv_range(s, epilogue, a, L.cfg, L.dcsr, L.interior0, L.interior1, nullptr, 0);
+    if (!halo_overlap_run(mg->comm, L.halo, xfull)) return false;
+    if (!halo_overlap_wait(mg->comm, s)) return false;
+    launch_spmv_range(s, epilogue, a, L.cfg, L.dcsr, 0, L.interior0, nullptr, 0);
+    launch_spmv_range(s, epilogue, a, L.cfg, L.dcsr, L.interior1, L.n, nullptr, 0);
+    return true;
+}
+
 // xout_loc = xin_loc + omega * (dinv * (b - A xin)); xin / xout are full-length buffers
 static bool mg_jacobi(MgcgMg* mg, MgLevel& L, const double* b, double* xin, double* xout, const int* done)
 {
-    if (!mg_halo(mg, L, xin)) return false;
     SpmvArgs a{};
     a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = xin; a.y = xout + L.offset;
     a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal;
     a.w = xin + L.offset; a.b = b; a.dinv = L.dinv; a.omega = mg->omega; a.doneFlag = done;
-    launch_spmv_auto(mg->stream, EPI_JACOBI, a, L.cfg, L.dcsr);
-    return true;
+    return mg_spmv(mg, L, EPI_JACOBI, a, xin);
 }
 
 // `sweeps` Jacobi sweeps on level L for right-hand side b.  first: the first sweep starts from zero.
@@ -96,11 +136,10 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
     double* cur = nullptr;
     if (!mg_smooth(mg, L, b, x0, x1, mg->nu, true, done, &cur)) return false;
     double* other = (cur == x0) ? x1 : x0;
-    if (!mg_halo(mg, L, cur)) return false;
     SpmvArgs a{};
     a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = cur; a.y = L.r;
     a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal; a.b = b; a.doneFlag = done;
-    launch_spmv_auto(mg->stream, EPI_RESIDUAL, a, L.cfg, L.dcsr);                             // r = b - A x
+    if (!mg_spmv(mg, L, EPI_RESIDUAL, a, cur)) return false;                                  // r = b - A x
     launch_restrict(mg->stream, L.nx, L.ny, L.z1 - L.z0, L.r, C.b, done);                     // b_c = P^T r (slab-local)
     double* e = nullptr;
     if (!mg_vcycle(mg, l + 1, C.b, C.xa, C.xb, done, &e)) return false;
@@ -145,7 +184,20 @@ struct CgRun {
     SpmvProfile* prof = nullptr;
     const DcsrMatrix* dcsr = nullptr;      // compressed form of the matrix if the handle has one
     MgcgSparse* cusparse = nullptr;
+    // rows [interior0, interior1) reference local columns only: they are multiplied while the halo of p is in flight
+    bool overlap = false;
+    long long interior0 = 0, interior1 = 0;
 };
+
+static thread_local long long t_lastOverlap[3] = { 0, 0, 0 };
+
+static bool cg_plan_overlap(CgRun& R)
+{
+    t_lastOverlap[0] = 0;
+    if (!plan_overlap(R.ws->stream, R.comm, R.nranks, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.overlap, &R.interior0, &R.interior1)) return false;
+    if (R.overlap) { t_lastOverlap[0] = 1; t_lastOverlap[1] = R.interior0; t_lastOverlap[2] = R.interior1; }
+    return true;
+}
 
 static void prof_mark(CgRun& R, bool begin)
 {
@@ -209,14 +261,27 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
     CgScalars* sc = R.ws->scalars;
     double* pLoc = R.p + R.offset;
     const int* done = &sc->done;
-    if (!halo_exchange(R.comm, R.halo, R.p, s)) return false;                        // SyncP  (:469)
     SpmvArgs a{};
     a.elements = R.elements; a.rowOffsets = R.rowOffsets; a.columnIndeces = R.columnIndeces; a.x = R.p; a.y = R.Ap;
     a.elementsCount = R.elementsCount; a.rowCount = (int)R.nLocal; a.columnCount = (int)R.count;
     a.w = pLoc; a.partials = R.ws->partials; a.doneFlag = done;
-    prof_mark(R, true);
-    int n = launch_spmv_auto(s, EPI_DOT, a, R.cfg, R.dcsr);                          // Ap = A p ; p.Ap   (Mgcg.cu:244-245)
-    prof_mark(R, false);
+    int n;
+    if (R.overlap) {
+        // SyncP (:469) on the communicator's stream; interior rows meanwhile, boundary rows once the halo is in
+        if (!halo_overlap_ready(R.comm, s)) return false;
+        prof_mark(R, true);
+        n = launch_spmv_range(s, EPI_DOT, a, R.cfg, R.dcsr, R.interior0, R.interior1, R.ws->partials, kMaxPartials / 2);
+        if (!halo_overlap_run(R.comm, R.halo, R.p)) return false;
+        if (!halo_overlap_wait(R.comm, s)) return false;
+        n += launch_spmv_range(s, EPI_DOT, a, R.cfg, R.dcsr, 0, R.interior0, R.ws->partials + n, kMaxPartials / 4);
+        n += launch_spmv_range(s, EPI_DOT, a, R.cfg, R.dcsr, R.interior1, R.nLocal, R.ws->partials + n, kMaxPartials / 4);
+        prof_mark(R, false);
+    } else {
+        if (!halo_exchange(R.comm, R.halo, R.p, s)) return false;                    // SyncP  (:469)
+        prof_mark(R, true);
+        n = launch_spmv_auto(s, EPI_DOT, a, R.cfg, R.dcsr);                          // Ap = A p ; p.Ap   (Mgcg.cu:244-245)
+        prof_mark(R, false);
+    }
     launch_reduce_to(s, R.ws->partials, n, &sc->pAp, done);
     if (R.nranks > 1 && !comm_allreduce_sum(R.comm, &sc->pAp, 1, s)) return false;   // (:499)
     double* pInf = R.wantInf ? R.ws->partials + kMaxPartials : nullptr;
@@ -382,6 +447,7 @@ int SolveParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMa
     if (R.nranks > 1) {
         R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ);
         if (!R.halo) return MGCG_ERROR;
+        if (!cg_plan_overlap(R)) { halo_plan_destroy(R.halo); return MGCG_ERROR; }
     }
     const int st = cg_solve(R, iteration, residual, residualTrace, traceCapacity);
     if (R.halo) halo_plan_destroy(R.halo);
@@ -406,7 +472,7 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     double* savedTrace = R.ws->trace; const int savedCap = R.ws->traceCap;
     R.ws->trace = nullptr; R.ws->traceCap = 0;
     bool ok = true;
-    if (R.nranks > 1) { R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ); ok = R.halo != nullptr; }
+    if (R.nranks > 1) { R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ); ok = R.halo != nullptr && cg_plan_overlap(R); }
     R.dcsr = dcsr_lookup(cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset);
     if (ok && restart) ok = cg_enqueue_init(R);
     else if (ok) hipLaunchKernelGGL(clear_done_kernel, dim3(1), dim3(1), 0, R.ws->stream, R.ws->scalars);
@@ -416,6 +482,12 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     if (R.halo) halo_plan_destroy(R.halo);
     R.ws->trace = savedTrace; R.ws->traceCap = savedCap;
     return ok ? (double)R.ws->mirror->residual : NAN;
+}
+
+int MgcgLastOverlap(long long interior[2])
+{
+    if (interior) { interior[0] = t_lastOverlap[1]; interior[1] = t_lastOverlap[2]; }
+    return (int)t_lastOverlap[0];
 }
 
 void MgcgProfileSpmv(MgcgSparse* h, int enable)
@@ -532,6 +604,7 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
             ok = ok && MGCG_HIP(hipStreamSynchronize(s));
             L.minJ = out[0]; L.maxJ = out[1];
             if (ok) { L.halo = halo_plan_create(comm, L.nGlobal, L.offset, L.n, L.minJ, L.maxJ); ok = L.halo != nullptr; }
+            ok = ok && plan_overlap(s, comm, nranks, L.rowOffsets, L.columnIndeces, L.n, L.offset, &L.overlap, &L.interior0, &L.interior1);
         }
         mg->lv.push_back(L);
         mg->levels = (int)mg->lv.size();
@@ -622,6 +695,7 @@ int SolveMgParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, Mgcg
     if (R.nranks > 1) {
         R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ);
         if (!R.halo) return MGCG_ERROR;
+        if (!cg_plan_overlap(R)) { halo_plan_destroy(R.halo); return MGCG_ERROR; }
     }
     const int st = cg_solve(R, iteration, residual, residualTrace, traceCapacity);
     if (R.halo) halo_plan_destroy(R.halo);

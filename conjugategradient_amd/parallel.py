@@ -229,6 +229,13 @@ class ConjugateGradientRankGpu(ConjugateGradientGpu):
             check("SolveParallel")
             raise MgcgError(f"SolveParallel failed with status {st}")
 
+    @staticmethod
+    def LastOverlap():
+        """(active, first interior row, end of interior rows) of the calling thread's last multi-rank solve."""
+        rng = (C.c_longlong * 2)(0, 0)
+        active = lib().MgcgLastOverlap(rng)
+        return bool(active), int(rng[0]), int(rng[1])
+
     def Steps(self, steps: int, restart: bool = True) -> float:
         """``steps`` CG iterations with no stop test and no host sync inside (bench.py)."""
         self._ensure_comm()

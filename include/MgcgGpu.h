@@ -334,6 +334,12 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
                int count, int countForDevice, int offsetForDevice, int elementsCountForDevice,
                int minJ, int maxJ, int steps, int restart);
 
+/* How the last multi-rank solve on the calling thread scheduled its halo: returns 1 and the local row range
+ * [interior[0], interior[1]) that was multiplied while the halo of p travelled on the communicator's own stream
+ * (rows outside it wait for the halo), or 0 when the exchange ran in line (single rank, MGCG_OVERLAP=0, or the
+ * slice has too few rows that reference local columns only).  interior may be NULL. */
+int MgcgLastOverlap(long long interior[2]);
+
 #ifdef __cplusplus
 }
 #endif

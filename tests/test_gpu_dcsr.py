@@ -111,6 +111,7 @@ def test_compressed_multirank(oracle, monkeypatch):
 
     world = 2
     monkeypatch.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    monkeypatch.setenv("MGCG_OVERLAP", "2")              # compressed interior / boundary row ranges while the halo travels
     s = problems.poisson(8, 8, 16)
     s.b[:] = np.random.default_rng(3).standard_normal(s.Count)
     ref = oracle.Multigrid(s).pcg(rule=oracle.RULE_CSHARP, max_iteration=400)

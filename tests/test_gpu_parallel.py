@@ -124,15 +124,24 @@ def _run_ranks_in_threads(world, make_rank):
     return results
 
 
-@pytest.mark.parametrize("world,which", [(2, "banded"), (4, "banded"), (3, "poisson"), (2, "unstructured")])
-def test_native_multirank_loop_over_loopback(oracle, monkeypatch, world, which):
+@pytest.mark.parametrize("overlap", ["0", "2", None])
+@pytest.mark.parametrize("world,which", [(2, "banded"), (4, "banded"), (3, "poisson"), (2, "poisson32"), (2, "unstructured")])
+def test_native_multirank_loop_over_loopback(oracle, monkeypatch, world, which, overlap):
     """SolveParallel with N > 1: partition, halo plan + exchange, all-reduced dot products and the per-chunk stop
-    decision, against the multi-device oracle (ConjugateGradientParallelGpu.cs:424-565 restated)."""
+    decision, against the multi-device oracle (ConjugateGradientParallelGpu.cs:424-565 restated).
+    overlap: MGCG_OVERLAP -- "0" halo then SpMV on one stream, "2" interior rows multiplied while the halo travels on the
+    communicator's stream whenever a slice has interior rows, None the library's own choice (on for poisson32)."""
     monkeypatch.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    if overlap is None:
+        monkeypatch.delenv("MGCG_OVERLAP", raising=False)
+    else:
+        monkeypatch.setenv("MGCG_OVERLAP", overlap)
     if which == "banded":
         s = problems.mgcg_main(2403, 160)
     elif which == "poisson":
         s = problems.poisson(12, 10, 9)
+    elif which == "poisson32":
+        s = problems.poisson(32, 32, 16)
     else:
         s = problems.random_spd(1500, mean_upper=6.0, seed=21)
         s.b[:] = np.cos(np.arange(s.Count) * 0.7) * (1.0 + np.arange(s.Count) % 5)     # (b = A.1 would converge at once)
@@ -146,6 +155,14 @@ def test_native_multirank_loop_over_loopback(oracle, monkeypatch, world, which):
         lo, hi = oracle.minmax_column(s, cg.part.offset, cg.part.offset + cg.part.count)
         assert (cg.part.minJ, cg.part.maxJ) == (lo, hi)
         cg.Solve(trace=True)
+        active, i0, i1 = cg.LastOverlap()
+        if which == "unstructured" or overlap == "0" or (overlap is None and which != "poisson32"):
+            assert not active
+        else:
+            assert active and 0 <= i0 < i1 <= cg.part.count
+            if which in ("poisson", "poisson32"):       # interior = the slab minus the planes that touch a neighbour
+                plane = s.grid[0] * s.grid[1]
+                assert i0 == (plane if rank > 0 else 0) and i1 == cg.part.count - (plane if rank < world - 1 else 0)
         cg.Read()
         out = (cg.part.offset, cg.part.count, cg.x[cg.part.offset: cg.part.offset + cg.part.count].copy(), cg.Iteration, cg.Residual, cg.trace)
         cg.Dispose()
@@ -172,6 +189,7 @@ def test_distributed_multigrid_over_loopback(oracle, monkeypatch, world, dims, l
     from tests.gpu_util import assert_trace_close
 
     monkeypatch.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    monkeypatch.setenv("MGCG_OVERLAP", "2")
     s = problems.poisson(*dims)
     rng = np.random.default_rng(3)
     s.b[:] = rng.standard_normal(s.Count)
