@@ -82,7 +82,38 @@ class ComputerGpu:
 
 
 class ConjugateGradientCLGpu(ConjugateGradientSingleGpu):
-    """HandmadeCL front-end: same class surface as ConjugateGradientSingleGpu, Residual = max|r_i|."""
+    """HandmadeCL front-end: same class surface as ConjugateGradientSingleGpu, Residual = max|r_i|.
+    ``A`` is the slot-0-diagonal ELL builder of that family (``cg.A[i, j] = v`` as in MgcgCLMain.cs:52-83) unless a CSR
+    system was handed over with ``load``; ``Initialize`` packs it to CSR in stored order (the device sums a row in the
+    order the reference's ``Matrix_x_Vector`` walks its slots, Mgcg.cl:171-216)."""
 
     def __init__(self, count, maxNonZeroCount, _minIteration, _maxIteration, allowableResidual):
         super().__init__(count, maxNonZeroCount, _minIteration, _maxIteration, allowableResidual, rule=_lib.RULE_HANDMADECL)
+        from .formats import EllSparseMatrix
+
+        self.A = EllSparseMatrix(count, maxNonZeroCount)
+
+    def Initialize(self):
+        from .formats import EllSparseMatrix
+        from .solver import SparseMatrix
+
+        if isinstance(self.A, EllSparseMatrix):
+            ell = self.A
+            csr = SparseMatrix.__new__(SparseMatrix)
+            csr.Elements, csr.ColumnIndeces, csr.RowOffsets = ell.to_csr()
+            self.A = csr
+            try:
+                super().Initialize()
+            finally:
+                self._csr, self.A = csr, ell
+        else:
+            self._csr = self.A
+            super().Initialize()
+
+    def Solve(self, trace: bool = False):
+        held = self.A
+        self.A = self._csr
+        try:
+            super().Solve(trace=trace)
+        finally:
+            self.A = held

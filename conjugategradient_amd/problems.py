@@ -85,8 +85,16 @@ def mgcg_main(count: int = 34567 * 6, max_nonzero: int = 160, x0_div: float = 10
     """
     half = max_nonzero // 2
     i = np.arange(count, dtype=np.int64)
-    jlo = np.maximum(0, i - half + 1)
-    jhi = np.minimum(count, i + half)
+    val, col, ro = _sin_band(count, np.maximum(0, i - half + 1), np.minimum(count, i + half), np.zeros(count))
+    b = np.cos(i.astype(np.float64)) * 10.0
+    x0 = i.astype(np.float64) / x0_div
+    return LinearSystem(val, col, ro, x0, b, f"mgcgmain{count}")
+
+
+def _sin_band(count: int, jlo: np.ndarray, jhi: np.ndarray, diag0: np.ndarray):
+    """Rows ``i`` with the diagonal FIRST, then every ``j in [jlo_i, jhi_i)``, ``j != i`` ascending, ``a_ij = |sin(i+j)|``;
+    diagonal = ``diag0_i`` plus the row's off-diagonals added left to right (MgcgMain.cs:79, MgcgCL.cs:33-40)."""
+    i = np.arange(count, dtype=np.int64)
     cnt = jhi - jlo  # includes the diagonal's own slot (moved to the front)
     ro = np.zeros(count + 1, dtype=np.int64)
     np.cumsum(cnt, out=ro[1:])
@@ -94,23 +102,28 @@ def mgcg_main(count: int = 34567 * 6, max_nonzero: int = 160, x0_div: float = 10
     row = np.repeat(i, cnt)
     k = np.arange(nnz, dtype=np.int64) - np.repeat(ro[:-1], cnt)  # position within row
     # position 0 -> diagonal; position q>=1 -> q-th off-diagonal in ascending j
-    off_rank = k - 1
-    j = np.repeat(jlo, cnt) + off_rank
+    j = np.repeat(jlo, cnt) + (k - 1)
     j = np.where(j >= row, j + 1, j)  # skip the diagonal
     col = np.where(k == 0, row, j).astype(np.int32)
     val = np.abs(np.sin((row + col).astype(np.float64)))
     val[ro[:-1]] = 0.0
-    # diagonal = left-to-right sum of the off-diagonals (MgcgMain.cs:79)
-    diag = np.zeros(count)
-    maxw = int(cnt.max()) - 1
-    for q in range(maxw):
+    diag = np.array(diag0, dtype=np.float64)
+    for q in range(int(cnt.max()) - 1):
         sel = (cnt - 1) > q
         idx = ro[:-1][sel] + 1 + q
         diag[sel] = diag[sel] + val[idx]
     val[ro[:-1]] = diag
-    b = np.cos(i.astype(np.float64)) * 10.0
-    x0 = i.astype(np.float64) / x0_div
-    return LinearSystem(val, col, ro.astype(np.int32), x0, b, f"mgcgmain{count}")
+    return val, col, ro.astype(np.int32)
+
+
+def viennacl_main(n: int = 34567 * 5, band_width: int = 160) -> LinearSystem:
+    """The driver system of Mgcg/ViennaCL/MgcgCL/MgcgCL.cs:14-61: ``A[i,i] = i`` is assigned first (so the dictionary row
+    starts with the diagonal), then ``j in [max(0, i-band/2), min(N-1, i+band/2)]`` INCLUSIVE, ``j != i`` ascending with
+    ``a_ij = |sin(i+j)|`` added onto the diagonal; ``b_i = asin(i/N)``, ``x0 = 0``; solved to 1e-4 RELATIVE."""
+    half = band_width // 2
+    i = np.arange(n, dtype=np.int64)
+    val, col, ro = _sin_band(n, np.maximum(0, i - half), np.minimum(n - 1, i + half) + 1, i.astype(np.float64))
+    return LinearSystem(val, col, ro, np.zeros(n), np.arcsin(i.astype(np.float64) / n), f"viennaclmain{n}")
 
 
 def poisson(nx: int, ny: int, nz: int = 1) -> LinearSystem:

@@ -207,3 +207,55 @@ def test_other_front_ends(oracle):
     assert abs(cl.Residual - ref["residual"]) <= 1e-3 * ref["residual"] + 1e-12      # round-off level max-norm after 50 forced iterations
     assert np.abs(cl.x - ref["x"]).max() <= 1e-9 * np.abs(ref["x"]).max()
     cl.Dispose()
+
+
+def test_front_ends_driven_from_their_own_builders(oracle):
+    """Row f1: the HandmadeCL ELL indexer and the ViennaCL dictionary-of-rows, filled like the reference drivers fill them,
+    flattened in stored order and solved on the device; the oracle solves the flattened CSR."""
+    from conjugategradient_amd.formats import CompressedMatrix
+    from conjugategradient_amd.frontends import ComputerGpu, ConjugateGradientCLGpu
+
+    n, K = 400, 160
+    cl = ConjugateGradientCLGpu(n, K, 50, n, 1e-4)
+    for i in range(n):                                                   # MgcgCLMain.cs:52-90
+        cl.A[i, i] = 0
+        for j in range(max(0, i - K // 2 + 1), min(n, i + K // 2)):
+            if i != j:
+                a = abs(np.sin(float(i + j)))
+                cl.A[i, j] = a
+                cl.A[i, i] = cl.A[i, i] + a
+        cl.b[i] = np.cos(float(i)) * 10
+        cl.x[i] = i / 100.0
+    s = problems.mgcg_main(n, K)
+    e, c, ro = cl.A.to_csr()
+    assert np.array_equal(e, s.Elements) and np.array_equal(c, s.ColumnIndeces) and np.array_equal(ro, s.RowOffsets)
+    ref = oracle.cg(s, rule=oracle.RULE_HANDMADECL, allowable_residual=1e-4, min_iteration=50, max_iteration=n)
+    cl.Initialize()
+    cl.Solve()
+    cl.Read()
+    assert cl.Iteration == ref["iteration"]
+    assert np.abs(cl.x - ref["x"]).max() <= 1e-9 * np.abs(ref["x"]).max()
+    cl.Dispose()
+
+    A = CompressedMatrix()
+    b = np.zeros(n)
+    for i in range(n):                                                   # MgcgCL.cs:31-45
+        A[i, i] = i
+        for j in range(max(0, i - K // 2), min(n - 1, i + K // 2) + 1):
+            if i != j:
+                a = abs(np.sin(float(i + j)))
+                A[i, j] = a
+                A[i, i] = A[i, i] + a
+        b[i] = np.arcsin(i / n)
+    v = problems.viennacl_main(n, K)
+    e, c, ro = A.to_csr()
+    assert np.array_equal(e, v.Elements) and np.array_equal(c, v.ColumnIndeces) and np.array_equal(b, v.b)
+    ref = oracle.cg(v, rule=oracle.RULE_VIENNACL, allowable_residual=1e-4, min_iteration=0, max_iteration=n, hard_cap=n + 10)
+    gpu = ComputerGpu(n)
+    gpu.Write(e, ro, c, np.zeros(n), b)
+    gpu.Solve(1e-4, 0, n)
+    x = np.zeros(n)
+    gpu.Read(x)
+    assert gpu.Iteration() == ref["iteration"] + 1
+    assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
+    gpu.Dispose()
