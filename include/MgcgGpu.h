@@ -334,6 +334,17 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
                int count, int countForDevice, int offsetForDevice, int elementsCountForDevice,
                int minJ, int maxJ, int steps, int restart);
 
+/* Extreme eigenvalues by `steps` Lanczos steps on the device (SpMV + dot kernels of the CG path): of A, or with
+ * jacobiScaled != 0 of D^-1/2 A D^-1/2 (the spectrum of D^-1 A, what the Jacobi smoother's damping depends on).
+ * Scalable counterpart of the reference's dense Jacobi-rotation GetEigenValues
+ * (Mgcg/HandmadeCL/MgcgCL/SparseMatrix.cs:234-372).  Ritz values lie inside the spectrum: lambdaMax is approached
+ * from below, lambdaMin from above.  ritz (optional) receives the *stepsDone Ritz values in ascending order (room for
+ * `steps`).  The start vector is a fixed function of `seed`.  Returns MGCG_OK or MGCG_ERROR. */
+int MgcgEstimateSpectrum(MgcgBlas* cublas, MgcgSparse* cusparse,
+                         Vector* elementsVector, VectorInt* rowOffsetsVector, VectorInt* columnIndecesVector,
+                         int elementsCount, int count, int jacobiScaled, int steps, unsigned seed,
+                         double* lambdaMin, double* lambdaMax, double ritz[], int* stepsDone);
+
 /* How the last multi-rank solve on the calling thread scheduled its halo: returns 1 and the local row range
  * [interior[0], interior[1]) that was multiplied while the halo of p travelled on the communicator's own stream
  * (rows outside it wait for the halo), or 0 when the exchange ran in line (single rank, MGCG_OVERLAP=0, or the

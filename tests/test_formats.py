@@ -92,3 +92,16 @@ def test_dictionary_rows_appear_on_first_assignment():
     A[2, 1] = 5.0
     e, c, ro = A.to_csr(4)
     assert ro.tolist() == [0, 0, 0, 1, 1] and e.tolist() == [5.0] and c.tolist() == [1]
+
+
+def test_dense_jacobi_rotation_eigenvalues_match_lapack():
+    """GetEigenValues (HandmadeCL SparseMatrix.cs:234-372) restated on the host, against numpy's symmetric solver."""
+    from conjugategradient_amd.spectrum import GetEigenValues, jacobi_omega
+
+    s = problems.mgcg_main(24, 10)
+    A = EllSparseMatrix.from_csr(s.Elements, s.ColumnIndeces, s.RowOffsets)
+    ev = np.sort(GetEigenValues(A, 10_000, 1e-12))
+    ref = np.linalg.eigvalsh(s.to_scipy().toarray())
+    assert np.abs(ev - ref).max() <= 1e-10 * np.abs(ref).max()
+    assert np.array_equal(GetEigenValues(A, 0, 1e-12), s.Elements[s.RowOffsets[:-1]])     # no rotation: the diagonal
+    assert jacobi_omega(2.0, 3) == pytest.approx(6 / 7) and jacobi_omega(2.0, 2) == pytest.approx(4 / 5) and jacobi_omega(2.0) == pytest.approx(2 / 3)
