@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--variants", default="")
+    ap.add_argument("--extra-grids", default="", help="comma list of grid sizes to add as 'dcsr gN' and 'rows gN' variants")
+    ap.add_argument("--only-ablations", default="", help="comma list of ablation codes to keep (default all)")
     ap.add_argument("--ablate", action="store_true", help="also time diagnostic ablations (no y store / gathers from L1)")
     a = ap.parse_args()
     L = _lib.lib()
@@ -44,11 +46,15 @@ def main():
                 ("wave R64 band", 1, 64, 4, 0, 0, 0), ("wave R32 band", 1, 32, 4, 0, 0, 0), ("wave R32 band 8Lx8", 1, 32, 4, 0, 8 * n, 8),
                 ("wg256 band 64Lx1", 1, 128, 4, 0, 64 * n, 1), ("vector 4 lanes", 4, 128, 0, 0, 0, 0),
                 ("rows", 9, 64, 0, 0, 0, 0), ("rows g2048", 9, 64, 0, 2048, 0, 0), ("rows g5120", 9, 64, 0, 5120, 0, 0), ("DOT rows", 9, 64, 0, 0, 0, 0),
-                ("dcsr", 1, 64, 0, 0, 0, 0), ("dcsr g2048", 1, 64, 0, 2048, 0, 0), ("dcsr g8192", 1, 64, 0, 8192, 0, 0), ("DOT dcsr", 1, 64, 0, 0, 0, 0),
+                ("dcsr", 1, 64, 0, 0, 0, 0), ("dcsr g2048", 1, 64, 0, 2048, 0, 0), ("dcsr g8192", 1, 64, 0, 8192, 0, 0), ("dcsr g5120", 1, 64, 0, 5120, 0, 0), ("dcsr g6144", 1, 64, 0, 6144, 0, 0), ("DOT dcsr", 1, 64, 0, 0, 0, 0),
                 ("DOT wave R64 g4096", 1, 64, 0, 4096, 0, 0), ("DOT wave R64 band", 1, 64, 4, 0, 0, 0), ("DOT wg256 R128", 1, 128, 0, 0, 0, 0)]
     if a.variants:
         keep = set(a.variants.split(","))
         variants = [v for v in variants if v[0] in keep]
+    for g in [int(t) for t in a.extra_grids.split(",") if t]:
+        variants.append((f"dcsr g{g}", 1, 64, 0, g, 0, 0))
+        variants.append((f"rows g{g}", 9, 64, 0, g, 0, 0))
+    variants = list({v[0]: v for v in variants}.values())
     ev0, ev1 = L.MgcgEventCreate(), L.MgcgEventCreate()
     times = {v[0]: [] for v in variants}
 
@@ -69,8 +75,10 @@ def main():
         return L.MgcgEventElapsedMs(ev0, ev1) / a.reps
 
     if a.ablate:
-        base = [v for v in variants if v[0] in ("wg256 R128", "wave R64 g4096", "wave R64 band", "wg256 band 64Lx1", "wave R64 g4096 nt", "dcsr", "rows")]
-        for ab, tag in ((1, "no y store"), (2, "gathers from L1"), (3, "no store + L1 gathers"), (8, "y store confined to 512 KB")):
+        base = [v for v in variants if v[0] in ("wg256 R128", "wave R64 g4096", "wave R64 band", "wg256 band 64Lx1", "wave R64 g4096 nt", "dcsr", "rows") or v[0].startswith(("rows g", "dcsr g"))]
+        for ab, tag in ((1, "no y store"), (2, "gathers from L1"), (3, "no store + L1 gathers"), (8, "y store confined to 512 KB"), (32, "chunked")):
+            if a.only_ablations and str(ab) not in a.only_ablations.split(","):
+                continue
             for v in base:
                 variants.append((v[0] + " | " + tag,) + tuple(v[1:]) + (ab,))
         times = {v[0]: [] for v in variants}
