@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--rel-tol", type=float, default=1e-8, help="stop at ||r||_2 < rel_tol * ||b||_2 (b = 1)")
     ap.add_argument("--max-it", type=int, default=20000)
     ap.add_argument("--skip-cg", action="store_true")
+    ap.add_argument("--compression", action="store_true", help="MgcgSetMatrixCompression(1): lossless dictionary form of every level")
     a = ap.parse_args()
     L = _lib.lib()
     _lib.require_gpu()
@@ -32,6 +33,8 @@ def main():
     out = {"grid": n, "rows": N, "abs_tol": tol, "levels": a.levels, "nu": a.nu, "nu_coarse": a.nu_coarse}
 
     mg = ConjugateGradientMgGpu(N, 7, 0, a.max_it, tol, (n, n, n), levels=a.levels, nu=a.nu, nuCoarse=a.nu_coarse, rule=_lib.RULE_CSHARP)
+    L.MgcgSetMatrixCompression(mg.cusparse, 1 if a.compression else 0)
+    out["compression"] = bool(a.compression)
     t0 = time.perf_counter()
     mg.InitializePoisson()
     L.MgcgDeviceSynchronize()
@@ -45,6 +48,7 @@ def main():
 
     if not a.skip_cg:
         cg = ConjugateGradientRankGpu(N, 7, 0, a.max_it, tol, rank=0, world=1, rule=_lib.RULE_CSHARP)
+        L.MgcgSetMatrixCompression(cg.cusparse, 1 if a.compression else 0)
         cg.InitializePoisson(n, n, n)
         L.MgcgDeviceSynchronize()
         t0 = time.perf_counter()
