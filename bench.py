@@ -74,16 +74,45 @@ def cpu_baseline(n: int, iters: int):
     x, b, work = np.zeros(N), np.ones(N), np.empty(3 * N)
     res = C.c_double(0)
     # init (r = b - A x, p = r, rr) is outside the per-iteration figure, as on the GPU side
+    L.oracle_cg_steps(e, c, r, N, x, b, 0, C.byref(res), work)      # first touch of the work arrays
     t0 = time.perf_counter()
     L.oracle_cg_steps(e, c, r, N, x, b, 0, C.byref(res), work)
     t_init = time.perf_counter() - t0
     x[:] = 0
     t0 = time.perf_counter()
     L.oracle_cg_steps(e, c, r, N, x, b, iters, C.byref(res), work)
-    dt = time.perf_counter() - t0 - t_init
-    its = iters / max(dt, 1e-9)
+    dt = max(time.perf_counter() - t0 - t_init, 1e-9)
+    its = iters / dt
     scale = (grid / n) ** 3     # report in units of the full-size workload
+    allcores = None
+    try:                        # second figure: the same loop on all host cores (OpenMP) -- NOT the reference's behaviour
+        omp_path = os.path.join(ROOT, "oracle", "liboracle_omp.so")
+        if not os.path.exists(omp_path):
+            import subprocess
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle_omp.so"])
+        M = C.CDLL(omp_path)
+        dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+        ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+        M.oracle_cg_steps_omp.argtypes = [dp, ip, ip, C.c_int64, dp, dp, C.c_int, C.POINTER(C.c_double), dp]
+        M.oracle_omp_threads.restype = C.c_int
+        res2 = C.c_double(0)
+        x[:] = 0
+        M.oracle_cg_steps_omp(e, c, r, N, x, b, 0, C.byref(res2), work)
+        t0 = time.perf_counter()
+        M.oracle_cg_steps_omp(e, c, r, N, x, b, 0, C.byref(res2), work)
+        t_init2 = time.perf_counter() - t0
+        x[:] = 0
+        omp_iters = 4 * iters
+        t0 = time.perf_counter()
+        M.oracle_cg_steps_omp(e, c, r, N, x, b, omp_iters, C.byref(res2), work)
+        dt2 = max(time.perf_counter() - t0 - t_init2, 1e-9)
+        allcores = {"value": omp_iters / max(dt2, 1e-9) * scale, "unit": "iterations/s", "cores": int(M.oracle_omp_threads()),
+                    "kind": "port, OpenMP all host cores -- not the reference's behaviour (its CPU loops are serial)",
+                    "sample": f"{omp_iters} iterations on 7-pt Poisson {grid}^3", "seconds_per_iteration": dt2 / omp_iters}
+    except Exception as ex:     # noqa: BLE001 -- the second figure is optional
+        allcores = {"error": str(ex)}
     return {
+        "all_cores_variant": allcores,
         "value": its * scale,
         "unit": "iterations/s",
         "cores": 1,
@@ -177,6 +206,7 @@ def main():
 
     # the plain-CSR kernel on the same matrix, timed in the same process (what the north star's 70 % target is about)
     csr_ms = 0.0
+    read_gbps = copy_gbps = 0.0
     if world == 1 and a.solver == "cg":
         L.MgcgSetMatrixCompression(cg.cusparse, 0)
         ev0, ev1 = L.MgcgEventCreate(), L.MgcgEventCreate()
@@ -189,6 +219,20 @@ def main():
         L.MgcgEventRecord(ev1)
         csr_ms = L.MgcgEventElapsedMs(ev0, ev1) / 20
         L.MgcgSetMatrixCompression(cg.cusparse, 0 if a.no_compression else 1)
+        # what this box streams ("% of attainable" next to "% of spec"): read-only = Dot over two vectors,
+        # copy = the library's Copy export (device-to-device), on the same 1 GiB vectors
+        pr, pa = cg.vectorR.ToRawPtr(), cg.vectorAp.ToRawPtr()
+        L.Dot(cg.cublas, pa, pr, rows_local)
+        L.MgcgEventRecord(ev0)
+        for _ in range(10):
+            L.Dot(cg.cublas, pa, pr, rows_local)
+        L.MgcgEventRecord(ev1)
+        read_gbps = 16 * rows_local / (L.MgcgEventElapsedMs(ev0, ev1) / 10 * 1e-3) / 1e9
+        L.MgcgEventRecord(ev0)
+        for _ in range(10):
+            L.Copy(cg.cublas, pa, pr, rows_local, 0, 0)
+        L.MgcgEventRecord(ev1)
+        copy_gbps = 16 * rows_local / (L.MgcgEventElapsedMs(ev0, ev1) / 10 * 1e-3) / 1e9
 
     if dist is not None:
         import torch
@@ -232,6 +276,7 @@ def main():
                                    f"b=1, x0=0, {world} z-slab partition(s)",
                        "rows": N, "nnz": nnz_total, "parallelism": f"row-range dp{world}"},
             "iteration_algorithmic_gbps": iter_bytes / (dt / a.steps) / 1e9,
+            "gflops": (2 * nnz_total + 10 * N) * (a.steps / dt) / 1e9 if a.solver == "cg" else None,
             "residual_after_steps": res,
             "roofline": {"bound": "hbm",
                          "kernel": ("spmv_rows_kernel, SpMV fused with p.Ap, matrix held as " +
@@ -244,7 +289,9 @@ def main():
         if csr_ms > 0:
             out["roofline_csr_spmv"] = {"bound": "hbm", "kernel": "spmv_rows_kernel on the plain CSR arrays (CsrMV export, 20 launches timed with HIP events)",
                                         "achieved": spmv_bytes / (csr_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                        "frac": spmv_bytes / (csr_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "avg_launch_ms": csr_ms}
+                                        "frac": spmv_bytes / (csr_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "avg_launch_ms": csr_ms,
+                                        "measured_read_only_gbps": read_gbps, "measured_copy_gbps": copy_gbps,
+                                        "frac_of_measured_read_only": spmv_bytes / (csr_ms * 1e-3) / 1e9 / read_gbps if read_gbps > 0 else None}
         out["config"]["matrix_format_in_loop"] = "csr" if a.no_compression else "dictionary-compressed csr (lossless, built once by MgcgSetMatrixCompression)"
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, a.cpu_iters)
