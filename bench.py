@@ -53,6 +53,18 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_share() -> int:
+    """Host threads this job may use: the affinity mask, the cgroup quota, and the GPU box's per-GPU share (16)."""
+    share = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            share = min(share, max(1, int(int(quota) / int(period))))
+    except Exception:       # noqa: BLE001 -- no cgroup v2 file: keep the affinity count
+        pass
+    return max(1, min(share, int(os.environ.get("MGCG_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(n: int, iters: int):
     """The CPU oracle (oracle/cg_oracle.c, single thread like the reference's serial C# loops) on the same
     7-point n^3 system; falls back to a smaller grid if host memory is short."""
@@ -95,6 +107,7 @@ def cpu_baseline(n: int, iters: int):
         ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
         M.oracle_cg_steps_omp.argtypes = [dp, ip, ip, C.c_int64, dp, dp, C.c_int, C.POINTER(C.c_double), dp]
         M.oracle_omp_threads.restype = C.c_int
+        M.oracle_omp_set_threads(_cpu_share())
         res2 = C.c_double(0)
         x[:] = 0
         M.oracle_cg_steps_omp(e, c, r, N, x, b, 0, C.byref(res2), work)

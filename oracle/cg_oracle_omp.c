@@ -14,6 +14,7 @@
 #include <omp.h>
 
 int oracle_omp_threads(void) { return omp_get_max_threads(); }
+void oracle_omp_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 
 static void spmv(const double *e, const int *c, const int *ro, int64_t n, double *y, const double *x)
 {
