@@ -139,8 +139,10 @@ enum SpmvEpilogue {
     EPI_RESIDUAL = 2,// y = b - A x
     EPI_JACOBI = 3,  // y = xo + omega*(dinv*(b - A x))
     EPI_RESIDUAL_DOT = 4, // y = b - A x ; partial += y_i*y_i
-    EPI_AXPBY_BETA = 5   // internal: EPI_AXPBY with beta != 0 (reads y)
+    EPI_AXPBY_BETA = 5,  // internal: EPI_AXPBY with beta != 0 (reads y)
+    EPI_JACOBI_DOT = 6   // EPI_JACOBI ; partial += b_i * y_i   (last sweep of the V-cycle: r.z of the PCG loop rides along)
 };
+constexpr bool epi_has_dot(int e) { return e == EPI_DOT || e == EPI_RESIDUAL_DOT || e == EPI_JACOBI_DOT; }
 
 struct SpmvArgs {
     const double* elements;
@@ -156,7 +158,7 @@ struct SpmvArgs {
     const double* b;         // EPI_RESIDUAL / EPI_JACOBI
     const double* dinv;      // EPI_JACOBI
     double omega;            // EPI_JACOBI
-    double* partials;        // EPI_DOT / EPI_RESIDUAL_DOT: one double per workgroup
+    double* partials;        // EPI_DOT / EPI_RESIDUAL_DOT / EPI_JACOBI_DOT: one double per workgroup
     const int* doneFlag;     // optional: exit at once when *doneFlag != 0
     int ablate;              // diagnostics only (tools/spmv_sweep.py --ablate): bit0 skip the y store, bit1 gathers from L1
 };

@@ -32,7 +32,7 @@ __device__ __forceinline__ RowsEpi rows_epi_prefetch(const SpmvArgs& a, long lon
     if constexpr (EPI == EPI_AXPBY_BETA) o.yold = a.y[row];
     if constexpr (EPI == EPI_DOT) o.w = a.w[row];
     if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_DOT) o.b = a.b[row];
-    if constexpr (EPI == EPI_JACOBI) { o.b = a.b[row]; o.dinv = a.dinv[row]; o.w = a.w[row]; }
+    if constexpr (EPI == EPI_JACOBI || EPI == EPI_JACOBI_DOT) { o.b = a.b[row]; o.dinv = a.dinv[row]; o.w = a.w[row]; }
     return o;
 }
 
@@ -44,7 +44,11 @@ __device__ __forceinline__ double rows_epilogue_value(const SpmvArgs& a, double 
     else if constexpr (EPI == EPI_DOT) { double t = o.w * acc; dotacc += t; return acc; }
     else if constexpr (EPI == EPI_RESIDUAL) return o.b - acc;
     else if constexpr (EPI == EPI_RESIDUAL_DOT) { double r = o.b - acc; double t = r * r; dotacc += t; return r; }
-    else { double res = o.b - acc; double t = o.dinv * res; double s = a.omega * t; return o.w + s; }
+    else {
+        double res = o.b - acc; double t = o.dinv * res; double s = a.omega * t; const double v = o.w + s;
+        if constexpr (EPI == EPI_JACOBI_DOT) { double q = o.b * v; dotacc += q; }
+        return v;
+    }
 }
 
 // Raw data of one pass held in registers between the prefetch and the LDS staging.
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(64) void spmv_rows_kernel(SpmvArgs a, DcsrView m, i
         }
         if (pendRow >= 0 && !(a.ablate & 1)) a.y[pendRow] = pendVal;
     }
-    if constexpr (EPI == EPI_DOT || EPI == EPI_RESIDUAL_DOT) {
+    if constexpr (epi_has_dot(EPI)) {
         double v = dotacc;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -268,6 +272,7 @@ int launch_spmv_rows(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrV
     case EPI_RESIDUAL:     return launch_rows_epi<EPI_RESIDUAL>(s, a, m, gridReq);
     case EPI_RESIDUAL_DOT: return launch_rows_epi<EPI_RESIDUAL_DOT>(s, a, m, gridReq);
     case EPI_JACOBI:       return launch_rows_epi<EPI_JACOBI>(s, a, m, gridReq);
+    case EPI_JACOBI_DOT:   return launch_rows_epi<EPI_JACOBI_DOT>(s, a, m, gridReq);
     }
     return 0;
 }

@@ -55,7 +55,7 @@ __device__ __forceinline__ EpiOperands epi_prefetch(const SpmvArgs& a, long long
     if constexpr (EPI == EPI_AXPBY_BETA) o.yold = a.y[row];
     if constexpr (EPI == EPI_DOT) o.w = a.w[row];
     if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_DOT) o.b = a.b[row];
-    if constexpr (EPI == EPI_JACOBI) { o.b = a.b[row]; o.dinv = a.dinv[row]; o.w = a.w[row]; }
+    if constexpr (EPI == EPI_JACOBI || EPI == EPI_JACOBI_DOT) { o.b = a.b[row]; o.dinv = a.dinv[row]; o.w = a.w[row]; }
     return o;
 }
 
@@ -80,11 +80,13 @@ __device__ __forceinline__ double spmv_epilogue_value(const SpmvArgs& a, double 
         double t = r * r;
         dotacc += t;
         return r;
-    } else {   // EPI_JACOBI
+    } else {   // EPI_JACOBI, EPI_JACOBI_DOT
         double res = o.b - acc;
         double t = o.dinv * res;
         double s = a.omega * t;
-        return o.w + s;
+        const double v = o.w + s;
+        if constexpr (EPI == EPI_JACOBI_DOT) { double q = o.b * v; dotacc += q; }
+        return v;
     }
 }
 
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs a, int nRow
         }
         if (pendRow >= 0 && !(a.ablate & 1)) a.y[pendRow] = pendVal;
     }
-    if constexpr (EPI == EPI_DOT || EPI == EPI_RESIDUAL_DOT) {
+    if constexpr (epi_has_dot(EPI)) {
         double t = wave_sum(dotacc);
         if constexpr (BLOCK > 64) {
             if ((tid & 63) == 0) s_red[tid >> 6] = t;
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(kBlock) void spmv_vector_kernel(SpmvArgs a)
         for (int off = LANES / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, LANES);
         if (sub == 0 && row < a.rowCount) { const EpiOperands eo = epi_prefetch<EPI>(a, row); spmv_epilogue<EPI>(a, row, acc, eo, dotacc); }
     }
-    if constexpr (EPI == EPI_DOT || EPI == EPI_RESIDUAL_DOT) {
+    if constexpr (epi_has_dot(EPI)) {
         const double t = block_sum_256(dotacc, s_red);
         if (tid == 0) a.partials[blockIdx.x] = t;
     }
@@ -526,6 +528,7 @@ int launch_spmv(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig
     case EPI_RESIDUAL:     return launch_spmv_epi<EPI_RESIDUAL>(s, a, cfg);
     case EPI_RESIDUAL_DOT: return launch_spmv_epi<EPI_RESIDUAL_DOT>(s, a, cfg);
     case EPI_JACOBI:       return launch_spmv_epi<EPI_JACOBI>(s, a, cfg);
+    case EPI_JACOBI_DOT:   return launch_spmv_epi<EPI_JACOBI_DOT>(s, a, cfg);
     }
     return 0;
 }

@@ -44,6 +44,9 @@ struct MgcgMg {
     hipStream_t stream = nullptr;
     MgcgComm* comm = nullptr;              // not owned
     int nranks = 1;
+    // r.z of the PCG loop rides on the V-cycle's last sweep (single rank): partial sums go here, fusedDotCount of them
+    double* fuseDotPartials = nullptr;
+    int fusedDotCount = 0;
 };
 
 namespace mgcg {
@@ -101,24 +104,30 @@ static bool mg_spmv(MgcgMg* mg, MgLevel& L, int epilogue, const SpmvArgs& a, dou
 }
 
 // xout_loc = xin_loc + omega * (dinv * (b - A xin)); xin / xout are full-length buffers
-static bool mg_jacobi(MgcgMg* mg, MgLevel& L, const double* b, double* xin, double* xout, const int* done)
+static bool mg_jacobi(MgcgMg* mg, MgLevel& L, const double* b, double* xin, double* xout, const int* done, bool withDot = false)
 {
     SpmvArgs a{};
     a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = xin; a.y = xout + L.offset;
     a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal;
     a.w = xin + L.offset; a.b = b; a.dinv = L.dinv; a.omega = mg->omega; a.doneFlag = done;
+    if (withDot && mg->nranks == 1 && mg->fuseDotPartials != nullptr) {          // + partial sums of b . xout
+        a.partials = mg->fuseDotPartials;
+        mg->fusedDotCount = launch_spmv_auto(mg->stream, EPI_JACOBI_DOT, a, L.cfg, L.dcsr);
+        return true;
+    }
     return mg_spmv(mg, L, EPI_JACOBI, a, xin);
 }
 
 // `sweeps` Jacobi sweeps on level L for right-hand side b.  first: the first sweep starts from zero.
 // cur is the buffer holding the iterate (ignored when first); *result receives the buffer holding the result.
-static bool mg_smooth(MgcgMg* mg, MgLevel& L, const double* b, double* cur, double* other, int sweeps, bool first, const int* done, double** result)
+static bool mg_smooth(MgcgMg* mg, MgLevel& L, const double* b, double* cur, double* other, int sweeps, bool first, const int* done, double** result,
+                      bool dotOnLast = false)
 {
     for (int sIdx = 0; sIdx < sweeps; ++sIdx) {
         if (first && sIdx == 0) {
             launch_jacobi_first(mg->stream, L.n, mg->omega, L.dinv, b, cur + L.offset, done);
         } else {
-            if (!mg_jacobi(mg, L, b, cur, other, done)) return false;
+            if (!mg_jacobi(mg, L, b, cur, other, done, dotOnLast && sIdx == sweeps - 1)) return false;
             double* t = cur; cur = other; other = t;
         }
     }
@@ -131,7 +140,7 @@ static bool mg_smooth(MgcgMg* mg, MgLevel& L, const double* b, double* cur, doub
 static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1, const int* done, double** result)
 {
     MgLevel& L = mg->lv[l];
-    if (l == mg->levels - 1) return mg_smooth(mg, L, b, x0, x1, mg->nuCoarse, true, done, result);
+    if (l == mg->levels - 1) return mg_smooth(mg, L, b, x0, x1, mg->nuCoarse, true, done, result, l == 0);
     MgLevel& C = mg->lv[l + 1];
     double* cur = nullptr;
     if (!mg_smooth(mg, L, b, x0, x1, mg->nu, true, done, &cur)) return false;
@@ -144,13 +153,17 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
     double* e = nullptr;
     if (!mg_vcycle(mg, l + 1, C.b, C.xa, C.xb, done, &e)) return false;
     launch_prolong_add(mg->stream, L.nx, L.ny, L.z1 - L.z0, cur + L.offset, e + C.offset, done);   // x += P e (slab-local)
-    return mg_smooth(mg, L, b, cur, other, mg->nu, false, done, result);
+    return mg_smooth(mg, L, b, cur, other, mg->nu, false, done, result, l == 0);
 }
 
 // z = M^-1 r (both local).  A single rank ping-pongs level 0 between z itself and lv[0].xa so that the result
 // lands in z; with several ranks the iterates must be full length, so the result is copied out of lv[0].xa/xb.
-static bool mg_apply(MgcgMg* mg, const double* r, double* z, const int* done)
+// dotPartials (optional, single rank): the last sweep also leaves *nDot partial sums of r . z there (0: not fused,
+// the caller runs the dot product itself).
+static bool mg_apply(MgcgMg* mg, const double* r, double* z, const int* done, double* dotPartials = nullptr, int* nDot = nullptr)
 {
+    mg->fuseDotPartials = dotPartials; mg->fusedDotCount = 0;
+    struct Reset { MgcgMg* m; int* n; ~Reset() { if (n) *n = m->fusedDotCount; m->fuseDotPartials = nullptr; } } reset{ mg, nDot };
     MgLevel& L0 = mg->lv[0];
     double* res = nullptr;
     if (mg->nranks == 1) {
@@ -239,9 +252,10 @@ static bool cg_enqueue_init(CgRun& R)
     launch_spmv_auto(s, EPI_RESIDUAL, a, R.cfg, R.dcsr);                             // r = b - A x   (Mgcg.cu:225-226)
     int n;
     if (R.mg) {
-        if (!mg_apply(R.mg, R.r, R.z, nullptr)) return false;                        // z = M^-1 r
+        int nz = 0;
+        if (!mg_apply(R.mg, R.r, R.z, nullptr, R.nranks == 1 ? R.ws->partials : nullptr, &nz)) return false;   // z = M^-1 r (+ r.z)
         launch_copy(s, pLoc, R.z, R.nLocal);                                         // p = z
-        n = launch_dot_partials(s, R.r, R.z, R.nLocal, R.ws->partials);              // rz = r.z
+        n = nz > 0 ? nz : launch_dot_partials(s, R.r, R.z, R.nLocal, R.ws->partials);   // rz = r.z
     } else {
         n = launch_copy_dot(s, pLoc, R.r, R.nLocal, R.ws->partials, nullptr);        // p = r ; rr = r.r  (Mgcg.cu:227-228)
     }
@@ -298,8 +312,9 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
         launch_finalize(s, R.ws->partials, pInf, n, true, f);                        // residual, stop test, beta  (:251-266)
     }
     if (R.mg) {
-        if (!mg_apply(R.mg, R.r, R.z, done)) return false;                           // z = M^-1 r
-        n = launch_dot_partials(s, R.r, R.z, R.nLocal, R.ws->partials);
+        int nz = 0;
+        if (!mg_apply(R.mg, R.r, R.z, done, R.nranks == 1 ? R.ws->partials : nullptr, &nz)) return false;   // z = M^-1 r (+ r.z on the last sweep)
+        n = nz > 0 ? nz : launch_dot_partials(s, R.r, R.z, R.nLocal, R.ws->partials);
         if (R.nranks > 1) {
             launch_reduce_to(s, R.ws->partials, n, &sc->rzNew, done);
             if (!comm_allreduce_sum(R.comm, &sc->rzNew, 1, s)) return false;
