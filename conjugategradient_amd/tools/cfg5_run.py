@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""BASELINE.json config 5 at full size (random SPD, N = 10 M, ~30 nnz/row, irregular): SpMV of every kernel family against
+the CPU oracle's product, timing, and the whole solve against a manufactured solution.  Prints one JSON line.
+Host generation needs ~25 GB of RAM and a few minutes; --rows scales it down."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from conjugategradient_amd import _lib, problems  # noqa: E402
+from conjugategradient_amd.solver import ConjugateGradientSingleGpu, VectorDouble  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--reps", type=int, default=10)
+    a = ap.parse_args()
+    t0 = time.perf_counter()
+    s = problems.random_spd(a.rows, mean_upper=14.0, seed=12345)
+    out = {"rows": s.Count, "nnz": s.nnz, "nnz_per_row": s.nnz / s.Count, "max_row": int(np.diff(s.RowOffsets).max()), "generate_s": time.perf_counter() - t0}
+    print(json.dumps(out), flush=True)
+    from oracle import oracle as O
+
+    x = np.cos(np.arange(s.Count) * 0.01)
+    t0 = time.perf_counter()
+    ref = O.spmv(s.Elements, s.ColumnIndeces, s.RowOffsets, x)
+    out["oracle_spmv_s"] = time.perf_counter() - t0
+    L = _lib.lib()
+    _lib.require_gpu()
+    cg = ConjugateGradientSingleGpu(s.Count, out["max_row"], 0, 1000, 1e-8, rule=_lib.RULE_CSHARP)
+    cg.A = type("M", (), {})()
+    cg.A.Elements, cg.A.ColumnIndeces, cg.A.RowOffsets = s.Elements, s.ColumnIndeces, s.RowOffsets
+    cg.vectorA.Dispose(); cg.vectorColumnIndeces.Dispose()
+    from conjugategradient_amd.solver import VectorInt
+    cg.vectorA, cg.vectorColumnIndeces = VectorDouble(s.nnz), VectorInt(s.nnz)          # exact size instead of Count * maxNonZero
+    # b = A.1 is the all-ones vector for this generator (row sums are 1), which CG solves in one step: use
+    # b = A.(x + 2) = A.x + 2 instead, so the answer is x + 2 and the solve takes a few dozen iterations
+    cg.x[:] = s.x
+    cg.b[:] = ref + 2.0
+    cg.Initialize()
+    dx, dy = VectorDouble(s.Count), VectorDouble(s.Count)
+    dx.CopyFrom(x, s.Count)
+    algo = 12 * s.nnz + 4 * (s.Count + 1) + 16 * s.Count
+    ev0, ev1 = L.MgcgEventCreate(), L.MgcgEventCreate()
+    out["kernels"] = {}
+    for name, k in (("auto", 0), ("row-block (stream form)", 1), ("rows (lane = row)", 9), ("8 lanes/row", 5), ("16 lanes/row", 6), ("32 lanes/row", 7)):
+        L.MgcgSetSpmvKernel(cg.cusparse, k)
+        args = (cg.cusparse, cg.matDescr, dy.ToRawPtr(), cg.vectorA.ToRawPtr(), cg.vectorRowOffsets.ToRawPtr(), cg.vectorColumnIndeces.ToRawPtr(), dx.ToRawPtr(), s.nnz, s.Count, s.Count, 1.0, 0.0)
+        L.CsrMV(*args)
+        _lib.check("CsrMV")
+        got = dy.to_numpy()
+        err = float(np.abs(got - ref).max() / np.abs(ref).max())
+        L.MgcgEventRecord(ev0)
+        for _ in range(a.reps):
+            L.CsrMV(*args)
+        L.MgcgEventRecord(ev1)
+        ms = L.MgcgEventElapsedMs(ev0, ev1) / a.reps
+        out["kernels"][name] = {"ms": ms, "algorithmic_gbps": algo / ms / 1e6, "bit_identical_to_oracle": bool(np.array_equal(got, ref)), "max_rel_err": err}
+    L.MgcgSetSpmvKernel(cg.cusparse, 0)
+    t0 = time.perf_counter()
+    cg.Solve()
+    out["solve_s"] = time.perf_counter() - t0
+    cg.Read()
+    out["iterations"] = cg.Iteration + 1
+    out["residual"] = cg.Residual
+    out["max_abs_error_of_x"] = float(np.abs(cg.x - (x + 2.0)).max())
+    out["solve_ms_per_iteration"] = 1e3 * out["solve_s"] / out["iterations"]
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
