@@ -91,7 +91,7 @@ struct MgcgComm {
     int nranks = 1, rank = 0;
     hipStream_t stream = nullptr;
     double* scratch = nullptr;       // device, 8 doubles
-    hipStream_t haloStream = nullptr;                 // the halo travels here while interior rows are multiplied on `stream`
+    hipStream_t haloStream = nullptr;                 // side stream: interior rows run here while the halo travels on `stream`
     hipEvent_t evReady = nullptr, evHalo = nullptr;
 };
 
@@ -212,9 +212,10 @@ bool halo_exchange(MgcgComm* c, HaloPlan* h, double* p, hipStream_t s)
     return ok;
 }
 
-// Overlapped form: ready(main) marks the point where p is final; run() exchanges on the communicator's own stream
-// behind that mark; wait(main) makes the main stream wait for the halo.  Kernels enqueued on the main stream
-// between ready and wait (the interior rows) run while the halo is in flight.
+// Overlapped form.  Every RCCL call stays on the rank's main stream (one stream per communicator, the pattern RCCL is
+// used with everywhere); what moves is the interior rows: fork() makes a side stream wait for the point where p is
+// final and returns it, the caller launches the interior rows there, exchanges the halo and multiplies the boundary
+// rows on the main stream, and join() makes the main stream wait for the side stream.
 bool halo_overlap_available(MgcgComm* c)
 {
     if (!c || c->nranks == 1) return false;
@@ -225,14 +226,16 @@ bool halo_overlap_available(MgcgComm* c)
     }
     return true;
 }
-bool halo_overlap_ready(MgcgComm* c, hipStream_t mainStream) { return MGCG_HIP(hipEventRecord(c->evReady, mainStream)); }
-bool halo_overlap_run(MgcgComm* c, HaloPlan* h, double* p)
+hipStream_t halo_overlap_fork(MgcgComm* c, hipStream_t mainStream)
 {
-    bool ok = MGCG_HIP(hipStreamWaitEvent(c->haloStream, c->evReady, 0));
-    ok = ok && halo_exchange(c, h, p, c->haloStream);
-    return ok && MGCG_HIP(hipEventRecord(c->evHalo, c->haloStream));
+    if (!MGCG_HIP(hipEventRecord(c->evReady, mainStream))) return nullptr;
+    if (!MGCG_HIP(hipStreamWaitEvent(c->haloStream, c->evReady, 0))) return nullptr;
+    return c->haloStream;
 }
-bool halo_overlap_wait(MgcgComm* c, hipStream_t mainStream) { return MGCG_HIP(hipStreamWaitEvent(mainStream, c->evHalo, 0)); }
+bool halo_overlap_join(MgcgComm* c, hipStream_t mainStream)
+{
+    return MGCG_HIP(hipEventRecord(c->evHalo, c->haloStream)) && MGCG_HIP(hipStreamWaitEvent(mainStream, c->evHalo, 0));
+}
 
 } // namespace mgcg
 

@@ -239,10 +239,9 @@ struct HaloPlan;  // per-peer contiguous send/recv ranges of p
 HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long long countLocal, int minJ, int maxJ);
 void halo_plan_destroy(HaloPlan* h);
 bool halo_exchange(MgcgComm* c, HaloPlan* h, double* p, hipStream_t s);
-// halo in flight on the communicator's own stream while the main stream multiplies the interior rows
+// interior rows on a side stream while the halo travels on the main stream (all RCCL calls stay on the main stream)
 bool halo_overlap_available(MgcgComm* c);
-bool halo_overlap_ready(MgcgComm* c, hipStream_t mainStream);
-bool halo_overlap_run(MgcgComm* c, HaloPlan* h, double* p);
-bool halo_overlap_wait(MgcgComm* c, hipStream_t mainStream);
+hipStream_t halo_overlap_fork(MgcgComm* c, hipStream_t mainStream);   // side stream, ordered after everything enqueued on mainStream so far
+bool halo_overlap_join(MgcgComm* c, hipStream_t mainStream);          // mainStream waits for the side stream
 
 } // namespace mgcg

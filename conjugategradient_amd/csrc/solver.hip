@@ -94,13 +94,13 @@ static bool mg_spmv(MgcgMg* mg, MgLevel& L, int epilogue, const SpmvArgs& a, dou
         launch_spmv_auto(s, epilogue, a, L.cfg, L.dcsr);
         return true;
     }
-    if (!halo_overlap_ready(mg->comm, s)) return false;
-    launch_spmv_range(s, epilogue, a, L.cfg, L.dcsr, L.interior0, L.interior1, nullptr, 0);
-    if (!halo_overlap_run(mg->comm, L.halo, xfull)) return false;
-    if (!halo_overlap_wait(mg->comm, s)) return false;
+    hipStream_t side = halo_overlap_fork(mg->comm, s);
+    if (!side) return false;
+    launch_spmv_range(side, epilogue, a, L.cfg, L.dcsr, L.interior0, L.interior1, nullptr, 0);
+    if (!mg_halo(mg, L, xfull)) return false;
     launch_spmv_range(s, epilogue, a, L.cfg, L.dcsr, 0, L.interior0, nullptr, 0);
     launch_spmv_range(s, epilogue, a, L.cfg, L.dcsr, L.interior1, L.n, nullptr, 0);
-    return true;
+    return halo_overlap_join(mg->comm, s);
 }
 
 // xout_loc = xin_loc + omega * (dinv * (b - A xin)); xin / xout are full-length buffers
@@ -197,7 +197,7 @@ struct CgRun {
     SpmvProfile* prof = nullptr;
     const DcsrMatrix* dcsr = nullptr;      // compressed form of the matrix if the handle has one
     MgcgSparse* cusparse = nullptr;
-    // rows [interior0, interior1) reference local columns only: they are multiplied while the halo of p is in flight
+    // rows [interior0, interior1) reference local columns only: they are multiplied (side stream) while the halo of p is in flight
     bool overlap = false;
     long long interior0 = 0, interior1 = 0;
 };
@@ -281,14 +281,15 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
     a.w = pLoc; a.partials = R.ws->partials; a.doneFlag = done;
     int n;
     if (R.overlap) {
-        // SyncP (:469) on the communicator's stream; interior rows meanwhile, boundary rows once the halo is in
-        if (!halo_overlap_ready(R.comm, s)) return false;
+        // interior rows on the side stream while SyncP (:469) travels on the main stream, then the boundary rows
         prof_mark(R, true);
-        n = launch_spmv_range(s, EPI_DOT, a, R.cfg, R.dcsr, R.interior0, R.interior1, R.ws->partials, kMaxPartials / 2);
-        if (!halo_overlap_run(R.comm, R.halo, R.p)) return false;
-        if (!halo_overlap_wait(R.comm, s)) return false;
+        hipStream_t side = halo_overlap_fork(R.comm, s);
+        if (!side) return false;
+        n = launch_spmv_range(side, EPI_DOT, a, R.cfg, R.dcsr, R.interior0, R.interior1, R.ws->partials, kMaxPartials / 2);
+        if (!halo_exchange(R.comm, R.halo, R.p, s)) return false;
         n += launch_spmv_range(s, EPI_DOT, a, R.cfg, R.dcsr, 0, R.interior0, R.ws->partials + n, kMaxPartials / 4);
         n += launch_spmv_range(s, EPI_DOT, a, R.cfg, R.dcsr, R.interior1, R.nLocal, R.ws->partials + n, kMaxPartials / 4);
+        if (!halo_overlap_join(R.comm, s)) return false;
         prof_mark(R, false);
     } else {
         if (!halo_exchange(R.comm, R.halo, R.p, s)) return false;                    // SyncP  (:469)
