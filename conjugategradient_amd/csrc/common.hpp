@@ -25,6 +25,8 @@ constexpr int kNumCu = 256;
 constexpr int kMaxGrid = kNumCu * 8; // 8 resident 256-thread workgroups per CU (32 waves/CU)
 constexpr int kMaxPartials = kNumCu * 32; // single-wavefront workgroups: up to 32 per CU, one partial sum each
 constexpr int kMaxDevices = 64;
+constexpr int kPatMax = 256;         // row-pattern form: distinct rows-as-sequences a matrix may have ...
+constexpr int kPatEntries = 2048;    // ... and nPattern * longest row (the table lives in LDS: 12 bytes per entry)
 
 // ---------------------------------------------------------------- errors
 void set_error(const char* fmt, ...);
@@ -95,6 +97,12 @@ struct DcsrView {
     const double* valueDict;
     int nDelta, nValue;
     long long rowBase;               // global index of local row 0
+    // row-pattern form (class 3): one byte per ROW names the row's whole (offsets, values) sequence
+    const unsigned char* patternId;  // nullptr: not in pattern form
+    const int* patCount;             // [nPattern] entries per pattern
+    const int* patDelta;             // [nPattern * patWidth]
+    const double* patValue;          // [nPattern * patWidth]
+    int nPattern, patWidth;
 };
 // ... and what the handle caches per analysed matrix (keyed by the CSR pointers and sizes).
 struct DcsrMatrix {
@@ -103,9 +111,16 @@ struct DcsrMatrix {
     unsigned char* colCode = nullptr; unsigned char* valCode = nullptr;
     int* deltaDict = nullptr; double* valueDict = nullptr;
     int nDelta = 0, nValue = 0;
+    unsigned char* patternId = nullptr; int* patCount = nullptr; int* patDelta = nullptr; double* patValue = nullptr;
+    int nPattern = 0, patWidth = 0;
     bool usable = false;
     void release();
-    DcsrView view() const { DcsrView v; v.colCode = colCode; v.valCode = valCode; v.deltaDict = deltaDict; v.valueDict = valueDict; v.nDelta = nDelta; v.nValue = nValue; v.rowBase = rowBase; return v; }
+    DcsrView view() const
+    {
+        DcsrView v; v.colCode = colCode; v.valCode = valCode; v.deltaDict = deltaDict; v.valueDict = valueDict; v.nDelta = nDelta; v.nValue = nValue; v.rowBase = rowBase;
+        v.patternId = patternId; v.patCount = patCount; v.patDelta = patDelta; v.patValue = patValue; v.nPattern = nPattern; v.patWidth = patWidth;
+        return v;
+    }
 };
 // Optional per-launch timing of the SpMV inside the CG loop (bench.py's roofline figure).
 struct SpmvProfile {
@@ -123,7 +138,7 @@ struct MgcgSparse {
     int gridBlocks = 0;
     int periodRows = 0;      // rows between strongly coupled windows (a grid plane); 0 = unknown
     int tileRows = 0, tilePlanes = 0;   // banded schedule tile (0 = default)
-    bool compression = false;           // opt-in: analyse matrices into the dictionary-compressed form
+    int compression = 0;                // opt-in: 0 off, 1 best lossless compact form (row patterns, else per-nonzero codes), 2 per-nonzero codes only
     std::vector<mgcg::DcsrMatrix*> analysed;
 };
 struct MgcgMatDescr { int type = 0; int base = 0; };
@@ -171,6 +186,9 @@ int launch_spmv(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig
 int launch_spmv_rows(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView* m, int gridReq);   // m == nullptr: plain CSR
 bool dcsr_build(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces,
                 long long rows, long long nnz, long long rowBase, DcsrMatrix* out);
+// Row-pattern form: usable (out->patternId != nullptr) when the matrix has <= 256 distinct rows-as-sequences.
+bool pattern_build(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces,
+                   long long rows, long long nnz, long long rowBase, DcsrMatrix* out);
 // Cached analysis of a matrix on a handle (nullptr: compression off, not applicable, or the build failed).
 const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* rowOffsets, const int* columnIndeces,
                               long long rows, long long nnz, long long rowBase);

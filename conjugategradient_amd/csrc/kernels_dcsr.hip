@@ -98,6 +98,108 @@ __global__ __launch_bounds__(kBlock) void dcsr_encode_kernel(const double* __res
     }
 }
 
+// ---------------------------------------------------------------- row-pattern analysis
+// A constant-coefficient stencil matrix has very few distinct ROWS when a row is read as the sequence of its
+// (col - row, value) pairs in stored order: 27 for the 7-point Laplacian on a box (interior + the boundary combinations).
+// With <= 256 of them one byte per row replaces the row's offsets, column ids and values altogether; the SpMV kernel
+// (spmv_pattern_kernel, kernels_rows.hip) keeps the table of sequences in LDS.  Rows are matched by a 64-bit hash and
+// then VERIFIED entry by entry against the table, so a hash collision can only make the analysis decline.
+constexpr int kPatHashCap = 4096;
+constexpr unsigned long long kPatEmpty = 0ull;
+
+__device__ inline unsigned long long pat_mix(unsigned long long h, unsigned long long v)
+{
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    h *= 0xFF51AFD7ED558CCDull;
+    h ^= h >> 33;
+    return h;
+}
+
+// rowHash[i] = hash of row i's sequence; distinct hashes are collected in `set`; stats[0] = distinct count (stops
+// growing meaningfully past kPatMax), stats[1] = longest row
+__global__ __launch_bounds__(kBlock) void pattern_hash_kernel(const double* __restrict__ elements, const int* __restrict__ rowOffsets,
+                                                              const int* __restrict__ columnIndeces, long long rows, long long rowBase,
+                                                              unsigned long long* __restrict__ rowHash, unsigned long long* set, int* stats)
+{
+    const long long stride = (long long)gridDim.x * kBlock;
+    int longest = 0;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < rows; i += stride) {
+        if (stats[0] > kPatMax) break;                             // hopeless: stop early (the analysis declines)
+        const int s = rowOffsets[i], e = rowOffsets[i + 1];
+        unsigned long long h = pat_mix(0x243F6A8885A308D3ull, (unsigned long long)(e - s));
+        for (int k = s; k < e; ++k) {
+            h = pat_mix(h, (unsigned long long)((long long)columnIndeces[k] - (rowBase + i)));
+            h = pat_mix(h, (unsigned long long)__double_as_longlong(elements[k]));
+        }
+        if (h == kPatEmpty) h = 1ull;
+        rowHash[i] = h;
+        longest = (e - s) > longest ? (e - s) : longest;
+        unsigned slot = (unsigned)(h >> 20) & (kPatHashCap - 1);
+        for (int probe = 0; probe < kPatHashCap; ++probe) {
+            const unsigned long long cur = set[slot];
+            if (cur == h) break;
+            if (cur == kPatEmpty) {
+                const unsigned long long prev = atomicCAS(&set[slot], kPatEmpty, h);
+                if (prev == kPatEmpty) { atomicAdd(&stats[0], 1); break; }
+                if (prev == h) break;
+            }
+            slot = (slot + 1) & (kPatHashCap - 1);
+        }
+    }
+    atomicMax(&stats[1], longest);
+}
+
+// patternId[i] = rank of the row's hash in the sorted list; rep[id] = smallest row with that id
+__global__ __launch_bounds__(kBlock) void pattern_assign_kernel(const unsigned long long* __restrict__ rowHash, long long rows,
+                                                                const unsigned long long* __restrict__ sorted, int n,
+                                                                unsigned char* __restrict__ patternId, long long* rep)
+{
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < rows; i += stride) {
+        const int id = find_sorted(sorted, n, rowHash[i]);
+        patternId[i] = (unsigned char)id;
+        if (rep[id] > i) atomicMin((unsigned long long*)&rep[id], (unsigned long long)i);
+    }
+}
+
+__global__ void pattern_table_kernel(const double* __restrict__ elements, const int* __restrict__ rowOffsets, const int* __restrict__ columnIndeces,
+                                     long long rowBase, const long long* __restrict__ rep, int n, int width,
+                                     int* __restrict__ patCount, int* __restrict__ patDelta, double* __restrict__ patValue)
+{
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n) return;
+    const long long i = rep[id];
+    const int s = rowOffsets[i], e = rowOffsets[i + 1];
+    patCount[id] = e - s;
+    for (int j = 0; j < width; ++j) {
+        const bool in = s + j < e;
+        patDelta[id * width + j] = in ? (int)((long long)columnIndeces[s + j] - (rowBase + i)) : 0;
+        patValue[id * width + j] = in ? elements[s + j] : 0.0;
+    }
+}
+
+// every row must equal its pattern entry by entry (guards against hash collisions); *err != 0 otherwise
+__global__ __launch_bounds__(kBlock) void pattern_verify_kernel(const double* __restrict__ elements, const int* __restrict__ rowOffsets,
+                                                                const int* __restrict__ columnIndeces, long long rows, long long rowBase,
+                                                                const unsigned char* __restrict__ patternId, int width,
+                                                                const int* __restrict__ patCount, const int* __restrict__ patDelta,
+                                                                const double* __restrict__ patValue, int* err)
+{
+    const long long stride = (long long)gridDim.x * kBlock;
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < rows; i += stride) {
+        const int id = patternId[i];
+        const int s = rowOffsets[i], e = rowOffsets[i + 1];
+        if (e - s != patCount[id]) { bad = true; continue; }
+        for (int k = s; k < e; ++k) {
+            const int d = (int)((long long)columnIndeces[k] - (rowBase + i));
+            bad = bad || d != patDelta[id * width + (k - s)] ||
+                  __double_as_longlong(elements[k]) != __double_as_longlong(patValue[id * width + (k - s)]);
+        }
+    }
+    if (bad) atomicExch(err, 1);
+}
+
 // ---------------------------------------------------------------- build
 void DcsrMatrix::release()
 {
@@ -105,7 +207,62 @@ void DcsrMatrix::release()
     if (valCode) (void)hipFree(valCode);
     if (deltaDict) (void)hipFree(deltaDict);
     if (valueDict) (void)hipFree(valueDict);
-    colCode = valCode = nullptr; deltaDict = nullptr; valueDict = nullptr; nDelta = nValue = 0; usable = false;
+    if (patternId) (void)hipFree(patternId);
+    if (patCount) (void)hipFree(patCount);
+    if (patDelta) (void)hipFree(patDelta);
+    if (patValue) (void)hipFree(patValue);
+    colCode = valCode = nullptr; deltaDict = nullptr; valueDict = nullptr; nDelta = nValue = 0;
+    patternId = nullptr; patCount = nullptr; patDelta = nullptr; patValue = nullptr; nPattern = patWidth = 0;
+    usable = false;
+}
+
+// On success out->patternId != nullptr says whether the row-pattern form exists.  Leaves the other fields of *out alone.
+bool pattern_build(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces,
+                   long long rows, long long nnz, long long rowBase, DcsrMatrix* out)
+{
+    if (rows <= 0 || nnz <= 0) return true;
+    unsigned long long *rowHash = nullptr, *set = nullptr, *dSorted = nullptr;
+    long long* rep = nullptr;
+    int* stats = nullptr;
+    unsigned char* ids = nullptr; int* pc = nullptr; int* pd = nullptr; double* pv = nullptr;
+    auto cleanup = [&](bool keep) {
+        for (void* p : { (void*)rowHash, (void*)set, (void*)dSorted, (void*)rep, (void*)stats }) if (p) (void)hipFree(p);
+        if (!keep) for (void* p : { (void*)ids, (void*)pc, (void*)pd, (void*)pv }) if (p) (void)hipFree(p);
+    };
+    bool ok = MGCG_HIP(hipMalloc((void**)&rowHash, sizeof(unsigned long long) * (size_t)rows)) &&
+              MGCG_HIP(hipMalloc((void**)&set, sizeof(unsigned long long) * kPatHashCap)) && MGCG_HIP(hipMalloc((void**)&stats, 3 * sizeof(int)));
+    ok = ok && MGCG_HIP(hipMemsetAsync(set, 0, sizeof(unsigned long long) * kPatHashCap, s)) && MGCG_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(int), s));
+    if (!ok) { cleanup(false); return false; }
+    long long blocks = (rows + kBlock - 1) / kBlock;
+    if (blocks > kMaxGrid) blocks = kMaxGrid;
+    hipLaunchKernelGGL(pattern_hash_kernel, dim3((int)blocks), dim3(kBlock), 0, s, elements, rowOffsets, columnIndeces, rows, rowBase, rowHash, set, stats);
+    int hS[3] = { 0, 0, 0 };
+    std::vector<unsigned long long> hSet(kPatHashCap);
+    ok = MGCG_HIP(hipMemcpyAsync(hS, stats, sizeof(hS), hipMemcpyDeviceToHost, s)) &&
+         MGCG_HIP(hipMemcpyAsync(hSet.data(), set, sizeof(unsigned long long) * kPatHashCap, hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
+    if (!ok) { cleanup(false); return false; }
+    const int n = hS[0], width = hS[1];
+    if (n < 1 || n > kPatMax || width < 1 || (long long)n * width > kPatEntries) { cleanup(false); return true; }   // not a pattern matrix
+    std::vector<unsigned long long> sorted;
+    for (unsigned long long v : hSet) if (v != kPatEmpty) sorted.push_back(v);
+    std::sort(sorted.begin(), sorted.end());
+    if ((int)sorted.size() != n) { cleanup(false); return true; }
+    std::vector<long long> hRep((size_t)n, 0x7fffffffffffffffLL);
+    ok = MGCG_HIP(hipMalloc((void**)&dSorted, sizeof(unsigned long long) * (size_t)n)) && MGCG_HIP(hipMalloc((void**)&rep, sizeof(long long) * (size_t)n)) &&
+         MGCG_HIP(hipMalloc((void**)&ids, (size_t)rows + 16)) && MGCG_HIP(hipMalloc((void**)&pc, sizeof(int) * (size_t)n)) &&
+         MGCG_HIP(hipMalloc((void**)&pd, sizeof(int) * (size_t)n * width)) && MGCG_HIP(hipMalloc((void**)&pv, sizeof(double) * (size_t)n * width));
+    ok = ok && MGCG_HIP(hipMemcpyAsync(dSorted, sorted.data(), sizeof(unsigned long long) * (size_t)n, hipMemcpyHostToDevice, s)) &&
+         MGCG_HIP(hipMemcpyAsync(rep, hRep.data(), sizeof(long long) * (size_t)n, hipMemcpyHostToDevice, s));
+    if (!ok) { cleanup(false); return false; }
+    hipLaunchKernelGGL(pattern_assign_kernel, dim3((int)blocks), dim3(kBlock), 0, s, rowHash, rows, dSorted, n, ids, rep);
+    hipLaunchKernelGGL(pattern_table_kernel, dim3((n + 63) / 64), dim3(64), 0, s, elements, rowOffsets, columnIndeces, rowBase, rep, n, width, pc, pd, pv);
+    hipLaunchKernelGGL(pattern_verify_kernel, dim3((int)blocks), dim3(kBlock), 0, s, elements, rowOffsets, columnIndeces, rows, rowBase, ids, width, pc, pd, pv, &stats[2]);
+    ok = MGCG_HIP(hipGetLastError()) && MGCG_HIP(hipMemcpyAsync(hS, stats, sizeof(hS), hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
+    if (!ok) { cleanup(false); return false; }
+    if (hS[2] != 0) { cleanup(false); return true; }                 // two different rows shared a hash: decline
+    out->patternId = ids; out->patCount = pc; out->patDelta = pd; out->patValue = pv; out->nPattern = n; out->patWidth = width;
+    cleanup(true);
+    return true;
 }
 
 // Analyse the CSR slice (rows `rows`, first global row `rowBase`); on success out->usable says whether a

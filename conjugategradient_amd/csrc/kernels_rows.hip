@@ -262,10 +262,123 @@ static int launch_rows_epi(hipStream_t s, const SpmvArgs& a, const DcsrView* m, 
     return grid;
 }
 
+// ---------------------------------------------------------------- row-pattern form (class 3, kernels_dcsr.hip)
+// One byte per row names the row's whole sequence of (col - row, value) pairs; the table of sequences sits in LDS.
+// Lane = row, RPL rows per lane per trip (rows r, r+64, ...): per wave-trip RPL coalesced 64-byte id loads, then per
+// entry slot j one LDS read of (offset, value) and one gather -- no row offsets, no column ids, no values from HBM.
+// Eight gathers per row are issued back to back before the first product is needed; products are added in stored order
+// (masked slots add +0.0, which leaves the sum's bits alone), so the result equals the CSR kernels' bit for bit.
+template <int EPI, int RPL>
+__global__ __launch_bounds__(64) void spmv_pattern_kernel(SpmvArgs a, DcsrView m, int nRowBlocks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const int W = m.patWidth, nP = m.nPattern;
+    double* s_val = (double*)s_raw;                               // [nP * W]
+    int* s_delta = (int*)(s_val + nP * W);                        // [nP * W]
+    int* s_cnt = s_delta + nP * W;                                // [nP]
+    if (a.doneFlag != nullptr && *a.doneFlag != 0) return;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nP * W; i += 64) { s_val[i] = m.patValue[i]; s_delta[i] = m.patDelta[i]; }
+    for (int i = tid; i < nP; i += 64) s_cnt[i] = m.patCount[i];
+    __syncthreads();
+
+    const long long lastRow = (long long)a.rowCount - 1;
+    double dotacc = 0.0;
+    for (long long rb = blockIdx.x; rb < nRowBlocks; rb += gridDim.x) {
+        const long long base = rb * (64 * RPL);
+        long long row[RPL]; bool live[RPL]; int tb[RPL], cnt[RPL]; double acc[RPL]; RowsEpi eo[RPL];
+#pragma unroll
+        for (int u = 0; u < RPL; ++u) {
+            row[u] = base + u * 64 + tid;
+            live[u] = row[u] <= lastRow;
+            row[u] = live[u] ? row[u] : lastRow;
+        }
+        int pid[RPL];
+#pragma unroll
+        for (int u = 0; u < RPL; ++u) pid[u] = m.patternId[row[u]];
+#pragma unroll
+        for (int u = 0; u < RPL; ++u) { eo[u] = rows_epi_prefetch<EPI>(a, row[u]); tb[u] = pid[u] * W; cnt[u] = s_cnt[pid[u]]; acc[u] = 0.0; }
+        int longest = 0;
+#pragma unroll
+        for (int u = 0; u < RPL; ++u) longest = cnt[u] > longest ? cnt[u] : longest;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(longest, off, 64); longest = o > longest ? o : longest; }
+        for (int j0 = 0; j0 < longest; j0 += 8) {                  // wave-uniform trip count
+            double xg[RPL][8], vv[RPL][8];
+#pragma unroll
+            for (int u = 0; u < RPL; ++u) {
+                const long long g = m.rowBase + row[u];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool on = j0 + j < cnt[u];
+                    const int t = tb[u] + (on ? j0 + j : 0);       // masked slots re-read the row's first entry
+                    vv[u][j] = s_val[t];
+                    xg[u][j] = a.x[g + s_delta[t]];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RPL; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const double p = vv[u][j] * xg[u][j]; acc[u] += (j0 + j < cnt[u]) ? p : 0.0; }
+        }
+#pragma unroll
+        for (int u = 0; u < RPL; ++u)
+            if (live[u]) a.y[row[u]] = rows_epilogue_value<EPI>(a, acc[u], eo[u], dotacc);
+    }
+    if constexpr (epi_has_dot(EPI)) {
+        double v = dotacc;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (tid == 0) a.partials[blockIdx.x] = v;
+    }
+}
+
+static int pattern_rows_per_lane()
+{
+    static int v = [] { const char* e = getenv("MGCG_PATTERN_RPL"); const int r = e ? atoi(e) : 2; return (r == 1 || r == 2 || r == 4) ? r : 2; }();
+    return v;
+}
+static int pattern_waves_per_cu()
+{
+    static int v = [] { const char* e = getenv("MGCG_PATTERN_WAVES"); const int r = e ? atoi(e) : 16; return (r >= 1 && r <= 32) ? r : 16; }();
+    return v;
+}
+
+template <int EPI>
+static int launch_pattern_epi(hipStream_t s, const SpmvArgs& a, const DcsrView& m, int gridReq)
+{
+    const int rpl = pattern_rows_per_lane();
+    const int nRowBlocks = (int)(((long long)a.rowCount + 64 * rpl - 1) / (64 * rpl));
+    DeviceState* d = device_state();
+    int grid = gridReq > 0 ? gridReq : pattern_waves_per_cu() * (d ? d->numCu : kNumCu);
+    if (grid > kMaxPartials) grid = kMaxPartials;
+    if (grid > nRowBlocks) grid = nRowBlocks;
+    if (grid < 1) grid = 1;
+    const size_t lds = (size_t)m.nPattern * m.patWidth * 12 + (size_t)m.nPattern * 4;
+    if (rpl == 1) hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 1>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks);
+    else if (rpl == 4) hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 4>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks);
+    else hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 2>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks);
+    return grid;
+}
+
+static int launch_spmv_pattern(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView& m, int gridReq)
+{
+    switch (epilogue) {
+    case EPI_AXPBY:        return a.beta != 0.0 ? launch_pattern_epi<EPI_AXPBY_BETA>(s, a, m, gridReq) : launch_pattern_epi<EPI_AXPBY>(s, a, m, gridReq);
+    case EPI_DOT:          return launch_pattern_epi<EPI_DOT>(s, a, m, gridReq);
+    case EPI_RESIDUAL:     return launch_pattern_epi<EPI_RESIDUAL>(s, a, m, gridReq);
+    case EPI_RESIDUAL_DOT: return launch_pattern_epi<EPI_RESIDUAL_DOT>(s, a, m, gridReq);
+    case EPI_JACOBI:       return launch_pattern_epi<EPI_JACOBI>(s, a, m, gridReq);
+    case EPI_JACOBI_DOT:   return launch_pattern_epi<EPI_JACOBI_DOT>(s, a, m, gridReq);
+    }
+    return 0;
+}
+
 // m == nullptr: plain CSR.  Requires 16-byte aligned elements, 8-byte aligned columnIndeces and elementsCount >= 8.
 int launch_spmv_rows(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView* m, int gridReq)
 {
     if (a.rowCount <= 0) return 0;
+    if (m != nullptr && m->patternId != nullptr) return launch_spmv_pattern(s, epilogue, a, *m, gridReq);
     switch (epilogue) {
     case EPI_AXPBY:        return a.beta != 0.0 ? launch_rows_epi<EPI_AXPBY_BETA>(s, a, m, gridReq) : launch_rows_epi<EPI_AXPBY>(s, a, m, gridReq);
     case EPI_DOT:          return launch_rows_epi<EPI_DOT>(s, a, m, gridReq);

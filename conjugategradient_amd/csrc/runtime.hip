@@ -104,14 +104,23 @@ bool Workspace::ensure_trace(int cap)
 const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* rowOffsets, const int* columnIndeces,
                               long long rows, long long nnz, long long rowBase)
 {
-    if (!h || !h->compression) return nullptr;
+    if (!h || h->compression == 0) return nullptr;
     for (const DcsrMatrix* m : h->analysed)
         if (m->elements == elements && m->rowOffsets == rowOffsets && m->columnIndeces == columnIndeces && m->rows == rows && m->nnz == nnz && m->rowBase == rowBase)
             return m->usable ? m : nullptr;
-    // the wide paths need 16-byte aligned values; short average rows only (one pass per 64-row block)
-    if ((((uintptr_t)elements) & 15) != 0 || rows <= 0 || (double)nnz / (double)rows > 7.75) return nullptr;
+    if (rows <= 0 || nnz < 8) return nullptr;
+    const double avg = (double)nnz / (double)rows;
+    if (avg > 32.0) return nullptr;
     DcsrMatrix* m = new DcsrMatrix();
-    if (!dcsr_build(h->ws.stream, elements, rowOffsets, columnIndeces, rows, nnz, rowBase, m)) { m->release(); m->elements = elements; m->rowOffsets = rowOffsets; m->columnIndeces = columnIndeces; m->rows = rows; m->nnz = nnz; m->rowBase = rowBase; }
+    auto identify = [&] { m->elements = elements; m->rowOffsets = rowOffsets; m->columnIndeces = columnIndeces; m->rows = rows; m->nnz = nnz; m->rowBase = rowBase; };
+    identify();
+    // 1. one byte per row (few distinct rows-as-sequences), 2. one or two bytes per nonzero (few distinct offsets / values;
+    //    the wide loads of that kernel need 16-byte aligned values and short average rows: one pass per 64-row block)
+    if (h->compression == 1 && pattern_build(h->ws.stream, elements, rowOffsets, columnIndeces, rows, nnz, rowBase, m) && m->patternId != nullptr) {
+        m->usable = true;
+    } else if ((((uintptr_t)elements) & 15) == 0 && avg <= 7.75) {
+        if (!dcsr_build(h->ws.stream, elements, rowOffsets, columnIndeces, rows, nnz, rowBase, m)) { m->release(); identify(); }
+    }
     h->analysed.push_back(m);
     return m->usable ? m : nullptr;
 }
@@ -142,6 +151,7 @@ int launch_spmv_range(hipStream_t s, int epilogue, const SpmvArgs& whole, const 
     if (compressed) {
         DcsrView v = dc->view();
         v.rowBase += r0;
+        if (v.patternId) v.patternId += r0;
         return launch_spmv_rows(s, epilogue, a, &v, c.gridBlocks);
     }
     if (c.kernel == 0) {                                 // the kernel choice follows the whole matrix, not the slice
@@ -243,7 +253,7 @@ void DestroySparse(MgcgSparse* h)
     delete h;
 }
 
-void MgcgSetMatrixCompression(MgcgSparse* h, int enable) { if (h) h->compression = enable != 0; }
+void MgcgSetMatrixCompression(MgcgSparse* h, int enable) { if (h) h->compression = enable < 0 ? 0 : (enable > 2 ? 1 : enable); }
 void MgcgAnalysisClear(MgcgSparse* h)
 {
     if (!h) return;
@@ -256,11 +266,13 @@ int MgcgAnalysisInfo(MgcgSparse* h, int index, int* distinctOffsets, int* distin
 {
     if (!h || index < 0 || index >= (int)h->analysed.size()) return -1;
     const mgcg::DcsrMatrix* m = h->analysed[(size_t)index];
-    if (distinctOffsets) *distinctOffsets = m->nDelta;
-    if (distinctValues) *distinctValues = m->nValue;
+    const bool pat = m->patternId != nullptr;
+    if (distinctOffsets) *distinctOffsets = pat ? m->nPattern : m->nDelta;     // class 3: distinct rows-as-sequences
+    if (distinctValues) *distinctValues = pat ? m->patWidth : m->nValue;       // class 3: longest row
     if (rows) *rows = m->rows;
     if (nnz) *nnz = m->nnz;
-    return m->usable ? (m->valCode ? 2 : 1) : 0;      // bytes-per-nonzero class: 2 = offsets+values coded, 1 = offsets coded, 0 = plain CSR
+    if (!m->usable) return 0;
+    return pat ? 3 : (m->valCode ? 2 : 1);   // 3 = one byte per row, 2 = offset + value code per nonzero, 1 = offset code per nonzero, 0 = plain CSR
 }
 
 MgcgMatDescr* CreateMatDescr(void) { return new MgcgMatDescr(); }

@@ -46,13 +46,14 @@ def main():
                 ("wave R64 band", 1, 64, 4, 0, 0, 0), ("wave R32 band", 1, 32, 4, 0, 0, 0), ("wave R32 band 8Lx8", 1, 32, 4, 0, 8 * n, 8),
                 ("wg256 band 64Lx1", 1, 128, 4, 0, 64 * n, 1), ("vector 4 lanes", 4, 128, 0, 0, 0, 0),
                 ("rows", 9, 64, 0, 0, 0, 0), ("rows g2048", 9, 64, 0, 2048, 0, 0), ("rows g5120", 9, 64, 0, 5120, 0, 0), ("DOT rows", 9, 64, 0, 0, 0, 0),
-                ("dcsr", 1, 64, 0, 0, 0, 0), ("dcsr g2048", 1, 64, 0, 2048, 0, 0), ("dcsr g8192", 1, 64, 0, 8192, 0, 0), ("dcsr g5120", 1, 64, 0, 5120, 0, 0), ("dcsr g6144", 1, 64, 0, 6144, 0, 0), ("DOT dcsr", 1, 64, 0, 0, 0, 0),
+                ("dcsr", 1, 64, 0, 0, 0, 0), ("dcsr g2048", 1, 64, 0, 2048, 0, 0), ("dcsr g8192", 1, 64, 0, 8192, 0, 0), ("dcsr g5120", 1, 64, 0, 5120, 0, 0), ("dcsr g6144", 1, 64, 0, 6144, 0, 0), ("DOT dcsr", 1, 64, 0, 0, 0, 0), ("pattern", 1, 64, 0, 0, 0, 0), ("DOT pattern", 1, 64, 0, 0, 0, 0),
                 ("DOT wave R64 g4096", 1, 64, 0, 4096, 0, 0), ("DOT wave R64 band", 1, 64, 4, 0, 0, 0), ("DOT wg256 R128", 1, 128, 0, 0, 0, 0)]
     if a.variants:
         keep = set(a.variants.split(","))
         variants = [v for v in variants if v[0] in keep]
     for g in [int(t) for t in a.extra_grids.split(",") if t]:
         variants.append((f"dcsr g{g}", 1, 64, 0, g, 0, 0))
+        variants.append((f"pattern g{g}", 1, 64, 0, g, 0, 0))
         variants.append((f"rows g{g}", 9, 64, 0, g, 0, 0))
     variants = list({v[0]: v for v in variants}.values())
     ev0, ev1 = L.MgcgEventCreate(), L.MgcgEventCreate()
@@ -60,7 +61,7 @@ def main():
 
     def run(v):
         os.environ["MGCG_SPMV_ABLATE"] = str(v[7]) if len(v) > 7 else "0"
-        L.MgcgSetMatrixCompression(sparse, 1 if "dcsr" in v[0] else 0)
+        L.MgcgSetMatrixCompression(sparse, 2 if "dcsr" in v[0] else (1 if "pattern" in v[0] else 0))
         L.MgcgSetSpmvKernel(sparse, v[1])
         L.MgcgSetSpmvTuning(sparse, v[2], v[3], v[4])
         L.MgcgSetSpmvPeriod(sparse, n * n if (v[3] & 4) else 0)

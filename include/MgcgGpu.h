@@ -198,12 +198,18 @@ void   MgcgSetSpmvPeriod(MgcgSparse* cusparse, int periodRows);
 void   MgcgSetSpmvTile(MgcgSparse* cusparse, int tileRows, int tilePlanes);
 
 /* Opt-in analysis (the role cuSPARSE's csrmv analysis plays in the reference's stack): with compression enabled the
- * Solve-family, MgSetup and CsrMV/CsrMVDot on this handle re-encode a matrix ONCE into a lossless dictionary form
- * when it has <= 256 distinct column offsets col-row (and, if also <= 256 distinct values, 2 bytes per nonzero
- * instead of 12) and use it for every later SpMV on the same arrays.  Results are bit-identical to the CSR kernels.
+ * Solve-family, MgSetup and CsrMV/CsrMVDot on this handle re-encode a matrix ONCE into a lossless compact form and use
+ * it for every later SpMV on the same arrays.  Results are bit-identical to the CSR kernels (same doubles, same order).
+ *   enable = 1: the best form the matrix admits --
+ *       class 3  one byte per ROW when the matrix has <= 256 distinct rows read as sequences of (col-row, value)
+ *                pairs (constant-coefficient stencils: 27 for the 7-point Laplacian on a box; every Galerkin level),
+ *       class 2  two bytes per nonzero when it has <= 256 distinct offsets col-row and <= 256 distinct values,
+ *       class 1  one byte per nonzero + the fp64 value when only the offsets qualify,
+ *       class 0  otherwise (plain CSR kernels);
+ *   enable = 2: per-nonzero codes only (classes 2 / 1 / 0);   enable = 0: off.
  * The cache is keyed by the array pointers and sizes: a caller that rewrites a matrix in place must call
- * MgcgAnalysisClear.  MgcgAnalysisInfo(index) reports a cached analysis: returns 2 / 1 / 0 (offsets+values coded /
- * offsets coded / not compressible), -1 past the end. */
+ * MgcgAnalysisClear.  MgcgAnalysisInfo(index) reports a cached analysis: returns the class (-1 past the end);
+ * distinctOffsets / distinctValues receive, for class 3, the number of distinct rows and the longest row. */
 void   MgcgSetMatrixCompression(MgcgSparse* cusparse, int enable);
 void   MgcgAnalysisClear(MgcgSparse* cusparse);
 int    MgcgAnalysisInfo(MgcgSparse* cusparse, int index, int* distinctOffsets, int* distinctValues, long long* rows, long long* nnz);

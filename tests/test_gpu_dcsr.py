@@ -31,6 +31,7 @@ def _scaled_poisson(dims, seed=4):
     return problems.LinearSystem(A.data.copy(), A.indices.astype(np.int32), A.indptr.astype(np.int32), np.zeros(s.Count), np.ones(s.Count), "scaled", grid=s.grid)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("name,builder,expect_class,expect_offsets,expect_values", [
     ("poisson7", lambda: problems.poisson(20, 17, 13), 2, 7, 2),
     ("poisson5", lambda: problems.poisson(37, 29, 1), 2, 5, 2),
@@ -40,7 +41,9 @@ def _scaled_poisson(dims, seed=4):
     ("random", lambda: problems.random_spd(4000, mean_upper=2.0, seed=9), 0, None, None),   # > 256 distinct offsets: stays CSR
     ("tiny", lambda: problems.poisson(2, 1, 1), 0, None, None),                 # fewer than 8 nonzeros: not encoded
 ])
-def test_compressed_spmv_is_bit_exact(oracle, name, builder, expect_class, expect_offsets, expect_values):
+def test_compressed_spmv_is_bit_exact(oracle, name, builder, expect_class, expect_offsets, expect_values, mode):
+    """mode 2: per-nonzero codes (classes 2 / 1); mode 1: the best form, i.e. one byte per row (class 3) for the
+    constant-coefficient stencils and the per-nonzero codes for the rest."""
     L = _lib.lib()
     s = builder()
     rng = np.random.default_rng(5)
@@ -49,10 +52,19 @@ def test_compressed_spmv_is_bit_exact(oracle, name, builder, expect_class, expec
     h = Handles()
     A = DeviceCsr(s)
     plain = A.spmv(h, x, kernel=1)
-    L.MgcgSetMatrixCompression(h.sparse, 1)
+    L.MgcgSetMatrixCompression(h.sparse, mode)
     got = A.spmv(h, x)
     assert np.array_equal(plain, ref) and np.array_equal(got, ref)
     cls, nd, nv, rows, nnz = _info(h.sparse)
+    if mode == 1 and expect_class == 2:          # few distinct values and offsets here also means few distinct rows
+        assert cls == 3, (cls, nd, nv)
+        expected_rows = {"poisson7": 27, "poisson5": 9, "tridiagonal": 3}[name]
+        assert (nd, nv) == (expected_rows, expect_offsets)       # distinct rows, longest row
+        y0 = rng.standard_normal(s.Count)
+        assert np.array_equal(A.spmv(h, x, alpha=-1.5, beta=0.25, y0=y0), -1.5 * ref + 0.25 * y0)
+        L.MgcgAnalysisClear(h.sparse)
+        h.close()
+        return
     if expect_class == 0:
         assert cls in (0, -1), (cls, nd, nv)      # analysed and rejected, or not even a candidate (long average rows)
         h.close()
@@ -72,11 +84,15 @@ def test_compressed_spmv_is_bit_exact(oracle, name, builder, expect_class, expec
 
 
 def test_compressed_solves_match_plain_bits(oracle):
-    """CG and MGCG with compression on: x, iteration count and the whole residual trace equal the uncompressed run
-    bit for bit (same kernels' arithmetic, same reduction grids)."""
+    """CG and MGCG with compression on.  Per-nonzero codes (mode 2): x, iteration count and the whole residual trace equal
+    the uncompressed run bit for bit (same arithmetic, same reduction grids).  Best form (mode 1, one byte per row here):
+    every SpMV is still bit-identical, but the fused p.Ap partial sums are grouped by 128-row blocks instead of 64, so
+    the trace agrees to the dot-product tolerance of every other CG test (1e-10 while above round-off)."""
+    from tests.gpu_util import assert_trace_close
+
     for s, mg in [(problems.poisson(24, 20, 16), False), (problems.poisson(16, 16, 16), True), (_scaled_poisson((16, 12, 8)), True)]:
         runs = []
-        for comp in (0, 1):
+        for comp in (0, 1, 2):
             if mg:
                 cg = ConjugateGradientMgGpu(s.Count, 7, 0, 1000, 1e-9, s.grid, rule=_lib.RULE_CSHARP).load(s)
             else:
@@ -91,9 +107,11 @@ def test_compressed_solves_match_plain_bits(oracle):
                     assert _info(cg.cusparse, 2)[0] >= 1      # every level analysed
             runs.append((cg.x.copy(), cg.Iteration, cg.trace.copy()))
             cg.Dispose()
-        assert runs[0][1] == runs[1][1]
-        assert np.array_equal(runs[0][2], runs[1][2])
-        assert np.array_equal(runs[0][0], runs[1][0])
+        plain, best, codes = runs
+        assert plain[1] == codes[1] and np.array_equal(plain[2], codes[2]) and np.array_equal(plain[0], codes[0])
+        assert plain[1] == best[1]
+        assert_trace_close(best[2], plain[2])
+        assert np.abs(best[0] - plain[0]).max() <= 1e-10 * np.abs(plain[0]).max()
     # and against the oracle's V-cycle: still bit-identical
     s = problems.poisson(16, 16, 16)
     cg = ConjugateGradientMgGpu(s.Count, 7, 0, 500, 1e-8, s.grid).load(s)
@@ -104,7 +122,8 @@ def test_compressed_solves_match_plain_bits(oracle):
     cg.Dispose()
 
 
-def test_compressed_multirank(oracle, monkeypatch):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_compressed_multirank(oracle, monkeypatch, mode):
     """Row slices with a non-zero row base (col - row uses the GLOBAL row) through the loopback transport."""
     from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu
     from tests.test_gpu_parallel import _run_ranks_in_threads
@@ -118,12 +137,12 @@ def test_compressed_multirank(oracle, monkeypatch):
 
     def make_rank(rank, comm):
         cg = ConjugateGradientMgRankGpu(s.Count, 7, 0, 400, 1e-8, s.grid, rank=rank, world=world, comm=comm, device=rank).load(s)
-        _lib.lib().MgcgSetMatrixCompression(cg.cusparse, 1)
+        _lib.lib().MgcgSetMatrixCompression(cg.cusparse, mode)
         cg.Initialize()
         cg.Setup()
         cg.Solve()
         cg.Read()
-        assert _info(cg.cusparse, 0)[0] == 2
+        assert _info(cg.cusparse, 0)[0] == (3 if mode == 1 else 2)
         out = (cg.part.offset, cg.part.count, cg.x[cg.part.offset: cg.part.offset + cg.part.count].copy(), cg.Iteration)
         cg.Dispose()
         return out
