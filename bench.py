@@ -44,7 +44,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=4, help="CG iterations of the CPU oracle sample")
     ap.add_argument("--no-compression", action="store_true",
-                    help="keep the matrix in plain CSR inside the loop (default: the library's opt-in lossless dictionary analysis is on)")
+                    help="keep the matrix in plain CSR inside the loop (default: the library's opt-in lossless analysis is on)")
+    ap.add_argument("--compression", type=int, default=None, choices=[0, 1, 2],
+                    help="MgcgSetMatrixCompression mode: 1 best lossless form (default), 2 per-nonzero codes only, 0 = --no-compression")
     ap.add_argument("--torch-first", action="store_true", help="import torch before the library even at N=1 (runtime-compat check)")
     ap.add_argument("--spmv-kernel", type=int, default=None)
     ap.add_argument("--spmv-rows", type=int, default=None)
@@ -177,7 +179,10 @@ def main():
                                         rule=_lib.RULE_NATIVE, levels=3, nu=1, nuCoarse=4)
     else:
         cg = ConjugateGradientRankGpu(N, 7, 0, 10**9, 1e-8, rank=rank, world=world, device=local_rank)
-    L.MgcgSetMatrixCompression(cg.cusparse, 0 if a.no_compression else 1)
+    if a.compression is None:
+        a.compression = 0 if a.no_compression else 1
+    a.no_compression = a.compression == 0
+    L.MgcgSetMatrixCompression(cg.cusparse, a.compression)
     if a.spmv_kernel is not None:
         L.MgcgSetSpmvKernel(cg.cusparse, a.spmv_kernel)
     if a.spmv_rows is not None or a.spmv_flags is not None or a.spmv_grid is not None:
@@ -231,7 +236,7 @@ def main():
             L.CsrMV(cg.cusparse, cg.matDescr, *ptrs, nnz_local, rows_local, N, 1.0, 0.0)
         L.MgcgEventRecord(ev1)
         csr_ms = L.MgcgEventElapsedMs(ev0, ev1) / 20
-        L.MgcgSetMatrixCompression(cg.cusparse, 0 if a.no_compression else 1)
+        L.MgcgSetMatrixCompression(cg.cusparse, a.compression)
         # what this box streams ("% of attainable" next to "% of spec"): read-only = Dot over two vectors,
         # copy = the library's Copy export (device-to-device), on the same 1 GiB vectors
         pr, pa = cg.vectorR.ToRawPtr(), cg.vectorAp.ToRawPtr()
@@ -256,13 +261,18 @@ def main():
     else:
         spmv_ms = spmv_ms_total / max(launches.value, 1)
 
+    # which form the analysis chose for the fine matrix (class 3 one byte per row, 2/1 per-nonzero codes, 0 plain CSR)
+    cls = L.MgcgAnalysisInfo(cg.cusparse, 0, None, None, None, None) if a.compression else 0
+    fmt = {3: "pattern", 2: "dcsr", 1: "dcsr"}.get(cls, "csr")
+    fmt_text = {"pattern": "lossless row-pattern form (1 byte per row: 27 distinct rows-as-sequences; opt-in analysis, results bit-identical)",
+                "dcsr": "lossless dictionary-compressed CSR (2 B/nnz; opt-in analysis, results bit-identical)",
+                "csr": "plain CSR (12 B/nnz)"}[fmt]
     if rank == 0:
         spmv_bytes = 12 * nnz_local + 4 * (rows_local + 1) + 16 * rows_local     # per launch, per GPU
         achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
         nnz_total = 7 * N - 6 * n * n
         iter_bytes = 12 * nnz_total + 4 * (N + 1) + 16 * N + 72 * N
         traffic = None
-        fmt = "csr" if a.no_compression else "dcsr"
         pmc_file = os.path.join(ROOT, "profiles", "spmv_traffic.json")
         if os.path.exists(pmc_file) and world == 1:
             try:
@@ -292,9 +302,8 @@ def main():
             "gflops": (2 * nnz_total + 10 * N) * (a.steps / dt) / 1e9 if a.solver == "cg" else None,
             "residual_after_steps": res,
             "roofline": {"bound": "hbm",
-                         "kernel": ("spmv_rows_kernel, SpMV fused with p.Ap, matrix held as " +
-                                    ("plain CSR (12 B/nnz)" if a.no_compression else
-                                     "lossless dictionary-compressed CSR (2 B/nnz; opt-in analysis, results bit-identical): frac > 1 means fewer bytes move than the CSR-algorithmic count")),
+                         "kernel": (("spmv_pattern_kernel" if fmt == "pattern" else "spmv_rows_kernel") + ", SpMV fused with p.Ap, matrix held as " + fmt_text +
+                                    ("" if fmt == "csr" else ": frac > 1 means fewer bytes move than the CSR-algorithmic count (see traffic)")),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms, "launches_timed": launches.value},
@@ -305,7 +314,7 @@ def main():
                                         "frac": spmv_bytes / (csr_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "avg_launch_ms": csr_ms,
                                         "measured_read_only_gbps": read_gbps, "measured_copy_gbps": copy_gbps,
                                         "frac_of_measured_read_only": spmv_bytes / (csr_ms * 1e-3) / 1e9 / read_gbps if read_gbps > 0 else None}
-        out["config"]["matrix_format_in_loop"] = "csr" if a.no_compression else "dictionary-compressed csr (lossless, built once by MgcgSetMatrixCompression)"
+        out["config"]["matrix_format_in_loop"] = fmt_text + ("" if fmt == "csr" else f" -- built once by MgcgSetMatrixCompression({a.compression})")
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, a.cpu_iters)
         print(json.dumps(out), flush=True)

@@ -138,6 +138,7 @@ struct MgcgSparse {
     int gridBlocks = 0;
     int periodRows = 0;      // rows between strongly coupled windows (a grid plane); 0 = unknown
     int tileRows = 0, tilePlanes = 0;   // banded schedule tile (0 = default)
+    int analysedMode = 0;               // the compression mode the cached analyses were built under
     int compression = 0;                // opt-in: 0 off, 1 best lossless compact form (row patterns, else per-nonzero codes), 2 per-nonzero codes only
     std::vector<mgcg::DcsrMatrix*> analysed;
 };

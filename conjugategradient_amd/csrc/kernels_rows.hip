@@ -269,7 +269,7 @@ static int launch_rows_epi(hipStream_t s, const SpmvArgs& a, const DcsrView* m, 
 // Eight gathers per row are issued back to back before the first product is needed; products are added in stored order
 // (masked slots add +0.0, which leaves the sum's bits alone), so the result equals the CSR kernels' bit for bit.
 template <int EPI, int RPL>
-__global__ __launch_bounds__(64) void spmv_pattern_kernel(SpmvArgs a, DcsrView m, int nRowBlocks)
+__global__ __launch_bounds__(64) void spmv_pattern_kernel(SpmvArgs a, DcsrView m, int nRowBlocks, int groupBlocks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int W = m.patWidth, nP = m.nPattern;
@@ -282,9 +282,34 @@ __global__ __launch_bounds__(64) void spmv_pattern_kernel(SpmvArgs a, DcsrView m
     for (int i = tid; i < nP; i += 64) s_cnt[i] = m.patCount[i];
     __syncthreads();
 
+    // Trip -> row block.  Workgroup k runs on XCD k % 8 (round-robin dispatch); with groupBlocks = G > 0 every XCD owns
+    // every 8th run of G consecutive row blocks, so the +-1 grid-line (and, for the usual extents, +-1 plane) neighbours
+    // of a row are multiplied on the same XCD and their x lines are shared through its L2.  G = 0 (default): plain
+    // grid-stride -- measured equal or faster at 512^3 (profiles/r1/spmv_sweep_pattern_512.log), MGCG_PATTERN_GROUP sets G.
+    const bool grouped = groupBlocks > 0 && (gridDim.x & 7) == 0;
+    const long long G = grouped ? groupBlocks : 1;
+    const int xcd = grouped ? (int)(blockIdx.x & 7) : 0;
+    const long long first = grouped ? (long long)(blockIdx.x >> 3) : (long long)blockIdx.x;
+    const long long step = grouped ? (long long)(gridDim.x >> 3) : (long long)gridDim.x;
+    const long long count = grouped ? (((long long)nRowBlocks + 8 * G - 1) / (8 * G)) * G : (long long)nRowBlocks;
+    auto block_of = [&](long long L) -> long long { return grouped ? ((L / G) * 8 + xcd) * G + (L % G) : L; };
+
     const long long lastRow = (long long)a.rowCount - 1;
+    auto load_ids = [&](long long rb, int* pid) {
+        const long long base = rb * (64 * RPL);
+#pragma unroll
+        for (int u = 0; u < RPL; ++u) { long long r = base + u * 64 + tid; r = r <= lastRow ? r : lastRow; r = r >= 0 ? r : 0; pid[u] = m.patternId[r]; }
+    };
     double dotacc = 0.0;
-    for (long long rb = blockIdx.x; rb < nRowBlocks; rb += gridDim.x) {
+    int pidNext[RPL];
+    if (first < count) load_ids(block_of(first) < nRowBlocks ? block_of(first) : 0, pidNext);
+    for (long long L = first; L < count; L += step) {
+        const long long rb = block_of(L);
+        int pid[RPL];
+#pragma unroll
+        for (int u = 0; u < RPL; ++u) pid[u] = pidNext[u];
+        if (L + step < count) { const long long nb = block_of(L + step); load_ids(nb < nRowBlocks ? nb : 0, pidNext); }   // ids of the next trip, in flight behind the gathers
+        if (rb >= nRowBlocks) continue;                            // wave-uniform (tail of the grouped enumeration)
         const long long base = rb * (64 * RPL);
         long long row[RPL]; bool live[RPL]; int tb[RPL], cnt[RPL]; double acc[RPL]; RowsEpi eo[RPL];
 #pragma unroll
@@ -293,9 +318,6 @@ __global__ __launch_bounds__(64) void spmv_pattern_kernel(SpmvArgs a, DcsrView m
             live[u] = row[u] <= lastRow;
             row[u] = live[u] ? row[u] : lastRow;
         }
-        int pid[RPL];
-#pragma unroll
-        for (int u = 0; u < RPL; ++u) pid[u] = m.patternId[row[u]];
 #pragma unroll
         for (int u = 0; u < RPL; ++u) { eo[u] = rows_epi_prefetch<EPI>(a, row[u]); tb[u] = pid[u] * W; cnt[u] = s_cnt[pid[u]]; acc[u] = 0.0; }
         int longest = 0;
@@ -333,6 +355,11 @@ __global__ __launch_bounds__(64) void spmv_pattern_kernel(SpmvArgs a, DcsrView m
     }
 }
 
+static int pattern_group_blocks()
+{
+    static int v = [] { const char* e = getenv("MGCG_PATTERN_GROUP"); const int r = e ? atoi(e) : 0; return (r >= 0 && r <= 65536) ? r : 0; }();
+    return v;
+}
 static int pattern_rows_per_lane()
 {
     static int v = [] { const char* e = getenv("MGCG_PATTERN_RPL"); const int r = e ? atoi(e) : 2; return (r == 1 || r == 2 || r == 4) ? r : 2; }();
@@ -355,9 +382,10 @@ static int launch_pattern_epi(hipStream_t s, const SpmvArgs& a, const DcsrView& 
     if (grid > nRowBlocks) grid = nRowBlocks;
     if (grid < 1) grid = 1;
     const size_t lds = (size_t)m.nPattern * m.patWidth * 12 + (size_t)m.nPattern * 4;
-    if (rpl == 1) hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 1>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks);
-    else if (rpl == 4) hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 4>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks);
-    else hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 2>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks);
+    const int group = (grid % 8 == 0 && nRowBlocks >= 64 * 8) ? pattern_group_blocks() : 0;
+    if (rpl == 1) hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 1>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks, group);
+    else if (rpl == 4) hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 4>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks, group);
+    else hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 2>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks, group);
     return grid;
 }
 

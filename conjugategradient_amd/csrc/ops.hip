@@ -59,6 +59,7 @@ double CsrMVDot(MgcgBlas* cublas, MgcgSparse* cusparse, double* y,
     if (!cublas || !cusparse || !y || !rowOffsets || !x || !w) { set_error("CsrMVDot: null argument"); return NAN; }
     if (rowCount <= 0) return 0.0;
     SpmvArgs a{};
+    if (const char* ab = getenv("MGCG_SPMV_ABLATE")) a.ablate = atoi(ab);     // timing diagnostics only
     a.elements = elements; a.rowOffsets = rowOffsets; a.columnIndeces = columnIndeces; a.x = x; a.y = y;
     a.elementsCount = elementsCount; a.rowCount = rowCount; a.columnCount = columnCount; a.w = w; a.partials = cublas->ws.partials;
     const DcsrMatrix* dc = dcsr_lookup(cusparse, elements, rowOffsets, columnIndeces, rowCount, elementsCount, 0);

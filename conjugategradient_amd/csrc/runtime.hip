@@ -253,7 +253,15 @@ void DestroySparse(MgcgSparse* h)
     delete h;
 }
 
-void MgcgSetMatrixCompression(MgcgSparse* h, int enable) { if (h) h->compression = enable < 0 ? 0 : (enable > 2 ? 1 : enable); }
+void MgcgAnalysisClear(MgcgSparse* h);
+void MgcgSetMatrixCompression(MgcgSparse* h, int enable)
+{
+    if (!h) return;
+    const int mode = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
+    if (mode != 0 && h->analysedMode != 0 && mode != h->analysedMode && !h->analysed.empty()) MgcgAnalysisClear(h);   // another form was asked for: analyse again
+    if (mode != 0) h->analysedMode = mode;
+    h->compression = mode;
+}
 void MgcgAnalysisClear(MgcgSparse* h)
 {
     if (!h) return;

@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--variants", default="1:128:0,1:128:4", help="kernel:rows:flags,...")
+    ap.add_argument("--compression", type=int, default=0, help="MgcgSetMatrixCompression mode for every variant (0 off, 1 best, 2 per-nonzero codes)")
     a = ap.parse_args()
     L = _lib.lib()
     _lib.require_gpu()
@@ -31,6 +32,7 @@ def main():
     L.MgcgDeviceSynchronize()
     for _ in range(2):
         L.Dot(blas, y.ToRawPtr(), x.ToRawPtr(), N)
+    L.MgcgSetMatrixCompression(sparse, a.compression)
     for v in a.variants.split(","):
         k, rows, flags = (int(t) for t in v.split(":"))
         L.MgcgSetSpmvKernel(sparse, k)

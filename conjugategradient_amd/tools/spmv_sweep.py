@@ -76,7 +76,7 @@ def main():
         return L.MgcgEventElapsedMs(ev0, ev1) / a.reps
 
     if a.ablate:
-        base = [v for v in variants if v[0] in ("wg256 R128", "wave R64 g4096", "wave R64 band", "wg256 band 64Lx1", "wave R64 g4096 nt", "dcsr", "rows") or v[0].startswith(("rows g", "dcsr g"))]
+        base = [v for v in variants if v[0] in ("wg256 R128", "wave R64 g4096", "wave R64 band", "wg256 band 64Lx1", "wave R64 g4096 nt", "dcsr", "rows", "DOT pattern") or v[0].startswith(("rows g", "dcsr g"))]
         for ab, tag in ((1, "no y store"), (2, "gathers from L1"), (3, "no store + L1 gathers"), (8, "y store confined to 512 KB"), (32, "chunked")):
             if a.only_ablations and str(ab) not in a.only_ablations.split(","):
                 continue
