@@ -268,9 +268,10 @@ static int launch_rows_epi(hipStream_t s, const SpmvArgs& a, const DcsrView* m, 
 // entry slot j one LDS read of (offset, value) and one gather -- no row offsets, no column ids, no values from HBM.
 // Eight gathers per row are issued back to back before the first product is needed; products are added in stored order
 // (masked slots add +0.0, which leaves the sum's bits alone), so the result equals the CSR kernels' bit for bit.
-template <int EPI, int RPL>
+template <int EPI, int CH>
 __global__ __launch_bounds__(64) void spmv_pattern_kernel(SpmvArgs a, DcsrView m, int nRowBlocks, int groupBlocks)
 {
+    constexpr int RPL = 2;                                        // rows per lane per trip (rows r and r + 64)
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int W = m.patWidth, nP = m.nPattern;
     double* s_val = (double*)s_raw;                               // [nP * W]
@@ -320,32 +321,58 @@ __global__ __launch_bounds__(64) void spmv_pattern_kernel(SpmvArgs a, DcsrView m
         }
 #pragma unroll
         for (int u = 0; u < RPL; ++u) { eo[u] = rows_epi_prefetch<EPI>(a, row[u]); tb[u] = pid[u] * W; cnt[u] = s_cnt[pid[u]]; acc[u] = 0.0; }
-        int longest = 0;
+        int longest = 0, shortest = 0x7fffffff;
 #pragma unroll
-        for (int u = 0; u < RPL; ++u) longest = cnt[u] > longest ? cnt[u] : longest;
+        for (int u = 0; u < RPL; ++u) { longest = cnt[u] > longest ? cnt[u] : longest; shortest = cnt[u] < shortest ? cnt[u] : shortest; }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(longest, off, 64); longest = o > longest ? o : longest; }
-        for (int j0 = 0; j0 < longest; j0 += 8) {                  // wave-uniform trip count
-            double xg[RPL][8], vv[RPL][8];
+        for (int off = 32; off > 0; off >>= 1) {
+            const int o = __shfl_xor(longest, off, 64), q = __shfl_xor(shortest, off, 64);
+            longest = o > longest ? o : longest; shortest = q < shortest ? q : shortest;
+        }
+        if (shortest == CH && longest == CH) {
+            // every row of the block is a full-length row (the interior of a stencil): CH gathers per row, no masks
+            double xg[RPL][CH], vv[RPL][CH];
 #pragma unroll
             for (int u = 0; u < RPL; ++u) {
                 const long long g = m.rowBase + row[u];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bool on = j0 + j < cnt[u];
-                    const int t = tb[u] + (on ? j0 + j : 0);       // masked slots re-read the row's first entry
-                    vv[u][j] = s_val[t];
-                    xg[u][j] = a.x[g + s_delta[t]];
+                for (int j = 0; j < CH; ++j) {
+                    vv[u][j] = s_val[tb[u] + j];
+                    long long col = g + s_delta[tb[u] + j];
+                    if (a.ablate & 2) col &= 1023;                 // diagnostics: gathers served from L1
+                    xg[u][j] = a.x[col];
                 }
             }
 #pragma unroll
             for (int u = 0; u < RPL; ++u)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const double p = vv[u][j] * xg[u][j]; acc[u] += (j0 + j < cnt[u]) ? p : 0.0; }
+                for (int j = 0; j < CH; ++j) { const double p = vv[u][j] * xg[u][j]; acc[u] += p; }
+        } else {
+            for (int j0 = 0; j0 < longest; j0 += CH) {             // wave-uniform trip count
+                double xg[RPL][CH], vv[RPL][CH];
+#pragma unroll
+                for (int u = 0; u < RPL; ++u) {
+                    const long long g = m.rowBase + row[u];
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        const bool on = j0 + j < cnt[u];
+                        const int t = tb[u] + (on ? j0 + j : 0);   // masked slots re-read the row's first entry
+                        vv[u][j] = s_val[t];
+                        xg[u][j] = a.x[g + s_delta[t]];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < RPL; ++u)
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) { const double p = vv[u][j] * xg[u][j]; acc[u] += (j0 + j < cnt[u]) ? p : 0.0; }
+            }
         }
 #pragma unroll
         for (int u = 0; u < RPL; ++u)
-            if (live[u]) a.y[row[u]] = rows_epilogue_value<EPI>(a, acc[u], eo[u], dotacc);
+            if (live[u]) {
+                const double v = rows_epilogue_value<EPI>(a, acc[u], eo[u], dotacc);
+                if (!(a.ablate & 1) || v == 1.2345e300) a.y[row[u]] = v;       // (bit0: diagnostics, no y store)
+            }
     }
     if constexpr (epi_has_dot(EPI)) {
         double v = dotacc;
@@ -360,11 +387,6 @@ static int pattern_group_blocks()
     static int v = [] { const char* e = getenv("MGCG_PATTERN_GROUP"); const int r = e ? atoi(e) : 0; return (r >= 0 && r <= 65536) ? r : 0; }();
     return v;
 }
-static int pattern_rows_per_lane()
-{
-    static int v = [] { const char* e = getenv("MGCG_PATTERN_RPL"); const int r = e ? atoi(e) : 2; return (r == 1 || r == 2 || r == 4) ? r : 2; }();
-    return v;
-}
 static int pattern_waves_per_cu()
 {
     static int v = [] { const char* e = getenv("MGCG_PATTERN_WAVES"); const int r = e ? atoi(e) : 16; return (r >= 1 && r <= 32) ? r : 16; }();
@@ -374,8 +396,7 @@ static int pattern_waves_per_cu()
 template <int EPI>
 static int launch_pattern_epi(hipStream_t s, const SpmvArgs& a, const DcsrView& m, int gridReq)
 {
-    const int rpl = pattern_rows_per_lane();
-    const int nRowBlocks = (int)(((long long)a.rowCount + 64 * rpl - 1) / (64 * rpl));
+    const int nRowBlocks = (int)(((long long)a.rowCount + 127) / 128);
     DeviceState* d = device_state();
     int grid = gridReq > 0 ? gridReq : pattern_waves_per_cu() * (d ? d->numCu : kNumCu);
     if (grid > kMaxPartials) grid = kMaxPartials;
@@ -383,9 +404,10 @@ static int launch_pattern_epi(hipStream_t s, const SpmvArgs& a, const DcsrView& 
     if (grid < 1) grid = 1;
     const size_t lds = (size_t)m.nPattern * m.patWidth * 12 + (size_t)m.nPattern * 4;
     const int group = (grid % 8 == 0 && nRowBlocks >= 64 * 8) ? pattern_group_blocks() : 0;
-    if (rpl == 1) hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 1>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks, group);
-    else if (rpl == 4) hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 4>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks, group);
-    else hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 2>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks, group);
+    // slots per pass = the longest row when it is 5 or 7 (the 2-D / 3-D stencils), else 8
+    if (m.patWidth == 7) hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 7>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks, group);
+    else if (m.patWidth == 5) hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 5>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks, group);
+    else hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 8>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks, group);
     return grid;
 }
 

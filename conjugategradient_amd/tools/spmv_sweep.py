@@ -76,8 +76,8 @@ def main():
         return L.MgcgEventElapsedMs(ev0, ev1) / a.reps
 
     if a.ablate:
-        base = [v for v in variants if v[0] in ("wg256 R128", "wave R64 g4096", "wave R64 band", "wg256 band 64Lx1", "wave R64 g4096 nt", "dcsr", "rows", "DOT pattern") or v[0].startswith(("rows g", "dcsr g"))]
-        for ab, tag in ((1, "no y store"), (2, "gathers from L1"), (3, "no store + L1 gathers"), (8, "y store confined to 512 KB"), (32, "chunked")):
+        base = [v for v in variants if v[0] in ("wg256 R128", "wave R64 g4096", "wave R64 band", "wg256 band 64Lx1", "wave R64 g4096 nt", "dcsr", "rows", "pattern", "DOT pattern") or v[0].startswith(("rows g", "dcsr g", "pattern g"))]
+        for ab, tag in ((1, "no y store"), (2, "gathers from L1"), (3, "no store + L1 gathers"), (8, "y store confined to 512 KB"), (128, "64-bit gather addresses")):
             if a.only_ablations and str(ab) not in a.only_ablations.split(","):
                 continue
             for v in base:
