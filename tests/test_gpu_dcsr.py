@@ -152,3 +152,63 @@ def test_compressed_multirank(oracle, monkeypatch, mode):
         x[off: off + cnt] = xs
         assert it == ref["iteration"]
     assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
+
+
+def _stencil27(n):
+    """27-point stencil on an n^3 box (tensor product of 1-D [1 4 1] masses with a shifted diagonal): rows of up to 27
+    entries, 27 distinct rows-as-sequences."""
+    import scipy.sparse as sp
+    t = sp.diags([1.0, 4.0, 1.0], [-1, 0, 1], shape=(n, n))
+    A = (sp.kron(sp.kron(t, t), t) + 100.0 * sp.identity(n**3)).tocsr()
+    A.sort_indices()
+    return problems.LinearSystem(A.data.copy(), A.indices.astype(np.int32), A.indptr.astype(np.int32), np.zeros(n**3), np.ones(n**3), "stencil27", grid=(n, n, n))
+
+
+def test_row_patterns_with_long_rows_and_many_passes(oracle):
+    """Rows longer than one pass of the kernel (27 entries: four passes of 8 slots, the last one masked), mixed with
+    shorter boundary rows in the same wavefront."""
+    L = _lib.lib()
+    s = _stencil27(9)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(s.Count)
+    ref = oracle.spmv(s.Elements, s.ColumnIndeces, s.RowOffsets, x)
+    h = Handles()
+    A = DeviceCsr(s)
+    L.MgcgSetMatrixCompression(h.sparse, 1)
+    assert np.array_equal(A.spmv(h, x), ref)
+    cls, nrows_distinct, longest, rows, nnz = _info(h.sparse)
+    assert (cls, nrows_distinct, longest) == (3, 27, 27)
+    y0 = rng.standard_normal(s.Count)
+    assert np.array_equal(A.spmv(h, x, alpha=0.5, beta=-2.0, y0=y0), 0.5 * ref + -2.0 * y0)
+    h.close()
+    # whole solve through the same form: the oracle's iteration count and x
+    r = oracle.cg(s, rule=oracle.RULE_CSHARP, max_iteration=200)
+    cg = ConjugateGradientSingleGpu(s.Count, 27, 0, 200, 1e-8, rule=_lib.RULE_CSHARP).load(s)
+    L.MgcgSetMatrixCompression(cg.cusparse, 1)
+    cg.Initialize()
+    cg.Solve()
+    cg.Read()
+    assert _info(cg.cusparse)[0] == 3
+    assert cg.Iteration == r["iteration"] and np.abs(cg.x - r["x"]).max() <= 1e-10 * np.abs(r["x"]).max()
+    cg.Dispose()
+
+
+def test_too_many_distinct_rows_fall_back_to_codes_or_csr(oracle):
+    """257+ distinct rows: the row-pattern analysis declines, the per-nonzero codes take over (few offsets), and a matrix
+    with neither property stays in CSR -- results identical in every case."""
+    L = _lib.lib()
+    s = problems.poisson(20, 17, 13)
+    rng = np.random.default_rng(2)
+    vals = s.Elements.copy()
+    diag = s.ColumnIndeces == np.repeat(np.arange(s.Count), np.diff(s.RowOffsets))
+    vals[diag] = 6.0 + (np.arange(s.Count) % 300)              # 300 distinct diagonals: 300+ distinct rows, 301 distinct values
+    t = problems.LinearSystem(vals, s.ColumnIndeces, s.RowOffsets, s.x, s.b, "poisson-300-diagonals", grid=s.grid)
+    x = rng.standard_normal(t.Count)
+    ref = oracle.spmv(t.Elements, t.ColumnIndeces, t.RowOffsets, x)
+    h = Handles()
+    A = DeviceCsr(t)
+    L.MgcgSetMatrixCompression(h.sparse, 1)
+    assert np.array_equal(A.spmv(h, x), ref)
+    cls, nd, nv, _, _ = _info(h.sparse)
+    assert (cls, nd) == (1, 7) and nv == 0                     # offsets coded, values stay fp64
+    h.close()
