@@ -30,3 +30,23 @@ def test_mgcg_main_driver(oracle, devices):
     w = (np.arange(count) % 7) + 1.0
     assert abs(rec["checksum"] - float(np.dot(ref["x"], w))) <= 1e-9 * abs(rec["checksum"])
     assert abs(rec["x0"] - ref["x"][0]) <= 1e-10 * abs(ref["x"][0]) and abs(rec["xlast"] - ref["x"][-1]) <= 1e-10 * abs(ref["x"][-1])
+
+
+def test_other_two_driver_families_in_cpp(oracle):
+    """host/MgcgFrontends.hpp + MgcgCLMain: the HandmadeCL ELL builder with the max-norm rule and the ViennaCL dictionary
+    builder with the relative rule, filled by the reference drivers' loops in C++, against the oracle's same rules."""
+    exe = os.path.join(ROOT, "conjugategradient_amd", "host", "MgcgCLMain")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe)])
+    count = 2345
+    out = subprocess.run([exe, str(count)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    rec = {l.split()[0]: l.split()[1:] for l in out.stdout.splitlines() if l.split() and l.split()[0] in ("handmadecl", "viennacl")}
+    s = problems.mgcg_main(count, 160)
+    ref = oracle.cg(s, rule=oracle.RULE_HANDMADECL, allowable_residual=1e-4, min_iteration=50, max_iteration=count)
+    assert int(rec["handmadecl"][0]) == ref["iteration"]
+    assert abs(float(rec["handmadecl"][2]) - ref["x"].sum()) <= 1e-9 * np.abs(ref["x"]).sum()
+    v = problems.viennacl_main(count, 160)
+    ref = oracle.cg(v, rule=oracle.RULE_VIENNACL, allowable_residual=1e-4, min_iteration=0, max_iteration=count, hard_cap=count + 10)
+    assert int(rec["viennacl"][0]) == ref["iteration"] + 1
+    assert abs(float(rec["viennacl"][2]) - ref["x"].sum()) <= 1e-9 * np.abs(ref["x"]).sum()
