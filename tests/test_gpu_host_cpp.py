@@ -50,3 +50,28 @@ def test_other_two_driver_families_in_cpp(oracle):
     ref = oracle.cg(v, rule=oracle.RULE_VIENNACL, allowable_residual=1e-4, min_iteration=0, max_iteration=count, hard_cap=count + 10)
     assert int(rec["viennacl"][0]) == ref["iteration"] + 1
     assert abs(float(rec["viennacl"][2]) - ref["x"].sum()) <= 1e-9 * np.abs(ref["x"]).sum()
+
+
+def test_command_line_driver(oracle):
+    """host/mgcg_solve.cpp: flags instead of the reference's compile-time constants; CG and MGCG on a Poisson grid, each
+    against the oracle's iteration count and solution sum."""
+    exe = os.path.join(ROOT, "conjugategradient_amd", "host", "mgcg_solve")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe)])
+
+    def run(*flags):
+        out = subprocess.run([exe, *flags], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        return json.loads(out.stdout.splitlines()[-1])
+
+    s = problems.poisson(16, 16, 16)
+    ref = oracle.cg(s, rule=oracle.RULE_CSHARP, max_iteration=s.Count)
+    rec = run("--n", "16", "--rule", "csharp", "--compression", "0")
+    assert rec["iteration"] == ref["iteration"] == 43                       # SURVEY.md section 8c scratch count
+    assert abs(rec["sum_x"] - ref["x"].sum()) <= 1e-9 * np.abs(ref["x"]).sum()
+    mref = oracle.Multigrid(s, levels=3).pcg(rule=oracle.RULE_CSHARP, max_iteration=400)
+    rec = run("--n", "16", "--mgcg", "--levels", "3", "--compression", "1")
+    assert rec["levels"] == 3 and rec["iteration"] == mref["iteration"]
+    assert abs(rec["sum_x"] - mref["x"].sum()) <= 1e-9 * np.abs(mref["x"]).sum()
+    bad = subprocess.run([exe, "--rule", "nonsense"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "unknown --rule" in bad.stderr
