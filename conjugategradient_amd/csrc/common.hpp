@@ -179,6 +179,17 @@ struct SpmvArgs {
     int ablate;              // diagnostics only (tools/spmv_sweep.py --ablate): bit0 skip the y store, bit1 gathers from L1
 };
 
+// Kernel family by average row length (measured on banded and random matrices, profiles/r1/rowlen_sweep.log):
+// 9 row-block "lane = row" form, 1 row-block stream form, 5 / 6 / 7 = 8 / 16 / 32 lanes per row.
+inline int spmv_auto_kernel(double avgRow)
+{
+    if (avgRow <= 8.0) return 9;
+    if (avgRow <= 20.0) return 1;
+    if (avgRow <= 28.0) return 5;
+    if (avgRow <= 56.0) return 6;
+    return 7;
+}
+
 struct SpmvConfig { int kernel = 0; int rowsPerBlock = 64; int flags = 0; int gridBlocks = 0; int periodRows = 0; int tileRows = 0; int tilePlanes = 0; };
 
 // Launches the SpMV; returns the number of partials written (grid size) for dot epilogues.

@@ -497,11 +497,7 @@ static int launch_spmv_epi(hipStream_t s, const SpmvArgs& a, const SpmvConfig& c
 {
     int kernel = cfg.kernel;
     if (kernel == 0) {
-        const double avg = a.rowCount > 0 ? (double)a.elementsCount / (double)a.rowCount : 0.0;
-        if (avg <= 24.0) kernel = 9;        // short rows: row-block kernel (falls back to the stream form for unaligned arrays)
-        else if (avg <= 48.0) kernel = 6;   // 16 lanes per row
-        else if (avg <= 96.0) kernel = 7;   // 32 lanes per row
-        else kernel = 8;                    // one wavefront per row
+        kernel = spmv_auto_kernel(a.rowCount > 0 ? (double)a.elementsCount / (double)a.rowCount : 0.0);
     }
     if (kernel == 9) {      // row-block kernel, "stage raw, multiply by row" form; same alignment needs as the stream kernel's wide path
         const bool ok = (((uintptr_t)a.elements & 15) == 0) && (((uintptr_t)a.columnIndeces & 7) == 0) && a.elementsCount >= 8;

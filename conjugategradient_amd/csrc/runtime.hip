@@ -84,6 +84,7 @@ bool Workspace::init()
 }
 void Workspace::destroy()
 {
+    if (stream) (void)hipStreamSynchronize(stream);     // nothing enqueued may still use what is freed below
     if (partials) (void)hipFree(partials);
     if (scalars) (void)hipFree(scalars);
     if (mirror) (void)hipHostFree((void*)mirror);
@@ -155,8 +156,7 @@ int launch_spmv_range(hipStream_t s, int epilogue, const SpmvArgs& whole, const 
         return launch_spmv_rows(s, epilogue, a, &v, c.gridBlocks);
     }
     if (c.kernel == 0) {                                 // the kernel choice follows the whole matrix, not the slice
-        const double avg = whole.rowCount > 0 ? (double)whole.elementsCount / (double)whole.rowCount : 0.0;
-        c.kernel = avg <= 24.0 ? 9 : avg <= 48.0 ? 6 : avg <= 96.0 ? 7 : 8;
+        c.kernel = spmv_auto_kernel(whole.rowCount > 0 ? (double)whole.elementsCount / (double)whole.rowCount : 0.0);
     }
     return launch_spmv(s, epilogue, a, c);
 }
@@ -248,7 +248,10 @@ MgcgSparse* CreateSparse(void)
 void DestroySparse(MgcgSparse* h)
 {
     if (!h) return;
+    if (h->ws.stream) (void)hipStreamSynchronize(h->ws.stream);      // kernels that still read the analysed forms
     for (auto* m : h->analysed) { m->release(); delete m; }
+    for (hipEvent_t e : h->prof.start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->prof.stop) (void)hipEventDestroy(e);
     h->ws.destroy();
     delete h;
 }
