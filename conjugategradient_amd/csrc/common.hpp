@@ -103,6 +103,13 @@ struct DcsrView {
     const int* patDelta;             // [nPattern * patWidth]
     const double* patValue;          // [nPattern * patWidth]
     int nPattern, patWidth;
+    // column-tiled form (class 4): nonzeros re-laid out by column tile, row-major inside a tile
+    const double* tileVals;          // nullptr: not tiled; else the nonzeros in tile-major, row-major order ...
+    const int* tileCols;             // ... their column ids ...
+    const int* tileRowIds;           // ... and (local) row ids
+    const int* tileStartHost;        // HOST array [nTiles + 1]: first entry of every tile
+    int nTiles;
+    long long tileRows;              // rows of the analysed matrix
 };
 // ... and what the handle caches per analysed matrix (keyed by the CSR pointers and sizes).
 struct DcsrMatrix {
@@ -113,12 +120,15 @@ struct DcsrMatrix {
     int nDelta = 0, nValue = 0;
     unsigned char* patternId = nullptr; int* patCount = nullptr; int* patDelta = nullptr; double* patValue = nullptr;
     int nPattern = 0, patWidth = 0;
+    double* tileVals = nullptr; int* tileCols = nullptr; int* tileRowIds = nullptr; int nTiles = 0; long long tileRows = 0;
+    std::vector<int> tileStart;
     bool usable = false;
     void release();
     DcsrView view() const
     {
         DcsrView v; v.colCode = colCode; v.valCode = valCode; v.deltaDict = deltaDict; v.valueDict = valueDict; v.nDelta = nDelta; v.nValue = nValue; v.rowBase = rowBase;
         v.patternId = patternId; v.patCount = patCount; v.patDelta = patDelta; v.patValue = patValue; v.nPattern = nPattern; v.patWidth = patWidth;
+        v.tileVals = tileVals; v.tileCols = tileCols; v.tileRowIds = tileRowIds; v.tileStartHost = tileStart.data(); v.nTiles = nTiles; v.tileRows = tileRows;
         return v;
     }
 };
@@ -201,9 +211,14 @@ bool dcsr_build(hipStream_t s, const double* elements, const int* rowOffsets, co
 // Row-pattern form: usable (out->patternId != nullptr) when the matrix has <= 256 distinct rows-as-sequences.
 bool pattern_build(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces,
                    long long rows, long long nnz, long long rowBase, DcsrMatrix* out);
+// Column-tiled form: usable (out->tileVals != nullptr) for sorted rows whose entries lie far from the diagonal when x
+// (columns doubles) does not fit a few L2s.
+bool tiled_build(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces,
+                 long long rows, long long nnz, long long rowBase, long long columns, DcsrMatrix* out);
+int launch_spmv_tiled(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView& m);
 // Cached analysis of a matrix on a handle (nullptr: compression off, not applicable, or the build failed).
 const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* rowOffsets, const int* columnIndeces,
-                              long long rows, long long nnz, long long rowBase);
+                              long long rows, long long nnz, long long rowBase, long long columns = 0);   // columns: length of x (0: unknown, no column tiling)
 // CSR or compressed, whichever the handle has for this matrix.
 int launch_spmv_auto(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg, const DcsrMatrix* dc);
 // Rows [r0, r1) of the same matrix (a describes the WHOLE local matrix; y, w, b, dinv are shifted here); partials for

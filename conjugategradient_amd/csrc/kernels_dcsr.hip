@@ -211,6 +211,10 @@ void DcsrMatrix::release()
     if (patCount) (void)hipFree(patCount);
     if (patDelta) (void)hipFree(patDelta);
     if (patValue) (void)hipFree(patValue);
+    if (tileVals) (void)hipFree(tileVals);
+    if (tileCols) (void)hipFree(tileCols);
+    if (tileRowIds) (void)hipFree(tileRowIds);
+    tileVals = nullptr; tileCols = nullptr; tileRowIds = nullptr; nTiles = 0; tileRows = 0; tileStart.clear();
     colCode = valCode = nullptr; deltaDict = nullptr; valueDict = nullptr; nDelta = nValue = 0;
     patternId = nullptr; patCount = nullptr; patDelta = nullptr; patValue = nullptr; nPattern = patWidth = 0;
     usable = false;

@@ -1,0 +1,298 @@
+// Column-tiled form for matrices whose gathers have no locality (class 4 of the opt-in analysis; BASELINE config 5:
+// random SPD, 10 M rows, ~31 nonzeros per row spread over the whole column range).
+//
+// On such a matrix the CSR kernels are bound by the gathers: x (80 MB) lives beyond the 4 MB L2 of an XCD, every 8-byte
+// gather pulls a 128-byte line through the fabric (40 GB per product instead of 3.9 GB of algorithmic bytes,
+// profiles/r1/config5_random_spd_10M.log).  Here the nonzeros are re-laid out ONCE by column tile (tile = a window of
+// x that stays in L2), row-major inside a tile, each entry with its row id, and the product runs tile by tile: pass t
+// multiplies tile t's entries ENTRY-parallel (coalesced streams of values, column ids and row ids; gathers only from the
+// tile's x window), the first entry of every (row, tile) segment then adds the segment's products to y[row] one after the
+// other.  For rows stored with ascending column ids -- the analysis requires it -- the tiles of a row are visited in
+// stored order and the running sum continues where the previous tile stopped, so every row is summed in exactly the
+// order of the CSR kernels: bit-identical results.  A last pass over the rows applies the epilogue.
+// Cost: one more copy of the matrix (16 B/nnz) and y is read and written once per (row, tile) segment.
+#include "common.hpp"
+#include <algorithm>
+
+namespace mgcg {
+
+constexpr int kScanBlock = 256;
+constexpr int kScanPer = 8;                    // elements per thread in the scan kernels
+
+// ---------------------------------------------------------------- analysis
+// One pass over the rows: are the column ids of every row ascending?  how far from the diagonal is the typical entry?
+// and counts[t * rows + i] = entries of row i in column tile t.
+__global__ __launch_bounds__(kBlock) void tiled_count_kernel(const int* __restrict__ rowOffsets, const int* __restrict__ columnIndeces,
+                                                             long long rows, long long rowBase, int tileShift, int nTiles,
+                                                             int* __restrict__ counts, unsigned long long* stats /* [0] unsorted rows, [1] sum |col-row| >> 10 */)
+{
+    const long long stride = (long long)gridDim.x * kBlock;
+    unsigned long long far = 0, unsorted = 0;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < rows; i += stride) {
+        const int s = rowOffsets[i], e = rowOffsets[i + 1];
+        int prev = -1, tile = -1, run = 0;
+        for (int k = s; k < e; ++k) {
+            const int c = columnIndeces[k];
+            if (c <= prev) unsorted = 1;
+            prev = c;
+            const long long d = (long long)c - (rowBase + i);
+            far += (unsigned long long)((d < 0 ? -d : d) >> 10);
+            const int t = c >> tileShift;
+            if (t != tile) { if (tile >= 0 && tile < nTiles) counts[(long long)tile * rows + i] = run; tile = t; run = 0; }
+            ++run;
+        }
+        if (tile >= 0 && tile < nTiles) counts[(long long)tile * rows + i] = run;
+    }
+    if (far) atomicAdd(&stats[1], far);
+    if (unsorted) atomicAdd(&stats[0], 1ull);
+}
+
+// exclusive scan of n ints in three steps (block-local scan, scan of the block totals, add-back); totals fit int (nnz < 2^31)
+__global__ __launch_bounds__(kScanBlock) void scan_local_kernel(int* __restrict__ data, long long n, int* __restrict__ blockTotals)
+{
+    __shared__ int s_sum[kScanBlock];
+    const long long base = ((long long)blockIdx.x * kScanBlock + threadIdx.x) * kScanPer;
+    int v[kScanPer], total = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) { v[j] = (base + j < n) ? data[base + j] : 0; total += v[j]; }
+    s_sum[threadIdx.x] = total;
+    __syncthreads();
+    for (int off = 1; off < kScanBlock; off <<= 1) {                // Hillis-Steele over the thread totals
+        const int add = threadIdx.x >= off ? s_sum[threadIdx.x - off] : 0;
+        __syncthreads();
+        s_sum[threadIdx.x] += add;
+        __syncthreads();
+    }
+    int run = s_sum[threadIdx.x] - total;                            // exclusive prefix of this thread inside the block
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) { if (base + j < n) data[base + j] = run; run += v[j]; }
+    if (threadIdx.x == kScanBlock - 1) blockTotals[blockIdx.x] = s_sum[kScanBlock - 1];
+}
+__global__ __launch_bounds__(kScanBlock) void scan_totals_kernel(int* __restrict__ blockTotals, int nBlocks)
+{
+    __shared__ int s_sum[kScanBlock];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nBlocks; base += kScanBlock) {         // one workgroup walks the totals
+        const int i = base + threadIdx.x;
+        const int v = i < nBlocks ? blockTotals[i] : 0;
+        s_sum[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < kScanBlock; off <<= 1) {
+            const int add = threadIdx.x >= off ? s_sum[threadIdx.x - off] : 0;
+            __syncthreads();
+            s_sum[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < nBlocks) blockTotals[i] = s_carry + s_sum[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == kScanBlock - 1) s_carry += s_sum[kScanBlock - 1];
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(kScanBlock) void scan_add_kernel(int* __restrict__ data, long long n, const int* __restrict__ blockTotals)
+{
+    const long long base = ((long long)blockIdx.x * kScanBlock + threadIdx.x) * kScanPer;
+    const int add = blockTotals[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) if (base + j < n) data[base + j] += add;
+}
+
+__global__ __launch_bounds__(kBlock) void tiled_zero_kernel(double* __restrict__ y, long long n, const int* __restrict__ doneFlag)
+{
+    if (doneFlag != nullptr && *doneFlag != 0) return;
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) y[i] = 0.0;
+}
+static int grid_rows(long long n)
+{
+    const long long blocks = (n + kBlock - 1) / kBlock;
+    return (int)(blocks < 1 ? 1 : (blocks > kMaxGrid ? kMaxGrid : blocks));
+}
+
+// entries of row i go to [ptr[t * rows + i], ...) of tile t in stored (= ascending column) order, each with its row id
+__global__ __launch_bounds__(kBlock) void tiled_scatter_kernel(const double* __restrict__ elements, const int* __restrict__ rowOffsets,
+                                                               const int* __restrict__ columnIndeces, long long rows, int tileShift,
+                                                               const int* __restrict__ ptr, double* __restrict__ tVals, int* __restrict__ tCols, int* __restrict__ tRows)
+{
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < rows; i += stride) {
+        const int s = rowOffsets[i], e = rowOffsets[i + 1];
+        int tile = -1, pos = 0;
+        for (int k = s; k < e; ++k) {
+            const int c = columnIndeces[k];
+            const int t = c >> tileShift;
+            if (t != tile) { tile = t; pos = ptr[(long long)t * rows + i]; }
+            tVals[pos] = elements[k]; tCols[pos] = c; tRows[pos] = (int)i;
+            ++pos;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- SpMV: one launch per column tile, then the epilogue
+// Entries [kBegin, kEnd) of one tile, kTileE entries per thread (entry e of thread t: blockBase + e * kBlock + t, so every
+// load is coalesced and kTileE gathers per lane are in flight).  y holds the running row sums (zeroed before the first tile).
+constexpr int kTileE = 4;
+
+__global__ __launch_bounds__(kBlock) void spmv_tile_pass_kernel(const double* __restrict__ x, double* __restrict__ y,
+                                                                const double* __restrict__ tVals, const int* __restrict__ tCols, const int* __restrict__ tRows,
+                                                                int kBegin, int kEnd, const int* __restrict__ doneFlag)
+{
+    __shared__ double s_p[kBlock * kTileE];
+    __shared__ int s_r[kBlock * kTileE];
+    if (doneFlag != nullptr && *doneFlag != 0) return;
+    const int blockBase = kBegin + (int)blockIdx.x * (kBlock * kTileE);
+    const int blockCount = (kEnd - blockBase) < kBlock * kTileE ? (kEnd - blockBase) : kBlock * kTileE;
+    double v[kTileE]; int c[kTileE], r[kTileE];
+#pragma unroll
+    for (int e = 0; e < kTileE; ++e) {
+        const int j = e * kBlock + (int)threadIdx.x;
+        const int k = blockBase + (j < blockCount ? j : 0);          // (blockCount >= 1: the grid covers the tile exactly)
+        v[e] = tVals[k]; c[e] = tCols[k]; r[e] = tRows[k];
+    }
+    double xv[kTileE];
+#pragma unroll
+    for (int e = 0; e < kTileE; ++e) xv[e] = x[c[e]];
+#pragma unroll
+    for (int e = 0; e < kTileE; ++e) {
+        const int j = e * kBlock + (int)threadIdx.x;
+        if (j < blockCount) { s_p[j] = v[e] * xv[e]; s_r[j] = r[e]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < kTileE; ++e) {
+        const int j0 = e * kBlock + (int)threadIdx.x;
+        if (j0 >= blockCount) continue;
+        const int row = r[e];
+        const int prevRow = j0 > 0 ? s_r[j0 - 1] : (blockBase > kBegin ? tRows[blockBase - 1] : -1);
+        if (prevRow == row) continue;                               // not the first entry of its (row, tile) segment
+        double acc = y[row];
+        int j = j0;
+        while (j < blockCount && s_r[j] == row) { acc += s_p[j]; ++j; }
+        if (j == blockCount) {                                      // the segment runs on into the next workgroup's entries
+            for (int kk = blockBase + blockCount; kk < kEnd && tRows[kk] == row; ++kk) { const double q = tVals[kk] * x[tCols[kk]]; acc += q; }
+        }
+        y[row] = acc;
+    }
+}
+
+// y[i] = epilogue(row sum y[i])  (+ partial sums of the fused dot product)
+template <int EPI>
+__global__ __launch_bounds__(kBlock) void tiled_epilogue_kernel(SpmvArgs a)
+{
+    __shared__ double s_red[4];
+    if (a.doneFlag != nullptr && *a.doneFlag != 0) return;
+    double dotacc = 0.0;
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < a.rowCount; i += stride) {
+        const double acc = a.y[i];
+        double val;
+        if constexpr (EPI == EPI_AXPBY) val = a.alpha * acc;
+        else if constexpr (EPI == EPI_DOT) { const double t = a.w[i] * acc; dotacc += t; val = acc; }
+        else if constexpr (EPI == EPI_RESIDUAL) val = a.b[i] - acc;
+        else if constexpr (EPI == EPI_RESIDUAL_DOT) { val = a.b[i] - acc; const double t = val * val; dotacc += t; }
+        else { const double res = a.b[i] - acc; const double t = a.dinv[i] * res; const double sft = a.omega * t; val = a.w[i] + sft;
+               if constexpr (EPI == EPI_JACOBI_DOT) { const double q = a.b[i] * val; dotacc += q; } }
+        if constexpr (EPI != EPI_DOT) a.y[i] = val;                  // (EPI_DOT leaves y = A x as it is)
+    }
+    if constexpr (epi_has_dot(EPI)) {
+        double v = dotacc;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) a.partials[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    }
+}
+
+template <int EPI>
+static int launch_tiled_epi(hipStream_t s, const SpmvArgs& a, const DcsrView& m)
+{
+    // the running sums start at +0.0 (0.0 + p == p exactly, the CSR kernels' start); skipped if the solve has stopped
+    hipLaunchKernelGGL(tiled_zero_kernel, dim3(grid_rows(a.rowCount)), dim3(kBlock), 0, s, a.y, (long long)a.rowCount, a.doneFlag);
+    for (int t = 0; t < m.nTiles; ++t) {
+        const int kb = m.tileStartHost[t], ke = m.tileStartHost[t + 1];
+        if (ke <= kb) continue;
+        hipLaunchKernelGGL(spmv_tile_pass_kernel, dim3((ke - kb + kBlock * kTileE - 1) / (kBlock * kTileE)), dim3(kBlock), 0, s, a.x, a.y, m.tileVals, m.tileCols, m.tileRowIds, kb, ke, a.doneFlag);
+    }
+    if (EPI == EPI_AXPBY && a.alpha == 1.0) return 0;                // y = A x is already in place
+    const int grid = grid_rows(a.rowCount);
+    hipLaunchKernelGGL((tiled_epilogue_kernel<EPI>), dim3(grid), dim3(kBlock), 0, s, a);
+    return grid;
+}
+
+// y must not be an input of the epilogue (EPI_AXPBY with beta != 0 is served by the CSR kernels)
+int launch_spmv_tiled(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView& m)
+{
+    if (a.rowCount <= 0) return 0;
+    switch (epilogue) {
+    case EPI_AXPBY:        return launch_tiled_epi<EPI_AXPBY>(s, a, m);
+    case EPI_DOT:          return launch_tiled_epi<EPI_DOT>(s, a, m);
+    case EPI_RESIDUAL:     return launch_tiled_epi<EPI_RESIDUAL>(s, a, m);
+    case EPI_RESIDUAL_DOT: return launch_tiled_epi<EPI_RESIDUAL_DOT>(s, a, m);
+    case EPI_JACOBI:       return launch_tiled_epi<EPI_JACOBI>(s, a, m);
+    case EPI_JACOBI_DOT:   return launch_tiled_epi<EPI_JACOBI_DOT>(s, a, m);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- build
+static bool exclusive_scan(hipStream_t s, int* data, long long n)
+{
+    const long long perBlock = (long long)kScanBlock * kScanPer;
+    const long long nBlocks = (n + perBlock - 1) / perBlock;
+    if (nBlocks > 0x7fffffffLL) { set_error("tiled analysis: too many scan blocks"); return false; }
+    int* totals = nullptr;
+    if (!MGCG_HIP(hipMalloc((void**)&totals, sizeof(int) * (size_t)nBlocks))) return false;
+    hipLaunchKernelGGL(scan_local_kernel, dim3((unsigned)nBlocks), dim3(kScanBlock), 0, s, data, n, totals);
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(kScanBlock), 0, s, totals, (int)nBlocks);
+    hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nBlocks), dim3(kScanBlock), 0, s, data, n, totals);
+    const bool ok = MGCG_HIP(hipGetLastError()) && MGCG_HIP(hipStreamSynchronize(s));
+    (void)hipFree(totals);
+    return ok;
+}
+
+// On success out->tileVals != nullptr says whether the tiled form exists (sorted rows, far-from-diagonal entries, an x
+// that does not fit the L2).  columns = length of x.  Leaves the other fields of *out alone.
+bool tiled_build(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces,
+                 long long rows, long long nnz, long long rowBase, long long columns, DcsrMatrix* out)
+{
+    int tileShift = 19;                                            // 2^19 columns = 4 MiB of x per tile (one XCD's L2)
+    if (const char* e = getenv("MGCG_TILE_SHIFT")) { const int v = atoi(e); if (v >= 12 && v <= 26) tileShift = v; }
+    const long long tileCols = 1LL << tileShift;
+    const int nTiles = (int)((columns + tileCols - 1) / tileCols);
+    if (rows <= 0 || nnz <= 0 || nTiles < 4 || nTiles > 256) return true;            // x fits a few L2s, or absurdly many passes
+    const long long cells = (long long)nTiles * rows;
+    int* counts = nullptr; unsigned long long* stats = nullptr;
+    double* tv = nullptr; int* tc = nullptr; int* tr = nullptr;
+    bool ok = MGCG_HIP(hipMalloc((void**)&counts, sizeof(int) * (size_t)(cells + 1))) && MGCG_HIP(hipMalloc((void**)&stats, 2 * sizeof(unsigned long long)));
+    ok = ok && MGCG_HIP(hipMemsetAsync(counts, 0, sizeof(int) * (size_t)(cells + 1), s)) && MGCG_HIP(hipMemsetAsync(stats, 0, 2 * sizeof(unsigned long long), s));
+    auto fail = [&](bool hard) { if (counts) (void)hipFree(counts); if (stats) (void)hipFree(stats); if (tv) (void)hipFree(tv); if (tc) (void)hipFree(tc); if (tr) (void)hipFree(tr); return !hard; };
+    if (!ok) return fail(true);
+    long long blocks = (rows + kBlock - 1) / kBlock;
+    if (blocks > kMaxGrid) blocks = kMaxGrid;
+    hipLaunchKernelGGL(tiled_count_kernel, dim3((int)blocks), dim3(kBlock), 0, s, rowOffsets, columnIndeces, rows, rowBase, tileShift, nTiles, counts, stats);
+    unsigned long long hs[2] = { 0, 0 };
+    ok = MGCG_HIP(hipMemcpyAsync(hs, stats, sizeof(hs), hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
+    if (!ok) return fail(true);
+    const double meanDistance = (double)hs[1] * 1024.0 / (double)nnz;
+    if (hs[0] != 0 || meanDistance < (double)tileCols) return fail(false);            // unsorted rows, or gathers that are local anyway
+    if (!exclusive_scan(s, counts, cells + 1)) return fail(true);
+    ok = MGCG_HIP(hipMalloc((void**)&tv, sizeof(double) * (size_t)nnz)) && MGCG_HIP(hipMalloc((void**)&tc, sizeof(int) * (size_t)nnz)) &&
+         MGCG_HIP(hipMalloc((void**)&tr, sizeof(int) * (size_t)nnz));
+    if (!ok) return fail(true);
+    hipLaunchKernelGGL(tiled_scatter_kernel, dim3((int)blocks), dim3(kBlock), 0, s, elements, rowOffsets, columnIndeces, rows, tileShift, counts, tv, tc, tr);
+    std::vector<int> starts((size_t)nTiles + 1, 0);                  // first entry of every tile = the flat scan at (tile, row 0)
+    ok = MGCG_HIP(hipGetLastError());
+    for (int t = 0; ok && t <= nTiles; ++t)
+        ok = MGCG_HIP(hipMemcpyAsync(&starts[(size_t)t], counts + (long long)t * rows, sizeof(int), hipMemcpyDeviceToHost, s));
+    ok = ok && MGCG_HIP(hipStreamSynchronize(s));
+    if (!ok) return fail(true);
+    if ((long long)starts[(size_t)nTiles] != nnz) { set_error("tiled analysis: %d of %lld nonzeros placed", starts[(size_t)nTiles], nnz); return fail(true); }
+    (void)hipFree(stats); (void)hipFree(counts);
+    out->tileVals = tv; out->tileCols = tc; out->tileRowIds = tr; out->nTiles = nTiles; out->tileRows = rows; out->tileStart = starts;
+    return true;
+}
+
+} // namespace mgcg

@@ -46,7 +46,7 @@ void CsrMV(MgcgSparse* cusparse, MgcgMatDescr* matDescr, double* y,
     a.elements = elements; a.rowOffsets = rowOffsets; a.columnIndeces = columnIndeces; a.x = x; a.y = y;
     a.elementsCount = elementsCount; a.rowCount = rowCount; a.columnCount = columnCount; a.alpha = alpha; a.beta = beta;
     if (const char* ab = getenv("MGCG_SPMV_ABLATE")) a.ablate = atoi(ab);     // timing diagnostics only (wrong results)
-    const DcsrMatrix* dc = dcsr_lookup(cusparse, elements, rowOffsets, columnIndeces, rowCount, elementsCount, 0);
+    const DcsrMatrix* dc = dcsr_lookup(cusparse, elements, rowOffsets, columnIndeces, rowCount, elementsCount, 0, columnCount);
     launch_spmv_auto(cusparse->ws.stream, EPI_AXPBY, a, cfg_of(cusparse), dc);
     (void)MGCG_HIP(hipGetLastError());
 }
@@ -62,7 +62,7 @@ double CsrMVDot(MgcgBlas* cublas, MgcgSparse* cusparse, double* y,
     if (const char* ab = getenv("MGCG_SPMV_ABLATE")) a.ablate = atoi(ab);     // timing diagnostics only
     a.elements = elements; a.rowOffsets = rowOffsets; a.columnIndeces = columnIndeces; a.x = x; a.y = y;
     a.elementsCount = elementsCount; a.rowCount = rowCount; a.columnCount = columnCount; a.w = w; a.partials = cublas->ws.partials;
-    const DcsrMatrix* dc = dcsr_lookup(cusparse, elements, rowOffsets, columnIndeces, rowCount, elementsCount, 0);
+    const DcsrMatrix* dc = dcsr_lookup(cusparse, elements, rowOffsets, columnIndeces, rowCount, elementsCount, 0, columnCount);
     const int n = launch_spmv_auto(cublas->ws.stream, EPI_DOT, a, cfg_of(cusparse), dc);
     return finish_reduction(cublas->ws, n, 0);
 }

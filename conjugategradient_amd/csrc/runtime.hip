@@ -103,7 +103,7 @@ bool Workspace::ensure_trace(int cap)
 }
 
 const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* rowOffsets, const int* columnIndeces,
-                              long long rows, long long nnz, long long rowBase)
+                              long long rows, long long nnz, long long rowBase, long long columns)
 {
     if (!h || h->compression == 0) return nullptr;
     for (const DcsrMatrix* m : h->analysed)
@@ -111,16 +111,20 @@ const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* 
             return m->usable ? m : nullptr;
     if (rows <= 0 || nnz < 8) return nullptr;
     const double avg = (double)nnz / (double)rows;
-    if (avg > 32.0) return nullptr;
+    if (avg > 64.0) return nullptr;
     DcsrMatrix* m = new DcsrMatrix();
     auto identify = [&] { m->elements = elements; m->rowOffsets = rowOffsets; m->columnIndeces = columnIndeces; m->rows = rows; m->nnz = nnz; m->rowBase = rowBase; };
     identify();
     // 1. one byte per row (few distinct rows-as-sequences), 2. one or two bytes per nonzero (few distinct offsets / values;
     //    the wide loads of that kernel need 16-byte aligned values and short average rows: one pass per 64-row block)
-    if (h->compression == 1 && pattern_build(h->ws.stream, elements, rowOffsets, columnIndeces, rows, nnz, rowBase, m) && m->patternId != nullptr) {
+    // 3. a column-tiled copy for matrices whose gathers have no locality (sorted rows, entries far from the diagonal)
+    if (h->compression == 1 && avg <= 32.0 && pattern_build(h->ws.stream, elements, rowOffsets, columnIndeces, rows, nnz, rowBase, m) && m->patternId != nullptr) {
         m->usable = true;
     } else if ((((uintptr_t)elements) & 15) == 0 && avg <= 7.75) {
         if (!dcsr_build(h->ws.stream, elements, rowOffsets, columnIndeces, rows, nnz, rowBase, m)) { m->release(); identify(); }
+    }
+    if (!m->usable && h->compression == 1 && columns > 0) {
+        if (tiled_build(h->ws.stream, elements, rowOffsets, columnIndeces, rows, nnz, rowBase, columns, m) && m->tileVals != nullptr) m->usable = true;
     }
     h->analysed.push_back(m);
     return m->usable ? m : nullptr;
@@ -128,7 +132,11 @@ const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* 
 
 int launch_spmv_auto(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg, const DcsrMatrix* dc)
 {
-    if (dc != nullptr && dc->usable && a.elementsCount >= 8) { const DcsrView v = dc->view(); return launch_spmv_rows(s, epilogue, a, &v, cfg.gridBlocks); }
+    if (dc != nullptr && dc->usable && a.elementsCount >= 8) {
+        const DcsrView v = dc->view();
+        if (v.tileVals == nullptr) return launch_spmv_rows(s, epilogue, a, &v, cfg.gridBlocks);
+        if (!(epilogue == EPI_AXPBY && a.beta != 0.0)) return launch_spmv_tiled(s, epilogue, a, v);   // (beta != 0 reads y: CSR kernels)
+    }
     return launch_spmv(s, epilogue, a, cfg);
 }
 
@@ -153,6 +161,10 @@ int launch_spmv_range(hipStream_t s, int epilogue, const SpmvArgs& whole, const 
         DcsrView v = dc->view();
         v.rowBase += r0;
         if (v.patternId) v.patternId += r0;
+        if (v.tileVals != nullptr) {                                            // the tiled passes cover whole matrices only: CSR kernels for a row range
+            if (c.kernel == 0) c.kernel = spmv_auto_kernel(whole.rowCount > 0 ? (double)whole.elementsCount / (double)whole.rowCount : 0.0);
+            return launch_spmv(s, epilogue, a, c);
+        }
         return launch_spmv_rows(s, epilogue, a, &v, c.gridBlocks);
     }
     if (c.kernel == 0) {                                 // the kernel choice follows the whole matrix, not the slice
@@ -283,6 +295,7 @@ int MgcgAnalysisInfo(MgcgSparse* h, int index, int* distinctOffsets, int* distin
     if (rows) *rows = m->rows;
     if (nnz) *nnz = m->nnz;
     if (!m->usable) return 0;
+    if (m->tileVals != nullptr) { if (distinctOffsets) *distinctOffsets = m->nTiles; if (distinctValues) *distinctValues = 0; return 4; }   // class 4: column tiles
     return pat ? 3 : (m->valCode ? 2 : 1);   // 3 = one byte per row, 2 = offset + value code per nonzero, 1 = offset code per nonzero, 0 = plain CSR
 }
 

@@ -105,7 +105,7 @@ extern "C" int MgcgEstimateSpectrum(MgcgBlas* cublas, MgcgSparse* cusparse,
         if (!MGCG_HIP(hipStreamSynchronize(s))) { ok = false; return NAN; }
         return ws.hostScalar[0];
     };
-    const DcsrMatrix* dc = dcsr_lookup(cusparse, elementsVector->data, rowOffsetsVector->data, columnIndecesVector->data, n, elementsCount, 0);
+    const DcsrMatrix* dc = dcsr_lookup(cusparse, elementsVector->data, rowOffsetsVector->data, columnIndecesVector->data, n, elementsCount, 0, n);
     SpmvConfig cfg; cfg.kernel = cusparse->kernel; cfg.rowsPerBlock = cusparse->rowsPerBlock; cfg.flags = cusparse->flags & ~6; cfg.gridBlocks = cusparse->gridBlocks;
 
     std::vector<double> alpha, beta(1, 0.0);               // T = tridiag(beta[1..], alpha[0..], beta[1..])

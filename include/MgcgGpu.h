@@ -205,11 +205,14 @@ void   MgcgSetSpmvTile(MgcgSparse* cusparse, int tileRows, int tilePlanes);
  *                pairs (constant-coefficient stencils: 27 for the 7-point Laplacian on a box; every Galerkin level),
  *       class 2  two bytes per nonzero when it has <= 256 distinct offsets col-row and <= 256 distinct values,
  *       class 1  one byte per nonzero + the fp64 value when only the offsets qualify,
+ *       class 4  a column-tiled copy (16 bytes per nonzero MORE, not fewer) for sorted rows whose entries are spread over
+ *                an x far larger than the L2: the gathers of a pass stay inside one 4 MiB window of x,
  *       class 0  otherwise (plain CSR kernels);
  *   enable = 2: per-nonzero codes only (classes 2 / 1 / 0);   enable = 0: off.
  * The cache is keyed by the array pointers and sizes: a caller that rewrites a matrix in place must call
  * MgcgAnalysisClear.  MgcgAnalysisInfo(index) reports a cached analysis: returns the class (-1 past the end);
- * distinctOffsets / distinctValues receive, for class 3, the number of distinct rows and the longest row. */
+ * distinctOffsets / distinctValues receive, for class 3, the number of distinct rows and the longest row; for class 4
+ * the number of column tiles and 0. */
 void   MgcgSetMatrixCompression(MgcgSparse* cusparse, int enable);
 void   MgcgAnalysisClear(MgcgSparse* cusparse);
 int    MgcgAnalysisInfo(MgcgSparse* cusparse, int index, int* distinctOffsets, int* distinctValues, long long* rows, long long* nnz);

@@ -212,3 +212,47 @@ def test_too_many_distinct_rows_fall_back_to_codes_or_csr(oracle):
     cls, nd, nv, _, _ = _info(h.sparse)
     assert (cls, nd) == (1, 7) and nv == 0                     # offsets coded, values stay fp64
     h.close()
+
+
+def test_column_tiled_form_for_matrices_without_locality(oracle, monkeypatch):
+    """Class 4 (BASELINE config 5 in miniature; MGCG_TILE_SHIFT shrinks the tile so that a 40 000-column matrix needs 10
+    tiles): sorted random rows are re-laid out by column tile, the running row sums travel through y from tile to tile
+    in stored order -- bit-identical products; unsorted rows make the analysis decline."""
+    L = _lib.lib()
+    monkeypatch.setenv("MGCG_TILE_SHIFT", "12")
+    s = problems.random_spd(40000, mean_upper=14.0, seed=3)
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(s.Count)
+    ref = oracle.spmv(s.Elements, s.ColumnIndeces, s.RowOffsets, x)
+    h = Handles()
+    A = DeviceCsr(s)
+    L.MgcgSetMatrixCompression(h.sparse, 1)
+    assert np.array_equal(A.spmv(h, x), ref)
+    cls, tiles, _, rows, nnz = _info(h.sparse)
+    assert (cls, tiles, rows, nnz) == (4, 10, s.Count, s.nnz)
+    y0 = rng.standard_normal(s.Count)
+    assert np.array_equal(A.spmv(h, x, alpha=2.0, beta=0.0, y0=y0), 2.0 * ref)
+    # beta != 0 reads y, which the tiled passes use as their accumulator: served by the CSR kernel for this row length
+    # (16 lanes per row: tree-summed, hence a tolerance)
+    np.testing.assert_allclose(A.spmv(h, x, alpha=-1.5, beta=0.25, y0=y0), -1.5 * ref + 0.25 * y0, rtol=1e-13, atol=1e-13 * np.abs(ref).max())
+    h.close()
+    # whole solve (fused p.Ap on the last tile, residual epilogue at the start)
+    s.b[:] = oracle.spmv(s.Elements, s.ColumnIndeces, s.RowOffsets, np.cos(np.arange(s.Count) * 0.01) + 2.0)
+    r = oracle.cg(s, rule=oracle.RULE_CSHARP, max_iteration=1000, trace=True)
+    cg = ConjugateGradientSingleGpu(s.Count, int(np.diff(s.RowOffsets).max()), 0, 1000, 1e-8, rule=_lib.RULE_CSHARP).load(s)
+    L.MgcgSetMatrixCompression(cg.cusparse, 1)
+    cg.Initialize()
+    cg.Solve(trace=True)
+    cg.Read()
+    assert _info(cg.cusparse)[0] == 4
+    assert cg.Iteration == r["iteration"] and np.abs(cg.x - r["x"]).max() <= 1e-10 * np.abs(r["x"]).max()
+    cg.Dispose()
+    # rows stored in descending column order: no tiling (the summation order could not be kept), still exact
+    u = problems.random_spd(40000, mean_upper=14.0, seed=3, sort_columns=False)
+    refu = oracle.spmv(u.Elements, u.ColumnIndeces, u.RowOffsets, x)
+    h = Handles()
+    B = DeviceCsr(u)
+    L.MgcgSetMatrixCompression(h.sparse, 1)
+    assert np.array_equal(B.spmv(h, x, kernel=1), refu)
+    assert _info(h.sparse)[0] in (0, -1)
+    h.close()
