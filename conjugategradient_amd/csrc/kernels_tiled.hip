@@ -135,6 +135,7 @@ __global__ __launch_bounds__(kBlock) void tiled_scatter_kernel(const double* __r
 // load is coalesced and kTileE gathers per lane are in flight).  y holds the running row sums (zeroed before the first tile).
 constexpr int kTileE = 4;
 
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void spmv_tile_pass_kernel(const double* __restrict__ x, double* __restrict__ y,
                                                                 const double* __restrict__ tVals, const int* __restrict__ tCols, const int* __restrict__ tRows,
                                                                 int kBegin, int kEnd, const int* __restrict__ doneFlag)
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(kBlock) void spmv_tile_pass_kernel(const double* __
     for (int e = 0; e < kTileE; ++e) {
         const int j = e * kBlock + (int)threadIdx.x;
         const int k = blockBase + (j < blockCount ? j : 0);          // (blockCount >= 1: the grid covers the tile exactly)
-        v[e] = tVals[k]; c[e] = tCols[k]; r[e] = tRows[k];
+        if (NT) { v[e] = __builtin_nontemporal_load(tVals + k); c[e] = __builtin_nontemporal_load(tCols + k); r[e] = __builtin_nontemporal_load(tRows + k); }
+        else { v[e] = tVals[k]; c[e] = tCols[k]; r[e] = tRows[k]; }
     }
     double xv[kTileE];
 #pragma unroll
@@ -206,6 +208,12 @@ __global__ __launch_bounds__(kBlock) void tiled_epilogue_kernel(SpmvArgs a)
     }
 }
 
+static bool tile_streams_nontemporal()
+{
+    static const bool v = [] { const char* e = getenv("MGCG_TILE_NT"); return e != nullptr && atoi(e) != 0; }();
+    return v;
+}
+
 template <int EPI>
 static int launch_tiled_epi(hipStream_t s, const SpmvArgs& a, const DcsrView& m)
 {
@@ -214,7 +222,9 @@ static int launch_tiled_epi(hipStream_t s, const SpmvArgs& a, const DcsrView& m)
     for (int t = 0; t < m.nTiles; ++t) {
         const int kb = m.tileStartHost[t], ke = m.tileStartHost[t + 1];
         if (ke <= kb) continue;
-        hipLaunchKernelGGL(spmv_tile_pass_kernel, dim3((ke - kb + kBlock * kTileE - 1) / (kBlock * kTileE)), dim3(kBlock), 0, s, a.x, a.y, m.tileVals, m.tileCols, m.tileRowIds, kb, ke, a.doneFlag);
+        const dim3 g((ke - kb + kBlock * kTileE - 1) / (kBlock * kTileE));
+        if (tile_streams_nontemporal()) hipLaunchKernelGGL(spmv_tile_pass_kernel<true>, g, dim3(kBlock), 0, s, a.x, a.y, m.tileVals, m.tileCols, m.tileRowIds, kb, ke, a.doneFlag);
+        else hipLaunchKernelGGL(spmv_tile_pass_kernel<false>, g, dim3(kBlock), 0, s, a.x, a.y, m.tileVals, m.tileCols, m.tileRowIds, kb, ke, a.doneFlag);
     }
     if (EPI == EPI_AXPBY && a.alpha == 1.0) return 0;                // y = A x is already in place
     const int grid = grid_rows(a.rowCount);
@@ -259,7 +269,7 @@ bool tiled_build(hipStream_t s, const double* elements, const int* rowOffsets, c
                  long long rows, long long nnz, long long rowBase, long long columns, DcsrMatrix* out)
 {
     int tileShift = 19;                                            // 2^19 columns = 4 MiB of x per tile (one XCD's L2)
-    if (const char* e = getenv("MGCG_TILE_SHIFT")) { const int v = atoi(e); if (v >= 12 && v <= 26) tileShift = v; }
+    if (const char* e = getenv("MGCG_TILE_SHIFT")) { const int v = atoi(e); if (v >= 8 && v <= 26) tileShift = v; }
     const long long tileCols = 1LL << tileShift;
     const int nTiles = (int)((columns + tileCols - 1) / tileCols);
     if (rows <= 0 || nnz <= 0 || nTiles < 4 || nTiles > 256) return true;            // x fits a few L2s, or absurdly many passes

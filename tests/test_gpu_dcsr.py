@@ -256,3 +256,35 @@ def test_column_tiled_form_for_matrices_without_locality(oracle, monkeypatch):
     assert np.array_equal(B.spmv(h, x, kernel=1), refu)
     assert _info(h.sparse)[0] in (0, -1)
     h.close()
+
+
+def test_column_tiles_on_row_slices_over_loopback(oracle, monkeypatch):
+    """Two ranks, unstructured matrix: every rank tiles its own row slice over the GLOBAL column range and the halo
+    degenerates to an all-gather of p; same iteration count and solution as the multi-device oracle."""
+    from conjugategradient_amd.parallel import ConjugateGradientRankGpu
+    from tests.test_gpu_parallel import _run_ranks_in_threads
+
+    world = 2
+    monkeypatch.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    monkeypatch.setenv("MGCG_TILE_SHIFT", "9")          # 512-column tiles: 12 of them, well below the mean |col - row| of both slices
+    s = problems.random_spd(6000, mean_upper=8.0, seed=17)
+    s.b[:] = np.cos(np.arange(s.Count) * 0.7) * (1.0 + np.arange(s.Count) % 5)
+    ref = oracle.cg_parallel(s, world, max_iteration=s.Count)
+    maxnz = int(np.diff(s.RowOffsets).max())
+
+    def make_rank(rank, comm):
+        cg = ConjugateGradientRankGpu(s.Count, maxnz, 0, s.Count, 1e-8, rank=rank, world=world, comm=comm, device=rank).load(s)
+        _lib.lib().MgcgSetMatrixCompression(cg.cusparse, 1)
+        cg.Initialize()
+        cg.Solve()
+        cg.Read()
+        assert _info(cg.cusparse, 0)[0] == 4
+        out = (cg.part.offset, cg.part.count, cg.x[cg.part.offset: cg.part.offset + cg.part.count].copy(), cg.Iteration)
+        cg.Dispose()
+        return out
+
+    x = np.zeros(s.Count)
+    for off, cnt, xs, it in _run_ranks_in_threads(world, make_rank):
+        x[off: off + cnt] = xs
+        assert it == ref["iteration"]
+    assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
