@@ -274,6 +274,12 @@ bool tiled_build(hipStream_t s, const double* elements, const int* rowOffsets, c
     const int nTiles = (int)((columns + tileCols - 1) / tileCols);
     if (rows <= 0 || nnz <= 0 || nTiles < 4 || nTiles > 256) return true;            // x fits a few L2s, or absurdly many passes
     const long long cells = (long long)nTiles * rows;
+    {   // the analysis needs 4 B per (tile, row) cell and the tiled copy 16 B per nonzero: decline rather than exhaust the device
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { (void)hipGetLastError(); return true; }
+        const double need = 4.0 * (double)(cells + 1) + 16.0 * (double)nnz;
+        if (cells + 1 > 0x7fffffffLL * 4LL || need > 0.5 * (double)freeB) return true;
+    }
     int* counts = nullptr; unsigned long long* stats = nullptr;
     double* tv = nullptr; int* tc = nullptr; int* tr = nullptr;
     bool ok = MGCG_HIP(hipMalloc((void**)&counts, sizeof(int) * (size_t)(cells + 1))) && MGCG_HIP(hipMalloc((void**)&stats, 2 * sizeof(unsigned long long)));
