@@ -91,6 +91,9 @@ struct MgcgComm {
     int nranks = 1, rank = 0;
     hipStream_t stream = nullptr;
     double* scratch = nullptr;       // device, 8 doubles
+    // callback transport (host-staged; MgcgCommInitCallbacks)
+    MgcgAllGatherFn cbAllGather = nullptr; MgcgAllReduceFn cbAllReduce = nullptr; MgcgExchangeFn cbExchange = nullptr; void* cbUser = nullptr;
+    std::vector<std::vector<double>> cbSend, cbRecv;
     hipStream_t haloStream = nullptr;                 // side stream: interior rows run here while the halo travels on `stream`
     hipEvent_t evReady = nullptr, evHalo = nullptr;
 };
@@ -114,6 +117,14 @@ bool comm_allreduce_sum(MgcgComm* c, double* devPtr, int count, hipStream_t s)
         ok = ok && MGCG_HIP(hipMemcpyAsync(devPtr, sum, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s));
         ok = ok && MGCG_HIP(hipStreamSynchronize(s));
         return ok;
+    }
+    if (c->cbAllReduce) {
+        if (count > 8) { set_error("callback all-reduce: at most 8 values"); return false; }
+        double vals[8];
+        bool ok = MGCG_HIP(hipMemcpyAsync(vals, devPtr, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
+        if (!ok) return false;
+        c->cbAllReduce(vals, count, c->cbUser);
+        return MGCG_HIP(hipMemcpyAsync(devPtr, vals, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s)) && MGCG_HIP(hipStreamSynchronize(s));
     }
     if (c->comm == nullptr) return true;             // single rank without a communicator: the local sum is the sum
     Rccl* r = rccl();
@@ -144,6 +155,9 @@ HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long 
         g->barrier();
         all = g->meta;
         g->barrier();
+    } else if (c->cbAllGather) {
+        const long long mine[4] = { offset, countLocal, (long long)minJ, (long long)maxJ };
+        c->cbAllGather(mine, all.data(), c->cbUser);
     } else {
         Rccl* r = rccl();
         if (!r) { delete h; return nullptr; }
@@ -200,6 +214,23 @@ bool halo_exchange(MgcgComm* c, HaloPlan* h, double* p, hipStream_t s)
         ok = MGCG_HIP(hipStreamSynchronize(s)) && ok;
         g->barrier();
         return ok;
+    }
+    if (c->cbExchange) {
+        const int n = h->nranks;
+        c->cbSend.resize((size_t)n); c->cbRecv.resize((size_t)n);
+        std::vector<const double*> sp((size_t)n, nullptr); std::vector<double*> rp((size_t)n, nullptr);
+        bool ok = true;
+        for (int q = 0; q < n; ++q) {
+            c->cbSend[(size_t)q].resize((size_t)h->sendCount[q]); c->cbRecv[(size_t)q].resize((size_t)h->recvCount[q]);
+            sp[(size_t)q] = c->cbSend[(size_t)q].data(); rp[(size_t)q] = c->cbRecv[(size_t)q].data();
+            if (h->sendCount[q] > 0) ok = ok && MGCG_HIP(hipMemcpyAsync(c->cbSend[(size_t)q].data(), p + h->sendBegin[q], sizeof(double) * (size_t)h->sendCount[q], hipMemcpyDeviceToHost, s));
+        }
+        ok = MGCG_HIP(hipStreamSynchronize(s)) && ok;
+        if (!ok) return false;
+        c->cbExchange(n, sp.data(), h->sendCount.data(), rp.data(), h->recvCount.data(), c->cbUser);
+        for (int q = 0; q < n; ++q)
+            if (h->recvCount[q] > 0) ok = ok && MGCG_HIP(hipMemcpyAsync(p + h->recvBegin[q], c->cbRecv[(size_t)q].data(), sizeof(double) * (size_t)h->recvCount[q], hipMemcpyHostToDevice, s));
+        return MGCG_HIP(hipStreamSynchronize(s)) && ok;
     }
     Rccl* r = rccl();
     if (!r) return false;
@@ -291,6 +322,18 @@ MgcgComm* MgcgCommInitLoopback(MgcgLoopback* group, int rank)
     if (!group || rank < 0 || rank >= group->nranks) { set_error("MgcgCommInitLoopback: bad argument"); return nullptr; }
     MgcgComm* c = new MgcgComm();
     c->nranks = group->nranks; c->rank = rank; c->stream = d->stream; c->loop = group;
+    if (!MGCG_HIP(hipMalloc((void**)&c->scratch, 8 * sizeof(double)))) { delete c; return nullptr; }
+    return c;
+}
+
+MgcgComm* MgcgCommInitCallbacks(int nranks, int rank, MgcgAllGatherFn allGather, MgcgAllReduceFn allReduce, MgcgExchangeFn exchange, void* user)
+{
+    DeviceState* d = device_state();
+    if (!d) return nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks || !allGather || !allReduce || !exchange) { set_error("MgcgCommInitCallbacks: bad argument"); return nullptr; }
+    MgcgComm* c = new MgcgComm();
+    c->nranks = nranks; c->rank = rank; c->stream = d->stream;
+    c->cbAllGather = allGather; c->cbAllReduce = allReduce; c->cbExchange = exchange; c->cbUser = user;
     if (!MGCG_HIP(hipMalloc((void**)&c->scratch, 8 * sizeof(double)))) { delete c; return nullptr; }
     return c;
 }

@@ -115,6 +115,51 @@ def create_comm(rank: int, world: int):
     return c
 
 
+_ALLGATHER_FN = C.CFUNCTYPE(None, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_void_p)
+_ALLREDUCE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int, C.c_void_p)
+_EXCHANGE_FN = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_longlong),
+                           C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_longlong), C.c_void_p)
+_CALLBACK_KEEPALIVE: dict = {}
+
+
+def create_callback_comm(rank: int, world: int):
+    """MgcgComm whose collectives are carried by the default torch.distributed group on HOST memory (gloo): the
+    host-staged fallback for machines where RCCL cannot form a communicator (``MgcgCommInitCallbacks``)."""
+    import torch
+    import torch.distributed as dist
+
+    def all_gather(mine, out, _user):
+        t = torch.tensor([mine[i] for i in range(4)], dtype=torch.int64)
+        parts = [torch.zeros(4, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(parts, t)
+        for q in range(world):
+            for i in range(4):
+                out[4 * q + i] = int(parts[q][i])
+
+    def all_reduce(values, count, _user):
+        t = torch.from_numpy(np.ctypeslib.as_array(values, shape=(count,)))     # shares the library's buffer
+        dist.all_reduce(t)
+
+    def exchange(n, send_bufs, send_counts, recv_bufs, recv_counts, _user):
+        reqs = []
+        for q in range(n):
+            if recv_counts[q] > 0:
+                reqs.append(dist.irecv(torch.from_numpy(np.ctypeslib.as_array(recv_bufs[q], shape=(recv_counts[q],))), src=q))
+        for q in range(n):
+            if send_counts[q] > 0:
+                reqs.append(dist.isend(torch.from_numpy(np.ctypeslib.as_array(send_bufs[q], shape=(send_counts[q],))), dst=q))
+        for r in reqs:
+            r.wait()
+
+    fns = (_ALLGATHER_FN(all_gather), _ALLREDUCE_FN(all_reduce), _EXCHANGE_FN(exchange))
+    c = lib().MgcgCommInitCallbacks(world, rank, C.cast(fns[0], C.c_void_p), C.cast(fns[1], C.c_void_p), C.cast(fns[2], C.c_void_p), None)
+    check("MgcgCommInitCallbacks")
+    if not c:
+        raise MgcgError("MgcgCommInitCallbacks returned NULL")
+    _CALLBACK_KEEPALIVE[c] = fns           # the library calls these for as long as the communicator lives
+    return c
+
+
 class ConjugateGradientRankGpu(ConjugateGradientGpu):
     """This rank's share of ConjugateGradientParallelGpu: same constructor arguments and members, plus
     (rank, world).  ``Initialize()`` uploads the rank's row slice with the reference's ``Initialize``

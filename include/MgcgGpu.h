@@ -308,6 +308,18 @@ typedef struct MgcgLoopback MgcgLoopback;
 MgcgLoopback* MgcgLoopbackCreate(int nranks);
 void          MgcgLoopbackDestroy(MgcgLoopback* group);
 MgcgComm*     MgcgCommInitLoopback(MgcgLoopback* group, int rank);
+/* Host-staged transport through callbacks of the launcher (e.g. torch.distributed / MPI on host memory): a fallback for
+ * hosts where RCCL cannot form a communicator, and a way to drive the multi-rank loop from any message layer.
+ *   allGather(mine, all, user):   all[4*q .. 4*q+3] = the four int64 of rank q  (every rank's `mine`, rank order)
+ *   allReduce(values, count, user): values[i] = sum over ranks, in place, the SAME bits on every rank
+ *   exchange(nranks, sendBufs, sendCounts, recvBufs, recvCounts, user): for every peer q with sendCounts[q] > 0 send
+ *       sendBufs[q][0 .. sendCounts[q]) to q, with recvCounts[q] > 0 receive into recvBufs[q]; returns when all arrived.
+ * All buffers are host memory owned by the library; the callbacks are invoked from the thread that calls the solver. */
+typedef void (*MgcgAllGatherFn)(const long long mine[4], long long all[], void* user);
+typedef void (*MgcgAllReduceFn)(double values[], int count, void* user);
+typedef void (*MgcgExchangeFn)(int nranks, const double* const sendBufs[], const long long sendCounts[],
+                               double* const recvBufs[], const long long recvCounts[], void* user);
+MgcgComm*     MgcgCommInitCallbacks(int nranks, int rank, MgcgAllGatherFn allGather, MgcgAllReduceFn allReduce, MgcgExchangeFn exchange, void* user);
 /* sum of one double over all ranks (test / bootstrap helper; blocking). */
 double    MgcgCommAllReduceSum(MgcgComm* comm, double value);
 /* The whole multi-rank CG of ConjugateGradientParallelGpu.Solve (ConjugateGradientParallelGpu.cs:424-565)

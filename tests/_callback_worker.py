@@ -1,0 +1,46 @@
+"""Worker of tests/test_gpu_parallel.py::test_native_loop_over_the_callback_transport (one rank per process): the native
+multi-rank loop (SolveParallel / SolveMgParallel) with its collectives carried by torch.distributed gloo on host memory."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, port, out_dir, which = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    import torch.distributed as dist
+
+    from conjugategradient_amd import _lib, problems as P
+    from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu, ConjugateGradientRankGpu, create_callback_comm
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = create_callback_comm(rank, world)
+    if which == "banded":
+        system = P.mgcg_main(2400, 160)
+        cg = ConjugateGradientRankGpu(system.Count, 160, 0, system.Count, 1e-8, rank=rank, world=world, comm=comm, device=0).load(system)
+        cg.Initialize()
+    else:
+        system = P.poisson(16, 16, 16)
+        system.b[:] = np.random.default_rng(3).standard_normal(system.Count)
+        cg = ConjugateGradientMgRankGpu(system.Count, 7, 0, 400, 1e-8, system.grid, rank=rank, world=world, comm=comm, device=0).load(system)
+        _lib.lib().MgcgSetMatrixCompression(cg.cusparse, 1)
+        cg.Initialize()
+        cg.Setup()
+    cg.Solve()
+    cg.Read()
+    p = cg.part
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=cg.x[p.offset: p.offset + p.count], iteration=cg.Iteration, residual=cg.Residual,
+             offset=p.offset, count=p.count)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.stdout.flush()
+    os._exit(0)      # skip interpreter teardown: two GPU runtimes' exit handlers are not this test's subject
+
+
+if __name__ == "__main__":
+    main()

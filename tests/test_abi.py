@@ -24,6 +24,7 @@ def declared_functions():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"#.*", "", text)
+    text = re.sub(r"typedef[^;]*\(\s*\*[^;]*;", "", text)        # function-pointer typedefs (callback types) declare no export
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text)
     skip = {"defined", "sizeof"}
     return sorted({n for n in names if n not in skip})

@@ -92,6 +92,33 @@ def test_phased_ranks_share_the_gpu_over_gloo(oracle, tmp_path):
     assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
 
 
+@pytest.mark.parametrize("which", ["banded", "mgcg"])
+def test_native_loop_over_the_callback_transport(oracle, tmp_path, which):
+    """MgcgCommInitCallbacks: the native multi-rank loop with its all-gather / all-reduce / halo exchange carried by
+    torch.distributed gloo on host memory (the fallback transport of bench.py); two processes share the GPU."""
+    import subprocess
+
+    world = 2
+    port = 31600 + (os.getpid() % 2000) + (7 if which == "mgcg" else 0)
+    worker = os.path.join(ROOT, "tests", "_callback_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(tmp_path), which]) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    if which == "banded":
+        system = problems.mgcg_main(2400, 160)
+        ref = oracle.cg_parallel(system, world, max_iteration=system.Count)
+    else:
+        system = problems.poisson(16, 16, 16)
+        system.b[:] = np.random.default_rng(3).standard_normal(system.Count)
+        ref = oracle.Multigrid(system).pcg(rule=oracle.RULE_CSHARP, max_iteration=400)
+    x = np.zeros(system.Count)
+    for r in range(world):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        x[int(d["offset"]): int(d["offset"]) + int(d["count"])] = d["x"]
+        assert int(d["iteration"]) == ref["iteration"]
+    assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
+
+
 def _run_ranks_in_threads(world, make_rank):
     """world ranks of this process as host threads on MGCG_VIRTUAL_DEVICES of the one GPU, joined by the
     library's loopback transport (RCCL needs one device per rank, so it cannot be used for this on the test box)."""
