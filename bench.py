@@ -183,6 +183,38 @@ def main():
         a.compression = 0 if a.no_compression else 1
     a.no_compression = a.compression == 0
     L.MgcgSetMatrixCompression(cg.cusparse, a.compression)
+    transport = "single rank"
+    if world > 1:
+        # RCCL communicator (the unique id travels over gloo).  Should it fail to form on this host, every rank falls back
+        # to the library's host-staged callback transport over the same gloo group: slow, but the scaling line stays valid.
+        import torch
+        from conjugategradient_amd.parallel import create_callback_comm, create_comm
+
+        ok, why = 1, ""
+        if os.environ.get("MGCG_BENCH_TRANSPORT", "rccl") != "rccl":
+            ok, why = 0, "MGCG_BENCH_TRANSPORT asked for the host-staged transport"
+        else:
+            try:
+                cg.comm = create_comm(rank, world)
+                cg._own_comm = True
+                probe = L.MgcgCommAllReduceSum(cg.comm, 1.0)
+                if probe != float(world):
+                    ok, why = 0, f"RCCL all-reduce probe returned {probe}"
+            except Exception as ex:     # noqa: BLE001 -- any failure of the RCCL bootstrap
+                ok, why = 0, str(ex)
+                L.MgcgClearLastError()
+        flag = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 1:
+            transport = "rccl"
+        else:
+            if rank == 0:
+                print(f"bench.py: RCCL transport unavailable ({why or 'another rank failed'}); using the host-staged gloo transport", file=sys.stderr, flush=True)
+            if cg.comm:
+                L.MgcgCommDestroy(cg.comm)
+            cg.comm = create_callback_comm(rank, world)
+            cg._own_comm = True
+            transport = "host-staged callbacks over torch.distributed gloo (RCCL fallback)"
     if a.spmv_kernel is not None:
         L.MgcgSetSpmvKernel(cg.cusparse, a.spmv_kernel)
     if a.spmv_rows is not None or a.spmv_flags is not None or a.spmv_grid is not None:
@@ -282,8 +314,8 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": ("CG iterations/sec (7-pt Poisson 512^3); SpMV achieved HBM GB/s in roofline" if a.solver == "cg"
-                       else "MGCG iterations/sec (3-level V(1,1) Jacobi, 7-pt Poisson 512^3)"),
+            "metric": (f"CG iterations/sec (7-pt Poisson {n}^3); SpMV achieved HBM GB/s in roofline" if a.solver == "cg"
+                       else f"MGCG iterations/sec (3-level V(1,1) Jacobi, 7-pt Poisson {n}^3)"),
             "value": a.steps / dt,
             "unit": "iterations/s",
             "n_gpus": world,
@@ -297,7 +329,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": ("unpreconditioned CG iteration" if a.solver == "cg" else "MGCG iteration (V-cycle + CG)") + f", 7-point Poisson {n}^3 CSR (fp64 values, int32 indices), "
                                    f"b=1, x0=0, {world} z-slab partition(s)",
-                       "rows": N, "nnz": nnz_total, "parallelism": f"row-range dp{world}"},
+                       "rows": N, "nnz": nnz_total, "parallelism": f"row-range dp{world}", "transport": transport},
             "iteration_algorithmic_gbps": iter_bytes / (dt / a.steps) / 1e9,
             "gflops": (2 * nnz_total + 10 * N) * (a.steps / dt) / 1e9 if a.solver == "cg" else None,
             "residual_after_steps": res,
