@@ -184,6 +184,8 @@ struct SpmvArgs {
     const double* b;         // EPI_RESIDUAL / EPI_JACOBI
     const double* dinv;      // EPI_JACOBI
     double omega;            // EPI_JACOBI
+    int dinvUniform;         // EPI_JACOBI: every diagonal is the same; dinvScalar is used and the dinv array is not read
+    double dinvScalar;
     double* partials;        // EPI_DOT / EPI_RESIDUAL_DOT / EPI_JACOBI_DOT: one double per workgroup
     const int* doneFlag;     // optional: exit at once when *doneFlag != 0
     int ablate;              // diagnostics only (tools/spmv_sweep.py --ablate): bit0 skip the y store, bit1 gathers from L1
@@ -263,7 +265,10 @@ void launch_finalize_precond(hipStream_t s, const double* partials, int n, bool 
 void launch_init_scalars(hipStream_t s, const double* partials, int n, bool reduceFirst, CgScalars* sc, HostMirror* mirror, int rule);
 
 // ---------------------------------------------------------------- multigrid kernels
-void launch_jacobi_first(hipStream_t s, long long n, double omega, const double* dinv, const double* b, double* x, const int* done);
+// dinvUniform: dinv[i] == dinvScalar for every i (the array is then not read)
+void launch_jacobi_first(hipStream_t s, long long n, double omega, const double* dinv, int dinvUniform, double dinvScalar, const double* b, double* x, const int* done);
+// *flag = 1 if some v[i] differs (bitwise) from v[0]; flag pre-set to 0 by the caller
+void launch_uniform_check(hipStream_t s, const double* v, long long n, int* flag);
 void launch_restrict(hipStream_t s, int nx, int ny, int nz, const double* r, double* bc, const int* done);
 void launch_prolong_add(hipStream_t s, int nx, int ny, int nz, double* x, const double* e, const int* done);
 void launch_extract_dinv(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces,

@@ -32,7 +32,7 @@ __device__ __forceinline__ RowsEpi rows_epi_prefetch(const SpmvArgs& a, long lon
     if constexpr (EPI == EPI_AXPBY_BETA) o.yold = a.y[row];
     if constexpr (EPI == EPI_DOT) o.w = a.w[row];
     if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_DOT) o.b = a.b[row];
-    if constexpr (EPI == EPI_JACOBI || EPI == EPI_JACOBI_DOT) { o.b = a.b[row]; o.dinv = a.dinv[row]; o.w = a.w[row]; }
+    if constexpr (EPI == EPI_JACOBI || EPI == EPI_JACOBI_DOT) { o.b = a.b[row]; o.dinv = a.dinvUniform ? a.dinvScalar : a.dinv[row]; o.w = a.w[row]; }
     return o;
 }
 

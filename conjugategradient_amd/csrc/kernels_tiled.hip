@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void tiled_epilogue_kernel(SpmvArgs a)
         else if constexpr (EPI == EPI_DOT) { const double t = a.w[i] * acc; dotacc += t; val = acc; }
         else if constexpr (EPI == EPI_RESIDUAL) val = a.b[i] - acc;
         else if constexpr (EPI == EPI_RESIDUAL_DOT) { val = a.b[i] - acc; const double t = val * val; dotacc += t; }
-        else { const double res = a.b[i] - acc; const double t = a.dinv[i] * res; const double sft = a.omega * t; val = a.w[i] + sft;
+        else { const double res = a.b[i] - acc; const double t = (a.dinvUniform ? a.dinvScalar : a.dinv[i]) * res; const double sft = a.omega * t; val = a.w[i] + sft;
                if constexpr (EPI == EPI_JACOBI_DOT) { const double q = a.b[i] * val; dotacc += q; } }
         if constexpr (EPI != EPI_DOT) a.y[i] = val;                  // (EPI_DOT leaves y = A x as it is)
     }

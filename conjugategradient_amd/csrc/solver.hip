@@ -24,6 +24,7 @@ struct MgLevel {
     double* elements = nullptr; int* rowOffsets = nullptr; int* columnIndeces = nullptr;
     bool ownsMatrix = false;
     double* dinv = nullptr;
+    bool dinvUniform = false; double dinvScalar = 0.0;   // every diagonal equal: the kernels use the scalar and skip the array
     double *xa = nullptr, *xb = nullptr;   // iterate ping-pong, full length (Jacobi is not in place)
     double *b = nullptr, *r = nullptr;     // right-hand side (restricted residual), residual; local
     SpmvConfig cfg;                        // per level: kernel picked from its nnz/row, banded period = nx*ny
@@ -109,7 +110,7 @@ static bool mg_jacobi(MgcgMg* mg, MgLevel& L, const double* b, double* xin, doub
     SpmvArgs a{};
     a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = xin; a.y = xout + L.offset;
     a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal;
-    a.w = xin + L.offset; a.b = b; a.dinv = L.dinv; a.omega = mg->omega; a.doneFlag = done;
+    a.w = xin + L.offset; a.b = b; a.dinv = L.dinv; a.dinvUniform = L.dinvUniform ? 1 : 0; a.dinvScalar = L.dinvScalar; a.omega = mg->omega; a.doneFlag = done;
     if (withDot && mg->nranks == 1 && mg->fuseDotPartials != nullptr) {          // + partial sums of b . xout
         a.partials = mg->fuseDotPartials;
         mg->fusedDotCount = launch_spmv_auto(mg->stream, EPI_JACOBI_DOT, a, L.cfg, L.dcsr);
@@ -125,7 +126,7 @@ static bool mg_smooth(MgcgMg* mg, MgLevel& L, const double* b, double* cur, doub
 {
     for (int sIdx = 0; sIdx < sweeps; ++sIdx) {
         if (first && sIdx == 0) {
-            launch_jacobi_first(mg->stream, L.n, mg->omega, L.dinv, b, cur + L.offset, done);
+            launch_jacobi_first(mg->stream, L.n, mg->omega, L.dinv, L.dinvUniform ? 1 : 0, L.dinvScalar, b, cur + L.offset, done);
         } else {
             if (!mg_jacobi(mg, L, b, cur, other, done, dotOnLast && sIdx == sweeps - 1)) return false;
             double* t = cur; cur = other; other = t;
@@ -609,6 +610,14 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
             ok = ok && MGCG_HIP(hipMemsetAsync(L.xa, 0, sizeof(double) * (size_t)L.nGlobal, s)) && MGCG_HIP(hipMemsetAsync(L.xb, 0, sizeof(double) * (size_t)L.nGlobal, s));
         }
         if (ok) launch_extract_dinv(s, L.elements, L.rowOffsets, L.columnIndeces, L.n, L.offset, L.dinv);
+        if (ok && L.n > 0) {                              // constant-coefficient operators: one diagonal for all rows
+            int differs = 1;
+            ok = MGCG_HIP(hipMemsetAsync(dmm, 0, sizeof(int), s));      // (dmm is re-initialised before its min/max use below)
+            if (ok) launch_uniform_check(s, L.dinv, L.n, dmm);
+            ok = ok && MGCG_HIP(hipMemcpyAsync(&differs, dmm, sizeof(int), hipMemcpyDeviceToHost, s)) &&
+                 MGCG_HIP(hipMemcpyAsync(&L.dinvScalar, L.dinv, sizeof(double), hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
+            L.dinvUniform = ok && differs == 0 && getenv("MGCG_NO_UNIFORM_DIAGONAL") == nullptr;
+        }
         if (ok) L.dcsr = dcsr_lookup(cusparse, L.elements, L.rowOffsets, L.columnIndeces, L.n, L.nnz, L.offset);
         L.cfg = mg->cfg;
         L.cfg.periodRows = (L.nz > 1) ? L.nx * L.ny : 0;       // far band of a 3-D stencil = one grid plane (used only if the caller switched the banded schedule on)
