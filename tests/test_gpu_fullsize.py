@@ -107,3 +107,39 @@ def test_config5_like_irregular_rows(oracle):
     assert cg.Iteration == r["iteration"]
     assert np.abs(cg.x - r["x"]).max() <= 1e-10 * np.abs(r["x"]).max()
     np.testing.assert_allclose(cg.x, np.ones(s.Count), rtol=1e-7)             # b = A.1
+
+
+def test_config3_mgcg_at_full_size():
+    """BASELINE config 3 (7-point 512^3, 3-level V(1,1) Jacobi) through size-independent properties: the iteration count
+    is the grid-independent one (157 here; 53 at 128^3, 157 +- a few at 512^3 because the coarsest grid is only smoothed),
+    the residual the solver reports equals ||b - A x|| recomputed from x, and the lossless matrix analysis is in use."""
+    from conjugategradient_amd.multigrid import ConjugateGradientMgGpu
+
+    n = 512
+    N = n**3
+    L = _lib.lib()
+    tol = 1e-8 * np.sqrt(N)                      # 1e-8 * ||b||_2 for b = 1
+    mg = ConjugateGradientMgGpu(N, 7, 0, 1000, tol, (n, n, n), levels=3, rule=_lib.RULE_CSHARP)
+    L.MgcgSetMatrixCompression(mg.cusparse, 1)
+    mg.InitializePoisson()
+    mg.Solve()
+    assert 150 <= mg.Iteration + 1 <= 165, mg.Iteration
+    assert mg.Residual < tol
+    assert L.MgcgAnalysisInfo(mg.cusparse, 0, None, None, None, None) == 3
+    y = VectorDouble(N)
+    nnz = 7 * N - 6 * n * n
+    L.CsrMV(mg.cusparse, mg.matDescr, y.ToRawPtr(), mg.vectorA.ToRawPtr(), mg.vectorRowOffsets.ToRawPtr(), mg.vectorColumnIndeces.ToRawPtr(),
+            mg.vectorX.ToRawPtr(), nnz, N, N, 1.0, 0.0)
+    _lib.check("CsrMV")
+    # r = 1 - A x on the device: y = -1 * y + 1  (Scal, then add the constant through Axpy with a vector of ones)
+    ones = VectorDouble(N)
+    L.MgcgFill(ones.Ptr, 1.0)
+    L.Scal(mg.cublas, y.ToRawPtr(), -1.0, N)
+    L.Axpy(mg.cublas, y.ToRawPtr(), ones.ToRawPtr(), N, 1.0)
+    true_res = float(np.sqrt(L.Dot(mg.cublas, y.ToRawPtr(), y.ToRawPtr(), N)))
+    # at a reduction of 1e-8 the recurrence residual and b - A x differ by the round-off of 157 updates of x
+    # (about eps * ||A|| * ||x|| ~ 1e-6 * ||r|| here): they must agree to a few per cent, not to the last digits
+    assert abs(true_res - mg.Residual) <= 0.05 * mg.Residual, (true_res, mg.Residual)
+    for v in (y, ones):
+        v.Dispose()
+    mg.Dispose()
