@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""The reference's own benchmark program at its own constants (MgcgMain.cs:15-35: COUNT = 207 402, 159 entries per row,
+MIN_ITERATION = 200): the C++ twin host/MgcgMain (single device and the host-driven multi-device phases) next to the CPU
+oracle on the same system.  The reference prints "ticks per iteration" for CPU / 1 GPU / N GPUs (MgcgMain.cs:165-167); this
+prints the same three figures as one JSON line."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from conjugategradient_amd import problems  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def main():
+    count, min_it = 34567 * 6, 200
+    exe = os.path.join(ROOT, "conjugategradient_amd", "host", "MgcgMain")
+    out = subprocess.run([exe, str(count), str(min_it)], capture_output=True, text=True, timeout=1200)
+    lines = out.stdout.splitlines()
+    rec = json.loads([l for l in lines if l.startswith("{")][-1])
+    rec["driver_stdout"] = [l for l in lines if "per iteration" in l]
+    s = problems.mgcg_main(count, 160)
+    t0 = time.perf_counter()
+    ref = O.cg(s, rule=O.RULE_NATIVE, min_iteration=min_it, max_iteration=count, hard_cap=count + 5)
+    dt = time.perf_counter() - t0
+    rec["cpu_oracle_seconds"] = dt
+    rec["cpu_oracle_iteration"] = ref["iteration"]
+    rec["cpu_oracle_us_per_iteration"] = 1e6 * dt / max(1, ref["iteration"])
+    print(json.dumps(rec))
+
+
+if __name__ == "__main__":
+    main()
