@@ -74,7 +74,7 @@ struct HostMirror {
 struct Workspace {
     int device = -1;
     hipStream_t stream = nullptr;
-    double* partials = nullptr;      // kMaxGrid * 2 doubles: per-workgroup partial sums
+    double* partials = nullptr;      // 3 * kMaxPartials doubles: per-workgroup partial sums (SpMV dot | max-norm | r.r of the fused single-rank path)
     CgScalars* scalars = nullptr;    // device
     HostMirror* mirror = nullptr;    // pinned host, device-visible
     double* hostScalar = nullptr;    // pinned host, 4 doubles (Dot results)
@@ -248,7 +248,10 @@ int  launch_update_xr(hipStream_t s, const CgScalars* sc, double* x, double* r, 
 // p = z + beta p with beta = sc->beta ; skipped when sc->done
 void launch_update_p(hipStream_t s, const CgScalars* sc, double* p, const double* z, long long n);
 // the loop's own split: r -= alpha Ap (+ r.r), then x += alpha p and p = z + beta p in one pass over p
-int  launch_update_r(hipStream_t s, CgScalars* sc, double* r, const double* Ap, long long n, double* partials, double* partialsInf);
+// pApPartials != nullptr: p.Ap is still in nPAp per-workgroup partial sums; every workgroup adds them up itself (same fixed
+// order everywhere) instead of a separate reduction launch.  partials (output) must not overlap pApPartials.
+int  launch_update_r(hipStream_t s, CgScalars* sc, double* r, const double* Ap, long long n, double* partials, double* partialsInf,
+                     const double* pApPartials = nullptr, int nPAp = 0);
 void launch_update_xp(hipStream_t s, const CgScalars* sc, double* x, double* p, const double* z, long long n);
 
 struct FinalizeArgs {

@@ -282,12 +282,24 @@ int launch_update_xr(hipStream_t s, const CgScalars* sc, double* x, double* r, c
 // alpha = rr / pAp ; r = r + (-alpha)*Ap ; partial r.r [, partial max|r|]
 template <bool V2, bool INF>
 __global__ __launch_bounds__(kBlock) void update_r_kernel(CgScalars* __restrict__ sc, double* __restrict__ r, const double* __restrict__ Ap, long long n,
-                                                          double* __restrict__ partials, double* __restrict__ partialsInf)
+                                                          double* __restrict__ partials, double* __restrict__ partialsInf,
+                                                          const double* __restrict__ pApPartials, int nPAp)
 {
     __shared__ double s_red[4];
     __shared__ double s_red2[4];
+    __shared__ double s_pAp;
     if (sc->done != 0) return;
-    const double alpha = sc->rr / sc->pAp;
+    double pAp;
+    if (pApPartials != nullptr) {                                     // single-rank loop: no separate reduction launch
+        const double t = reduce_partials_block(pApPartials, nPAp, s_red, 0);
+        if (threadIdx.x == 0) s_pAp = t;
+        __syncthreads();
+        pAp = s_pAp;
+        if (blockIdx.x == 0 && threadIdx.x == 0) sc->pAp = pAp;
+    } else {
+        pAp = sc->pAp;
+    }
+    const double alpha = sc->rr / pAp;
     if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;      // for update_xp of this iteration
     const double malpha = -alpha;
     double acc = 0.0, mx = 0.0;
@@ -320,12 +332,13 @@ __global__ __launch_bounds__(kBlock) void update_r_kernel(CgScalars* __restrict_
         if (threadIdx.x == 0) partialsInf[blockIdx.x] = m;
     }
 }
-int launch_update_r(hipStream_t s, CgScalars* sc, double* r, const double* Ap, long long n, double* partials, double* partialsInf)
+int launch_update_r(hipStream_t s, CgScalars* sc, double* r, const double* Ap, long long n, double* partials, double* partialsInf,
+                    const double* pApPartials, int nPAp)
 {
     const bool v2 = al16(r) && al16(Ap);
     const int grid = grid_for(n, v2 ? 4 : 2);
     const bool inf = partialsInf != nullptr;
-#define GO(V, I) hipLaunchKernelGGL((update_r_kernel<V, I>), dim3(grid), dim3(kBlock), 0, s, sc, r, Ap, n, partials, partialsInf)
+#define GO(V, I) hipLaunchKernelGGL((update_r_kernel<V, I>), dim3(grid), dim3(kBlock), 0, s, sc, r, Ap, n, partials, partialsInf, pApPartials, nPAp)
     if (v2) { if (inf) GO(true, true); else GO(true, false); }
     else { if (inf) GO(false, true); else GO(false, false); }
 #undef GO

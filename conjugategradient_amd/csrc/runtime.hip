@@ -74,7 +74,7 @@ bool Workspace::init()
     if (!d) return false;
     device = current_device();
     stream = d->stream;
-    if (!MGCG_HIP(hipMalloc((void**)&partials, sizeof(double) * kMaxPartials * 2))) return false;
+    if (!MGCG_HIP(hipMalloc((void**)&partials, sizeof(double) * kMaxPartials * 3))) return false;
     if (!MGCG_HIP(hipMalloc((void**)&scalars, sizeof(CgScalars)))) return false;
     if (!MGCG_HIP(hipMemset(scalars, 0, sizeof(CgScalars)))) return false;
     if (!MGCG_HIP(hipHostMalloc((void**)&mirror, sizeof(HostMirror), hipHostMallocMapped))) return false;

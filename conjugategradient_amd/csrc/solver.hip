@@ -298,20 +298,28 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
         n = launch_spmv_auto(s, EPI_DOT, a, R.cfg, R.dcsr);                          // Ap = A p ; p.Ap   (Mgcg.cu:244-245)
         prof_mark(R, false);
     }
-    launch_reduce_to(s, R.ws->partials, n, &sc->pAp, done);
-    if (R.nranks > 1 && !comm_allreduce_sum(R.comm, &sc->pAp, 1, s)) return false;   // (:499)
     double* pInf = R.wantInf ? R.ws->partials + kMaxPartials : nullptr;
-    n = launch_update_r(s, sc, R.r, R.Ap, R.nLocal, R.ws->partials, pInf);           // r -= a Ap ; r.r  (:247-248); x += a p rides with the p update below
+    double* rrPartials = R.ws->partials;
+    if (R.nranks > 1) {
+        launch_reduce_to(s, R.ws->partials, n, &sc->pAp, done);
+        if (!comm_allreduce_sum(R.comm, &sc->pAp, 1, s)) return false;               // (:499)
+        n = launch_update_r(s, sc, R.r, R.Ap, R.nLocal, rrPartials, pInf);           // r -= a Ap ; r.r  (:247-248); x += a p rides with the p update below
+    } else {
+        // one rank: the workgroups of the r update add the p.Ap partial sums themselves (one launch fewer per iteration);
+        // their own r.r partial sums go to the third region of the buffer
+        rrPartials = R.ws->partials + 2 * kMaxPartials;
+        n = launch_update_r(s, sc, R.r, R.Ap, R.nLocal, rrPartials, pInf, R.ws->partials, n);
+    }
     FinalizeArgs f{};
     f.sc = sc; f.mirror = R.ws->mirror; f.trace = R.ws->trace; f.traceCap = R.ws->traceCap;
     f.tol = R.tol; f.minIt = R.minIt; f.maxIt = R.maxIt; f.rule = R.rule; f.preconditioned = R.mg ? 1 : 0;
     if (!withStopTest) { f.tol = -1.0; f.minIt = 0; f.maxIt = 0x7fffffff; f.rule = MGCG_RULE_NATIVE; }   // never converges
     if (R.nranks > 1) {
-        launch_reduce_to(s, R.ws->partials, n, &sc->rrNew, done);
+        launch_reduce_to(s, rrPartials, n, &sc->rrNew, done);
         if (!comm_allreduce_sum(R.comm, &sc->rrNew, 1, s)) return false;             // (:525)
-        launch_finalize(s, R.ws->partials, pInf, n, false, f);
+        launch_finalize(s, rrPartials, pInf, n, false, f);
     } else {
-        launch_finalize(s, R.ws->partials, pInf, n, true, f);                        // residual, stop test, beta  (:251-266)
+        launch_finalize(s, rrPartials, pInf, n, true, f);                            // residual, stop test, beta  (:251-266)
     }
     if (R.mg) {
         int nz = 0;
