@@ -186,6 +186,8 @@ struct SpmvArgs {
     double omega;            // EPI_JACOBI
     int dinvUniform;         // EPI_JACOBI: every diagonal is the same; dinvScalar is used and the dinv array is not read
     double dinvScalar;
+    int xScaled;             // row-pattern kernel only: the multiplied vector is xOuter * (xInner * x[col]), formed per gather
+    double xInner, xOuter;   //   (a first Jacobi sweep from zero folded into the residual pass of the V-cycle)
     double* partials;        // EPI_DOT / EPI_RESIDUAL_DOT / EPI_JACOBI_DOT: one double per workgroup
     const int* doneFlag;     // optional: exit at once when *doneFlag != 0
     int ablate;              // diagnostics only (tools/spmv_sweep.py --ablate): bit0 skip the y store, bit1 gathers from L1
@@ -274,6 +276,8 @@ void launch_jacobi_first(hipStream_t s, long long n, double omega, const double*
 void launch_uniform_check(hipStream_t s, const double* v, long long n, int* flag);
 void launch_restrict(hipStream_t s, int nx, int ny, int nz, const double* r, double* bc, const int* done);
 void launch_prolong_add(hipStream_t s, int nx, int ny, int nz, double* x, const double* e, const int* done);
+// x[i] = outer * (inner * b[i]) + e[parent(i)]   (prolong_add onto a first Jacobi sweep that was never stored)
+void launch_prolong_scaled(hipStream_t s, int nx, int ny, int nz, double* x, const double* b, double inner, double outer, const double* e, const int* done);
 void launch_extract_dinv(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces,
                          long long n, long long rowBase, double* dinv);
 // Galerkin: count pass (elementsC == nullptr) writes per-row counts to countsC[I]; fill pass writes entries.

@@ -113,6 +113,27 @@ void launch_prolong_add(hipStream_t s, int nx, int ny, int nz, double* x, const 
     hipLaunchKernelGGL(prolong_add_kernel, dim3(grid1((long long)nx * ny * nz)), dim3(kBlock), 0, s, nx, ny, nz, x, e, done);
 }
 
+// x[i] = outer * (inner * b[i]) + e[parent(i)]: the first sweep's iterate is formed here instead of being read back
+__global__ __launch_bounds__(kBlock) void prolong_scaled_kernel(int nx, int ny, int nz, double* __restrict__ x, const double* __restrict__ b,
+                                                                double inner, double outer, const double* __restrict__ e, const int* done)
+{
+    if (done != nullptr && *done != 0) return;
+    const int cx = nx > 1 ? 2 : 1, cy = ny > 1 ? 2 : 1, cz = nz > 1 ? 2 : 1;
+    const int NX = nx / cx, NY = ny / cy;
+    const long long N = (long long)nx * ny * nz;
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < N; i += stride) {
+        const int xx = (int)(i % nx), yy = (int)((i / nx) % ny), zz = (int)(i / ((long long)nx * ny));
+        const double t = inner * b[i];
+        const double x1 = outer * t;
+        x[i] = x1 + e[((long long)(zz / cz) * NY + (yy / cy)) * NX + (xx / cx)];
+    }
+}
+void launch_prolong_scaled(hipStream_t s, int nx, int ny, int nz, double* x, const double* b, double inner, double outer, const double* e, const int* done)
+{
+    hipLaunchKernelGGL(prolong_scaled_kernel, dim3(grid1((long long)nx * ny * nz)), dim3(kBlock), 0, s, nx, ny, nz, x, b, inner, outer, e, done);
+}
+
 // dinv[i] = 1 / (first stored entry of local row i whose column is rowBase + i)
 __global__ __launch_bounds__(kBlock) void extract_dinv_kernel(const double* __restrict__ elements, const int* __restrict__ rowOffsets,
                                                               const int* __restrict__ columnIndeces, long long n, long long rowBase, double* __restrict__ dinv)

@@ -343,6 +343,12 @@ __global__ __launch_bounds__(64) void spmv_pattern_kernel(SpmvArgs a, DcsrView m
                     xg[u][j] = a.x[col];
                 }
             }
+            if (a.xScaled) {                                       // wave-uniform: x[col] stands for xOuter * (xInner * x[col])
+#pragma unroll
+                for (int u = 0; u < RPL; ++u)
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) { const double t = a.xInner * xg[u][j]; xg[u][j] = a.xOuter * t; }
+            }
 #pragma unroll
             for (int u = 0; u < RPL; ++u)
 #pragma unroll
@@ -360,6 +366,12 @@ __global__ __launch_bounds__(64) void spmv_pattern_kernel(SpmvArgs a, DcsrView m
                         vv[u][j] = s_val[t];
                         xg[u][j] = a.x[g + s_delta[t]];
                     }
+                }
+                if (a.xScaled) {
+#pragma unroll
+                    for (int u = 0; u < RPL; ++u)
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) { const double t = a.xInner * xg[u][j]; xg[u][j] = a.xOuter * t; }
                 }
 #pragma unroll
                 for (int u = 0; u < RPL; ++u)

@@ -144,16 +144,23 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
     if (l == mg->levels - 1) return mg_smooth(mg, L, b, x0, x1, mg->nuCoarse, true, done, result, l == 0);
     MgLevel& C = mg->lv[l + 1];
     double* cur = nullptr;
-    if (!mg_smooth(mg, L, b, x0, x1, mg->nu, true, done, &cur)) return false;
+    // V(1,*) on one rank with a uniform diagonal and the row-pattern form: the first sweep x1 = omega (d0 b) is not stored;
+    // the residual pass forms x1[col] per gather and the prolongation forms x1[i] again when it adds the correction
+    const bool fold = mg->nu == 1 && mg->nranks == 1 && L.dinvUniform && L.dcsr != nullptr && L.dcsr->usable && L.dcsr->patternId != nullptr &&
+                      getenv("MGCG_NO_FOLD") == nullptr;
+    if (fold) cur = x0;
+    else if (!mg_smooth(mg, L, b, x0, x1, mg->nu, true, done, &cur)) return false;
     double* other = (cur == x0) ? x1 : x0;
     SpmvArgs a{};
-    a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = cur; a.y = L.r;
+    a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = fold ? b : cur; a.y = L.r;
     a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal; a.b = b; a.doneFlag = done;
+    if (fold) { a.xScaled = 1; a.xInner = L.dinvScalar; a.xOuter = mg->omega; }
     if (!mg_spmv(mg, L, EPI_RESIDUAL, a, cur)) return false;                                  // r = b - A x
     launch_restrict(mg->stream, L.nx, L.ny, L.z1 - L.z0, L.r, C.b, done);                     // b_c = P^T r (slab-local)
     double* e = nullptr;
     if (!mg_vcycle(mg, l + 1, C.b, C.xa, C.xb, done, &e)) return false;
-    launch_prolong_add(mg->stream, L.nx, L.ny, L.z1 - L.z0, cur + L.offset, e + C.offset, done);   // x += P e (slab-local)
+    if (fold) launch_prolong_scaled(mg->stream, L.nx, L.ny, L.z1 - L.z0, cur + L.offset, b, L.dinvScalar, mg->omega, e + C.offset, done);
+    else launch_prolong_add(mg->stream, L.nx, L.ny, L.z1 - L.z0, cur + L.offset, e + C.offset, done);   // x += P e (slab-local)
     return mg_smooth(mg, L, b, cur, other, mg->nu, false, done, result, l == 0);
 }
 
