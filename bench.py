@@ -299,6 +299,10 @@ def main():
     fmt_text = {"pattern": "lossless row-pattern form (1 byte per row: 27 distinct rows-as-sequences; opt-in analysis, results bit-identical)",
                 "dcsr": "lossless dictionary-compressed CSR (2 B/nnz; opt-in analysis, results bit-identical)",
                 "csr": "plain CSR (12 B/nnz)"}[fmt]
+    overlap = None
+    if world > 1 and a.solver == "cg":
+        ov = (C.c_longlong * 2)(0, 0)
+        overlap = {"active": bool(L.MgcgLastOverlap(ov)), "interior_rows": [int(ov[0]), int(ov[1])], "local_rows": int(rows_local)}
     if rank == 0:
         spmv_bytes = 12 * nnz_local + 4 * (rows_local + 1) + 16 * rows_local     # per launch, per GPU
         achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
@@ -346,6 +350,8 @@ def main():
                                         "frac": spmv_bytes / (csr_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "avg_launch_ms": csr_ms,
                                         "measured_read_only_gbps": read_gbps, "measured_copy_gbps": copy_gbps,
                                         "frac_of_measured_read_only": spmv_bytes / (csr_ms * 1e-3) / 1e9 / read_gbps if read_gbps > 0 else None}
+        if overlap is not None:
+            out["config"]["halo_overlap_rank0"] = overlap
         out["config"]["matrix_format_in_loop"] = fmt_text + ("" if fmt == "csr" else f" -- built once by MgcgSetMatrixCompression({a.compression})")
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, a.cpu_iters)
