@@ -66,6 +66,34 @@ __global__ __launch_bounds__(256) void r_kernel(d2* __restrict__ r, const d2* __
     if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// chunk mapping with a compile-time workgroup size (the library uses 256)
+template <int BLOCK, int U, bool NT>
+__global__ __launch_bounds__(BLOCK) void xp_chunk_kernel(d2* __restrict__ x, d2* __restrict__ p, const d2* __restrict__ z, long long n2, double a, double b)
+{
+    const long long per = ((n2 + gridDim.x - 1) / gridDim.x + (BLOCK - 1)) & ~(long long)(BLOCK - 1);
+    long long i = per * blockIdx.x + threadIdx.x, end = per * (blockIdx.x + 1);
+    if (end > n2) end = n2;
+    for (; i + (U - 1) * BLOCK < end; i += U * BLOCK) {
+        d2 pv[U], xv[U], zv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pv[u] = NT ? __builtin_nontemporal_load(p + i + u * BLOCK) : p[i + u * BLOCK];
+            xv[u] = NT ? __builtin_nontemporal_load(x + i + u * BLOCK) : x[i + u * BLOCK];
+            zv[u] = NT ? __builtin_nontemporal_load(z + i + u * BLOCK) : z[i + u * BLOCK];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            xv[u].x += a * pv[u].x; xv[u].y += a * pv[u].y;
+            pv[u].x = zv[u].x + b * pv[u].x; pv[u].y = zv[u].y + b * pv[u].y;
+            if (NT) { __builtin_nontemporal_store(xv[u], x + i + u * BLOCK); __builtin_nontemporal_store(pv[u], p + i + u * BLOCK); }
+            else { x[i + u * BLOCK] = xv[u]; p[i + u * BLOCK] = pv[u]; }
+        }
+    }
+    for (; i < end; i += BLOCK) { d2 pv = p[i], xv = x[i], zv = z[i]; xv.x += a * pv.x; xv.y += a * pv.y; pv.x = zv.x + b * pv.x; pv.y = zv.y + b * pv.y; x[i] = xv; p[i] = pv; }
+}
+template <int BLOCK, int U, bool NT>
+static void go_xpc(int grid, d2* x, d2* p, d2* z, long long n2, double*) { hipLaunchKernelGGL((xp_chunk_kernel<BLOCK, U, NT>), dim3(grid), dim3(BLOCK), 0, 0, x, p, z, n2, 1e-9, 0.999999); }
+
 struct Variant { std::string name; int kind; int grid; void (*launch)(int, d2*, d2*, d2*, long long, double*); };
 
 template <int U, bool NTS, bool NTL, bool CHUNK>
@@ -85,7 +113,16 @@ int main(int argc, char** argv)
     d2* x = (d2*)xb; d2* p = (d2*)(pb + skewBytes); d2* z = (d2*)(zb + 2 * skewBytes);
     printf("x %p  p %p  z %p  (skew %lld B)\n", (void*)x, (void*)p, (void*)z, skewBytes);
     std::vector<Variant> vs;
-    for (int g : { 1024, 2048, 4096 }) {
+    for (int g : { 1024, 2048, 4096, 8192 }) {
+        vs.push_back({ "xpc B128 U2 nt g" + std::to_string(g), 0, g, go_xpc<128, 2, true> });
+        vs.push_back({ "xpc B128 U4 nt g" + std::to_string(g), 0, g, go_xpc<128, 4, true> });
+        vs.push_back({ "xpc B256 U2 nt g" + std::to_string(g), 0, g, go_xpc<256, 2, true> });
+        vs.push_back({ "xpc B256 U4 nt g" + std::to_string(g), 0, g, go_xpc<256, 4, true> });
+        vs.push_back({ "xpc B512 U2 nt g" + std::to_string(g), 0, g, go_xpc<512, 2, true> });
+        vs.push_back({ "xpc B512 U1 nt g" + std::to_string(g), 0, g, go_xpc<512, 1, true> });
+        vs.push_back({ "xpc B256 U2 g" + std::to_string(g), 0, g, go_xpc<256, 2, false> });
+    }
+    for (int g : { 2048 }) {
         vs.push_back({ "xp U1 chunk g" + std::to_string(g), 0, g, go_xp<1, false, false, true> });
         vs.push_back({ "xp U4 chunk g" + std::to_string(g), 0, g, go_xp<4, false, false, true> });
         vs.push_back({ "xp U2 chunk nts ntl g" + std::to_string(g), 0, g, go_xp<2, true, true, true> });
