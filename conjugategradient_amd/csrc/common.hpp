@@ -200,7 +200,7 @@ inline int spmv_auto_kernel(double avgRow)
     if (avgRow <= 8.0) return 9;
     if (avgRow <= 20.0) return 1;
     if (avgRow <= 28.0) return 5;
-    if (avgRow <= 56.0) return 6;
+    if (avgRow <= 128.0) return 6;
     return 7;
 }
 

@@ -362,7 +362,19 @@ __global__ __launch_bounds__(kBlock) void spmv_vector_kernel(SpmvArgs a)
         double acc = 0.0;
         if (row < a.rowCount) {
             const int s = a.rowOffsets[row], e = a.rowOffsets[row + 1];
-            for (int k = s + sub; k < e; k += LANES) {
+            int k = s + sub;
+            // four strides of the row in flight per lane (values, column ids, then the four gathers), added in the same order
+            // as the rolled loop
+            for (; k + 3 * LANES < e; k += 4 * LANES) {
+                double v[4]; int c[4]; double xv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { v[u] = a.elements[k + u * LANES]; c[u] = a.columnIndeces[k + u * LANES]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xv[u] = a.x[c[u]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const double prod = v[u] * xv[u]; acc += prod; }
+            }
+            for (; k < e; k += LANES) {
                 double prod = a.elements[k] * a.x[a.columnIndeces[k]];
                 acc += prod;
             }
