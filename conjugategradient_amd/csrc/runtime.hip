@@ -127,6 +127,7 @@ const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* 
         if (tiled_build(h->ws.stream, elements, rowOffsets, columnIndeces, rows, nnz, rowBase, columns, m) && m->tileVals != nullptr) m->usable = true;
     }
     h->analysed.push_back(m);
+    h->analysedMode = h->compression;                  // (also when the mode came from MGCG_COMPRESSION, not from the setter)
     return m->usable ? m : nullptr;
 }
 
