@@ -102,6 +102,7 @@ SIGNATURES = {
     "SolveMg": (_i, [_vp] * 13 + [_i, _i, _d, _i, _i, _i, _pi, _pd, _vp, _i]),
     "SolveMgParallel": (_i, [_vp] * 14 + [_i, _i, _i, _i, _i, _i, _d, _i, _i, _i, _pi, _pd, _vp, _i]),
     "MgcgCommGetUniqueId": (_i, [_vp]),
+    "MgcgRcclAvailable": (_i, []),
     "MgcgCommInitRank": (_vp, [_vp, _i, _i]),
     "MgcgLoopbackCreate": (_vp, [_i]),
     "MgcgLoopbackDestroy": (None, [_vp]),

@@ -274,6 +274,8 @@ using namespace mgcg;
 
 extern "C" {
 
+int MgcgRcclAvailable(void) { return mgcg::rccl() != nullptr ? 1 : 0; }
+
 int MgcgCommGetUniqueId(void* id128)
 {
     Rccl* r = rccl();

@@ -151,6 +151,10 @@ struct MgcgSparse {
     int analysedMode = 0;               // the compression mode the cached analyses were built under
     int compression = 0;                // opt-in: 0 off, 1 best lossless compact form (row patterns, else per-nonzero codes), 2 per-nonzero codes only
     std::vector<mgcg::DcsrMatrix*> analysed;
+    // far-band distance found per matrix (the tile order of the row-tile kernel; any value gives the same results, so a stale
+    // entry can only cost locality): keyed by the array pointers and the row count
+    struct PeriodEntry { const int* rowOffsets; const int* columnIndeces; long long rows, rowBase; int period; };
+    std::vector<PeriodEntry> periods;
 };
 struct MgcgMatDescr { int type = 0; int base = 0; };
 struct Vector    { double* data = nullptr; long long size = 0; int device = -1; };
@@ -194,10 +198,11 @@ struct SpmvArgs {
 };
 
 // Kernel family by average row length (measured on banded and random matrices, profiles/r1/rowlen_sweep.log):
-// 9 row-block "lane = row" form, 1 row-block stream form, 5 / 6 / 7 = 8 / 16 / 32 lanes per row.
+// 10 row-tile "lane = row" form (kernels_rowtile.hip; 9 = its single-wavefront predecessor, kernels_rows.hip),
+// 1 row-block stream form, 5 / 6 / 7 = 8 / 16 / 32 lanes per row.
 inline int spmv_auto_kernel(double avgRow)
 {
-    if (avgRow <= 8.0) return 9;
+    if (avgRow <= 8.0) return 10;
     if (avgRow <= 20.0) return 1;
     if (avgRow <= 28.0) return 5;
     if (avgRow <= 128.0) return 6;
@@ -208,6 +213,13 @@ struct SpmvConfig { int kernel = 0; int rowsPerBlock = 64; int flags = 0; int gr
 
 // Launches the SpMV; returns the number of partials written (grid size) for dot epilogues.
 int launch_spmv(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg);
+// Row-tile kernel for short rows on plain CSR (kernels_rowtile.hip); periodRows = distance of the far band in rows (0: unknown),
+// gridReq = wavefronts (0: 8 per CU).  Needs 16-byte aligned elements / columnIndeces and elementsCount >= 8.
+int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int periodRows, int gridReq);
+// Distance (in rows) of the farthest band of the matrix, read off one row in the middle of the slice (one tiny kernel and a
+// 4-byte read, remembered per handle); the caller's hint (MgcgSetSpmvPeriod) wins.  0: not found.
+int spmv_period(MgcgSparse* h, const int* rowOffsets, const int* columnIndeces, long long rows, long long rowBase);
+void launch_far_band(hipStream_t s, const int* rowOffsets, const int* columnIndeces, long long row, long long rowBase, int* out);
 // The same on the dictionary-compressed form of the matrix (a.elements / a.columnIndeces still serve array tails and long rows).
 int launch_spmv_rows(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView* m, int gridReq);   // m == nullptr: plain CSR
 bool dcsr_build(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces,

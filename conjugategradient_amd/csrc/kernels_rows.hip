@@ -9,6 +9,7 @@
 // Same software pipeline as the stream kernel: gathers(t) -> epilogue operands(t) -> raw loads(t+1) -> y store(t-1),
 // so every wait is a counted vmcnt that leaves the prefetch and the store in flight.
 #include "common.hpp"
+#include "spmv_epilogue.hpp"
 
 namespace mgcg {
 
@@ -22,34 +23,6 @@ constexpr int kRR = 64;            // rows per trip (one per lane)
 constexpr int kRCap = 512;         // nonzeros staged per pass (8 per lane)
 constexpr int kRAlign = 32;        // spans are read from a 32-nonzero boundary (128 B of column ids / 32 B of codes)
 constexpr int kRDict = 256;
-
-struct RowsEpi { double w, b, dinv, yold; };
-
-template <int EPI>
-__device__ __forceinline__ RowsEpi rows_epi_prefetch(const SpmvArgs& a, long long row)
-{
-    RowsEpi o; o.w = 0.0; o.b = 0.0; o.dinv = 0.0; o.yold = 0.0;
-    if constexpr (EPI == EPI_AXPBY_BETA) o.yold = a.y[row];
-    if constexpr (EPI == EPI_DOT) o.w = a.w[row];
-    if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_DOT) o.b = a.b[row];
-    if constexpr (EPI == EPI_JACOBI || EPI == EPI_JACOBI_DOT) { o.b = a.b[row]; o.dinv = a.dinvUniform ? a.dinvScalar : a.dinv[row]; o.w = a.w[row]; }
-    return o;
-}
-
-template <int EPI>
-__device__ __forceinline__ double rows_epilogue_value(const SpmvArgs& a, double acc, const RowsEpi& o, double& dotacc)
-{
-    if constexpr (EPI == EPI_AXPBY) return a.alpha * acc;
-    else if constexpr (EPI == EPI_AXPBY_BETA) { double v = a.alpha * acc; double t = a.beta * o.yold; return v + t; }
-    else if constexpr (EPI == EPI_DOT) { double t = o.w * acc; dotacc += t; return acc; }
-    else if constexpr (EPI == EPI_RESIDUAL) return o.b - acc;
-    else if constexpr (EPI == EPI_RESIDUAL_DOT) { double r = o.b - acc; double t = r * r; dotacc += t; return r; }
-    else {
-        double res = o.b - acc; double t = o.dinv * res; double s = a.omega * t; const double v = o.w + s;
-        if constexpr (EPI == EPI_JACOBI_DOT) { double q = o.b * v; dotacc += q; }
-        return v;
-    }
-}
 
 // Raw data of one pass held in registers between the prefetch and the LDS staging.
 template <int FMT>

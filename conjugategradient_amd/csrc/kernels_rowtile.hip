@@ -1,0 +1,248 @@
+// Row-tile SpMV for short rows (gfx950): the default CSR kernel when the average row has <= 8 nonzeros.
+// Replaces cusparseDcsrmv of Mgcg/cuBlas/MgcgGpu/Mgcg.cu:10-19 on plain CSR arrays (nothing is re-encoded or cached).
+//
+// A workgroup of four wavefronts owns one tile of 256 consecutive rows per trip; inside it every wavefront is on its own:
+// 64 rows, lane = row, a private 6 KB slice of LDS.  Per trip a wavefront
+//   1. parks the raw column ids / values of its 64 rows (one contiguous span of the CSR arrays, fetched one trip earlier
+//      with 16-byte loads) in LDS,
+//   2. reads its own row's entries back (lane = row), issues the x gathers, the epilogue operands, the y store of the
+//      PREVIOUS trip, the raw loads of the NEXT trip and the row offsets of the trip after that -- in this order, all
+//      unconditional, so that every wait is a counted vmcnt that leaves the younger prefetches in flight,
+//   3. forms acc += value * x[col] in stored order (product rounded, then added: bit-identical to
+//      Mgcg/cuBlas/Mgcg/SparseMatrix.cs:68-88) and the epilogue value.
+// What the measurements behind this shape say (conjugategradient_amd/tools/spmv_lab.hip, profiles/r2/spmv_lab_*.log):
+//   * four wavefronts that issue the raw loads of four adjacent 64-row blocks together (one barrier per trip keeps them
+//     in step) stream 7-10 % faster than four independent wavefronts: the HBM rows of a 26 KB span are opened once;
+//   * 8 wavefronts per CU (grid = 2 workgroups per CU) is the sweet spot; 10-14 and 20 per CU lose 15-25 %;
+//   * the y store costs 0.3-0.5 ms per GB whatever its shape (write-to-read turnarounds of the HBM); a non-temporal store
+//     issued between the gathers and the next raw loads hides its latency and is the cheapest form measured;
+//   * with a known plane stride (7-point stencils) the tiles are walked plane by plane inside one eighth of the
+//     xy-plane per XCD ("z sweep"): the +-plane and +-line neighbours of a row are then multiplied on the same XCD one
+//     trip apart and x is fetched from beyond L2 1.1 times instead of 4.7 times (PMC: 12.97 GB read for 12.87 GB
+//     algorithmic at 512^3).
+// Blocks the fast path cannot take (a span of more than 512 nonzeros, a row of more than 8, the ragged end of the arrays)
+// are multiplied row by row from global memory by the same wavefront (slow, rare for the matrices this kernel is chosen for).
+#include "common.hpp"
+#include "spmv_epilogue.hpp"
+#include <type_traits>
+
+namespace mgcg {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef int i4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTW = 4;              // wavefronts per workgroup
+constexpr int kTRows = 64 * kTW;    // rows per tile
+constexpr int kTCap = 512;          // nonzeros a wavefront stages per trip
+
+// Order in which the tiles are walked.  mode 0: tile = workgroup + trip * workgroups.  mode 1 (z sweep): XCD k = workgroup % 8
+// owns the k-th eighth of the tiles of every plane, cut into nSlices slices of sliceW tiles; its workgroups walk
+// slice 0 of plane 0, 1, ..., nPlanes - 1, then slice 1 of every plane, ...
+struct TileMap { int mode; int tilesPerPlane; int nPlanes; int sliceW; int nSlices; };
+
+template <int EPI>
+__device__ __forceinline__ RowsEpi tile_epi_prefetch(const SpmvArgs& a, int row)
+{
+    // as rows_epi_prefetch, but without a conditional load (a branch around a load would make the waits uncounted)
+    RowsEpi o; o.w = 0.0; o.b = 0.0; o.dinv = 0.0; o.yold = 0.0;
+    if constexpr (EPI == EPI_AXPBY_BETA) o.yold = a.y[row];
+    if constexpr (EPI == EPI_DOT) o.w = a.w[row];
+    if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_DOT) o.b = a.b[row];
+    if constexpr (EPI == EPI_JACOBI || EPI == EPI_JACOBI_DOT) {
+        o.b = a.b[row]; o.w = a.w[row];
+        const double* dp = a.dinvUniform ? a.b : a.dinv;      // uniform diagonal: the array is not read (a.b stands in, same line as o.b)
+        const double dl = dp[row];
+        o.dinv = a.dinvUniform ? a.dinvScalar : dl;
+    }
+    return o;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, TileMap tm, int nTiles)
+{
+    __shared__ __attribute__((aligned(16))) int s_colAll[kTCap * kTW];
+    __shared__ __attribute__((aligned(16))) double s_valAll[kTCap * kTW];
+    if (a.doneFlag != nullptr && *a.doneFlag != 0) return;
+    const int tid = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int* s_col = s_colAll + wv * kTCap;
+    double* s_val = s_valAll + wv * kTCap;
+    const int wg = blockIdx.x, nWG = gridDim.x;
+    const int lastRow = a.rowCount - 1;                // (the loop runs over full tiles only: every row index below is <= lastRow)
+    const int kMax4 = (a.elementsCount - 4) & ~3;     // last aligned quad of column ids that lies inside the arrays
+    const int kMax2 = (a.elementsCount - 2) & ~1;
+
+    // ---- the trips of this workgroup (workgroup-uniform, scalar)
+    const int perXcd = nWG >> 3, xcd = wg & 7, slot = wg >> 3;
+    const int planeItems = tm.nPlanes * tm.sliceW;                 // mode 1: tiles of one slice over all planes
+    const int xcdItems = tm.nSlices * planeItems;
+    int nTrips;
+    if (tm.mode == 0) nTrips = nTiles > wg ? (nTiles - wg + nWG - 1) / nWG : 0;
+    else nTrips = xcdItems > slot ? (xcdItems - slot + perXcd - 1) / perXcd : 0;
+    double dot = 0.0;
+    auto finish = [&]() {
+        // rows behind the last full tile: workgroup 0, one row per thread, straight from global memory
+        const int tailRow = nTiles * kTRows + (int)threadIdx.x;
+        if (wg == 0 && tailRow <= lastRow) {
+            double acc = 0.0;
+            for (int k = a.rowOffsets[tailRow]; k < a.rowOffsets[tailRow + 1]; ++k) { const double p = a.elements[k] * a.x[a.columnIndeces[k]]; acc += p; }
+            const RowsEpi eo = rows_epi_prefetch<EPI>(a, tailRow);
+            a.y[tailRow] = rows_epilogue_value<EPI>(a, acc, eo, dot);
+        }
+        if constexpr (epi_has_dot(EPI)) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dot += __shfl_down(dot, off, 64);
+            if (tid == 0) a.partials[blockIdx.x * kTW + wv] = dot;
+        }
+    };
+    if (nTrips <= 0) { finish(); return; }                         // (workgroup-uniform)
+    auto tile_of = [&](int t) -> int {
+        t = t < nTrips ? t : nTrips - 1;                           // past the end: the last tile again (loads only, results unused)
+        if (tm.mode == 0) return wg + nWG * t;
+        const int m = t * perXcd + slot;
+        const int h = m / planeItems, rem = m - h * planeItems;
+        const int p = rem / tm.sliceW, j = rem - p * tm.sliceW;
+        return p * tm.tilesPerPlane + xcd * (tm.tilesPerPlane >> 3) + h * tm.sliceW + j;
+    };
+
+    // ---- per-trip pieces
+    int roA_s, roA_e, roB_s, roB_e;                                // row offsets of my row: this trip / next trip
+    i4 c0, c1; d2 v0, v1, v2, v3;                                  // raw span of this wavefront's 64 rows
+    auto load_ro = [&](int tile, int& rs, int& re) {
+        const int r = tile * kTRows + wv * 64 + tid;
+        rs = a.rowOffsets[r]; re = a.rowOffsets[r + 1];
+    };
+    auto load_raw = [&](int s) {
+        const int tb = s & ~3;
+        int k0 = tb + 4 * tid, k1 = k0 + 256;
+        k0 = k0 < kMax4 ? k0 : kMax4; k1 = k1 < kMax4 ? k1 : kMax4;
+        c0 = *(const i4*)(a.columnIndeces + k0); c1 = *(const i4*)(a.columnIndeces + k1);
+        int j0 = tb + 2 * tid, j1 = j0 + 128, j2 = j0 + 256, j3 = j0 + 384;
+        j0 = j0 < kMax2 ? j0 : kMax2; j1 = j1 < kMax2 ? j1 : kMax2; j2 = j2 < kMax2 ? j2 : kMax2; j3 = j3 < kMax2 ? j3 : kMax2;
+        v0 = *(const d2*)(a.elements + j0); v1 = *(const d2*)(a.elements + j1); v2 = *(const d2*)(a.elements + j2); v3 = *(const d2*)(a.elements + j3);
+    };
+
+    // prologue in the loop's own issue order: ro(0); raw(0); ro(1)
+    int tileCur = tile_of(0), tileNext = tile_of(1);
+    load_ro(tileCur, roA_s, roA_e);
+    load_raw(__builtin_amdgcn_readfirstlane(roA_s));
+    load_ro(tileNext, roB_s, roB_e);
+
+    double pend = 0.0;
+    int pendRow = tileCur * kTRows + wv * 64 + tid;
+    // (the first store of the loop writes 0.0 to the first row, which the same lane overwrites one trip later; for epilogues
+    //  that read y or an operand aliased with y the read of a row is always issued before any store to it)
+    for (int t = 0; t < nTrips; ++t) {
+        const int s = __builtin_amdgcn_readfirstlane(roA_s);
+        const int e = __builtin_amdgcn_readlane(roA_e, 63);
+        const int tb = s & ~3;
+        const int my_s = roA_s, cnt = roA_e - roA_s;
+        const int row = tileCur * kTRows + wv * 64 + tid;
+        // the fast path holds the whole span in one pass and every row in one batch of gathers
+        const bool spanOk = (e - tb <= kTCap) && (e <= kMax4 + 4);
+        const bool short8 = __ballot(cnt > 8) == 0ull;
+        const bool fast = spanOk && short8;                        // wavefront-uniform
+
+        *(i4*)(s_col + 4 * tid) = c0; *(i4*)(s_col + 256 + 4 * tid) = c1;
+        *(d2*)(s_val + 2 * tid) = v0; *(d2*)(s_val + 128 + 2 * tid) = v1; *(d2*)(s_val + 256 + 2 * tid) = v2; *(d2*)(s_val + 384 + 2 * tid) = v3;
+        __syncthreads();
+        int cc[8]; double vv[8], xg[8];
+        double accSlow = 0.0;
+        if (fast) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int idx = my_s - tb + j;
+                idx = j < cnt ? idx : 0;                           // masked slots read entry 0 of the span (a valid column)
+                cc[j] = s_col[idx]; vv[j] = s_val[idx];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { cc[j] = 0; vv[j] = 0.0; }
+            for (int k = my_s; k < roA_e; ++k) { const double p = a.elements[k] * a.x[a.columnIndeces[k]]; accSlow += p; }
+        }
+        __builtin_amdgcn_sched_barrier(0);                         // all LDS reads in flight before the first gather waits for its column id
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xg[j] = a.x[cc[j]];
+        const RowsEpi eo = tile_epi_prefetch<EPI>(a, row);
+        // the previous trip's result, then the next trip's raw stream and the row offsets of the trip after it
+        __builtin_nontemporal_store(pend, a.y + pendRow);
+        load_raw(__builtin_amdgcn_readfirstlane(roB_s));
+        roA_s = roB_s; roA_e = roB_e;
+        const int tileAfter = tile_of(t + 2);
+        load_ro(tileAfter, roB_s, roB_e);
+        __builtin_amdgcn_sched_barrier(0);                         // no product in front of the prefetch: its wait would hold the raw loads back
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const double p = vv[j] * xg[j]; acc += (j < cnt) ? p : 0.0; }
+        acc = fast ? acc : accSlow;
+        pend = rows_epilogue_value<EPI>(a, acc, eo, dot);
+        pendRow = row;
+        __syncthreads();
+        tileCur = tileNext; tileNext = tileAfter;
+    }
+    __builtin_nontemporal_store(pend, a.y + pendRow);
+    finish();
+}
+
+__global__ void far_band_kernel(const int* rowOffsets, const int* columnIndeces, long long row, long long rowBase, int* out)
+{
+    long long far = 0;
+    for (int k = rowOffsets[row]; k < rowOffsets[row + 1]; ++k) {
+        long long d = (long long)columnIndeces[k] - (rowBase + row);
+        d = d < 0 ? -d : d;
+        far = d > far ? d : far;
+    }
+    *out = far > 0x7fffffffLL ? 0 : (int)far;
+}
+void launch_far_band(hipStream_t s, const int* rowOffsets, const int* columnIndeces, long long row, long long rowBase, int* out)
+{
+    hipLaunchKernelGGL(far_band_kernel, dim3(1), dim3(1), 0, s, rowOffsets, columnIndeces, row, rowBase, out);
+}
+
+// Tile order for a matrix of `rows` rows whose far band lies periodRows rows from the diagonal (0: unknown).
+static TileMap make_tile_map(long long rows, int periodRows, int nWG)
+{
+    TileMap tm{};
+    tm.mode = 0;
+    if (periodRows <= 0 || (nWG & 7) != 0) return tm;
+    if (periodRows % (kTRows * 8) != 0 || rows % periodRows != 0) return tm;
+    const int tilesPerPlane = periodRows / kTRows, eighth = tilesPerPlane / 8, perXcd = nWG / 8;
+    const int nSlices = (eighth + perXcd - 1) / perXcd;
+    if (eighth % nSlices != 0) return tm;
+    const long long nPlanes = rows / periodRows;
+    if (nPlanes < 3 || nPlanes > 65535) return tm;
+    tm.mode = 1; tm.tilesPerPlane = tilesPerPlane; tm.nPlanes = (int)nPlanes; tm.sliceW = eighth / nSlices; tm.nSlices = nSlices;
+    return tm;
+}
+
+template <int EPI>
+static int launch_rowtile_epi(hipStream_t s, const SpmvArgs& a, int periodRows, int gridReq)
+{
+    const int nTiles = a.rowCount / kTRows;                       // full tiles; the kernel's workgroup 0 takes the rows behind them
+    DeviceState* d = device_state();
+    const int numCu = d ? d->numCu : kNumCu;
+    int nWG = gridReq > 0 ? gridReq / kTW : 2 * numCu;            // 8 wavefronts per CU
+    if (nWG * kTW > kMaxPartials) nWG = kMaxPartials / kTW;
+    if (nWG > nTiles) nWG = nTiles;
+    if (nWG < 1) nWG = 1;
+    static const bool noSweep = getenv("MGCG_NO_ZSWEEP") != nullptr;
+    const TileMap tm = make_tile_map(a.rowCount, noSweep ? 0 : periodRows, nWG);
+    hipLaunchKernelGGL((spmv_rowtile_kernel<EPI>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
+    return nWG * kTW;
+}
+
+// Requires 16-byte aligned elements and columnIndeces and elementsCount >= 8 (checked by the caller).
+int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int periodRows, int gridReq)
+{
+    if (a.rowCount <= 0) return 0;
+    switch (epilogue) {
+    case EPI_AXPBY:        return a.beta != 0.0 ? launch_rowtile_epi<EPI_AXPBY_BETA>(s, a, periodRows, gridReq) : launch_rowtile_epi<EPI_AXPBY>(s, a, periodRows, gridReq);
+    case EPI_DOT:          return launch_rowtile_epi<EPI_DOT>(s, a, periodRows, gridReq);
+    case EPI_RESIDUAL:     return launch_rowtile_epi<EPI_RESIDUAL>(s, a, periodRows, gridReq);
+    case EPI_RESIDUAL_DOT: return launch_rowtile_epi<EPI_RESIDUAL_DOT>(s, a, periodRows, gridReq);
+    case EPI_JACOBI:       return launch_rowtile_epi<EPI_JACOBI>(s, a, periodRows, gridReq);
+    case EPI_JACOBI_DOT:   return launch_rowtile_epi<EPI_JACOBI_DOT>(s, a, periodRows, gridReq);
+    }
+    return 0;
+}
+
+} // namespace mgcg

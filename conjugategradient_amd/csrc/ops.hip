@@ -17,6 +17,12 @@ static SpmvConfig cfg_of(const MgcgSparse* h)
     SpmvConfig c; c.kernel = h->kernel; c.rowsPerBlock = h->rowsPerBlock; c.flags = h->flags; c.gridBlocks = h->gridBlocks; c.periodRows = h->periodRows; c.tileRows = h->tileRows; c.tilePlanes = h->tilePlanes;
     return c;
 }
+static SpmvConfig cfg_for(MgcgSparse* h, const SpmvArgs& a, long long rowBase)
+{
+    SpmvConfig c = cfg_of(h);
+    if (c.periodRows == 0 && a.elementsCount >= 8) c.periodRows = spmv_period(h, a.rowOffsets, a.columnIndeces, a.rowCount, rowBase);
+    return c;
+}
 
 // sum of `n` partials -> host double (blocking)
 static double finish_reduction(Workspace& ws, int n, int mode)
@@ -47,7 +53,7 @@ void CsrMV(MgcgSparse* cusparse, MgcgMatDescr* matDescr, double* y,
     a.elementsCount = elementsCount; a.rowCount = rowCount; a.columnCount = columnCount; a.alpha = alpha; a.beta = beta;
     if (const char* ab = getenv("MGCG_SPMV_ABLATE")) a.ablate = atoi(ab);     // timing diagnostics only (wrong results)
     const DcsrMatrix* dc = dcsr_lookup(cusparse, elements, rowOffsets, columnIndeces, rowCount, elementsCount, 0, columnCount);
-    launch_spmv_auto(cusparse->ws.stream, EPI_AXPBY, a, cfg_of(cusparse), dc);
+    launch_spmv_auto(cusparse->ws.stream, EPI_AXPBY, a, cfg_for(cusparse, a, 0), dc);
     (void)MGCG_HIP(hipGetLastError());
 }
 
@@ -63,7 +69,7 @@ double CsrMVDot(MgcgBlas* cublas, MgcgSparse* cusparse, double* y,
     a.elements = elements; a.rowOffsets = rowOffsets; a.columnIndeces = columnIndeces; a.x = x; a.y = y;
     a.elementsCount = elementsCount; a.rowCount = rowCount; a.columnCount = columnCount; a.w = w; a.partials = cublas->ws.partials;
     const DcsrMatrix* dc = dcsr_lookup(cusparse, elements, rowOffsets, columnIndeces, rowCount, elementsCount, 0, columnCount);
-    const int n = launch_spmv_auto(cublas->ws.stream, EPI_DOT, a, cfg_of(cusparse), dc);
+    const int n = launch_spmv_auto(cublas->ws.stream, EPI_DOT, a, cfg_for(cusparse, a, 0), dc);
     return finish_reduction(cublas->ws, n, 0);
 }
 
@@ -223,7 +229,7 @@ double Solve0(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr,
     a.elements = elementsVector->data; a.rowOffsets = rowOffsetsVector->data; a.columnIndeces = columnIndecesVector->data;
     a.x = pVector->data; a.y = ApVector->data; a.elementsCount = elementsCountForDevice; a.rowCount = countForDevice; a.columnCount = count;
     a.alpha = 1.0; a.beta = 0.0;
-    launch_spmv(s, EPI_AXPBY, a, cfg_of(cusparse));                                   // Ap = A p            (:138)
+    launch_spmv(s, EPI_AXPBY, a, cfg_for(cusparse, a, offsetForDevice));              // Ap = A p            (:138)
     launch_copy(s, rVector->data, bVector->data, countForDevice);                     // r = b               (:139)
     launch_axpy(s, rVector->data, ApVector->data, countForDevice, -1.0);              // r -= Ap
     launch_copy(s, pVector->data + offsetForDevice, rVector->data, countForDevice);   // p[offset..] = r     (:140)
@@ -245,7 +251,7 @@ double Solve1(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr,
     a.elements = elementsVector->data; a.rowOffsets = rowOffsetsVector->data; a.columnIndeces = columnIndecesVector->data;
     a.x = pVector->data; a.y = ApVector->data; a.elementsCount = elementsCountForDevice; a.rowCount = countForDevice; a.columnCount = count;
     a.w = pVector->data + offsetForDevice; a.partials = cublas->ws.partials;
-    const int n = launch_spmv(cublas->ws.stream, EPI_DOT, a, cfg_of(cusparse));       // Ap = A p ; p_loc.Ap  (:161-162) in one pass
+    const int n = launch_spmv(cublas->ws.stream, EPI_DOT, a, cfg_for(cusparse, a, offsetForDevice));   // Ap = A p ; p_loc.Ap  (:161-162) in one pass
     return finish_reduction(cublas->ws, n, 0);
 }
 

@@ -131,6 +131,22 @@ const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* 
     return m->usable ? m : nullptr;
 }
 
+int spmv_period(MgcgSparse* h, const int* rowOffsets, const int* columnIndeces, long long rows, long long rowBase)
+{
+    if (!h || rows < 4096) return 0;
+    if (h->periodRows > 0) return h->periodRows;
+    for (const auto& e : h->periods)
+        if (e.rowOffsets == rowOffsets && e.columnIndeces == columnIndeces && e.rows == rows && e.rowBase == rowBase) return e.period;
+    int period = 0;
+    int* slot = (int*)&h->ws.hostScalar[3];                 // pinned, device-visible
+    *slot = 0;
+    launch_far_band(h->ws.stream, rowOffsets, columnIndeces, rows / 2, rowBase, slot);
+    if (MGCG_HIP(hipGetLastError()) && MGCG_HIP(hipStreamSynchronize(h->ws.stream))) period = *slot;
+    if (h->periods.size() >= 64) h->periods.clear();
+    h->periods.push_back({ rowOffsets, columnIndeces, rows, rowBase, period });
+    return period;
+}
+
 int launch_spmv_auto(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg, const DcsrMatrix* dc)
 {
     if (dc != nullptr && dc->usable && a.elementsCount >= 8) {

@@ -1,0 +1,36 @@
+// Epilogue pieces shared by the lane = row SpMV kernels (kernels_rows.hip, kernels_rowtile.hip): the operands a row's
+// epilogue needs are loaded early (behind the gathers), the value is formed after the row sum.
+#pragma once
+#include "common.hpp"
+
+namespace mgcg {
+
+struct RowsEpi { double w, b, dinv, yold; };
+
+template <int EPI>
+__device__ __forceinline__ RowsEpi rows_epi_prefetch(const SpmvArgs& a, long long row)
+{
+    RowsEpi o; o.w = 0.0; o.b = 0.0; o.dinv = 0.0; o.yold = 0.0;
+    if constexpr (EPI == EPI_AXPBY_BETA) o.yold = a.y[row];
+    if constexpr (EPI == EPI_DOT) o.w = a.w[row];
+    if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_DOT) o.b = a.b[row];
+    if constexpr (EPI == EPI_JACOBI || EPI == EPI_JACOBI_DOT) { o.b = a.b[row]; o.dinv = a.dinvUniform ? a.dinvScalar : a.dinv[row]; o.w = a.w[row]; }
+    return o;
+}
+
+template <int EPI>
+__device__ __forceinline__ double rows_epilogue_value(const SpmvArgs& a, double acc, const RowsEpi& o, double& dotacc)
+{
+    if constexpr (EPI == EPI_AXPBY) return a.alpha * acc;
+    else if constexpr (EPI == EPI_AXPBY_BETA) { double v = a.alpha * acc; double t = a.beta * o.yold; return v + t; }
+    else if constexpr (EPI == EPI_DOT) { double t = o.w * acc; dotacc += t; return acc; }
+    else if constexpr (EPI == EPI_RESIDUAL) return o.b - acc;
+    else if constexpr (EPI == EPI_RESIDUAL_DOT) { double r = o.b - acc; double t = r * r; dotacc += t; return r; }
+    else {
+        double res = o.b - acc; double t = o.dinv * res; double s = a.omega * t; const double v = o.w + s;
+        if constexpr (EPI == EPI_JACOBI_DOT) { double q = o.b * v; dotacc += q; }
+        return v;
+    }
+}
+
+} // namespace mgcg

@@ -9,7 +9,7 @@ ARGS="$*"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 export PYTHONPATH=$GRAFT_REPO_ROOT
-BENCH="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline $ARGS"
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras $ARGS"
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/stats" -- $BENCH) > "$OUT/stats.log" 2>&1
 echo "stats rc=$?"
 (cd /tmp && rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/pmc_rd" -- $BENCH) > "$OUT/pmc_rd.log" 2>&1

@@ -297,6 +297,10 @@ int     SolveMg(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr, 
 /* 128-byte RCCL unique id created on one rank and handed to every rank by the launcher
  * (torch.distributed store / MPI / a file). Returns 0 on success. */
 int       MgcgCommGetUniqueId(void* id128);
+/* 1 if librccl resolved in this process with every entry point the library binds, else 0 (MgcgGetLastError says why).
+ * ncclCommInitRank is collective: launchers agree on this (and on one device per local rank) over their own channel
+ * BEFORE any rank calls MgcgCommInitRank, so that a rank that cannot enter it never leaves the others blocked inside. */
+int       MgcgRcclAvailable(void);
 MgcgComm* MgcgCommInitRank(const void* id128, int nranks, int rank);
 void      MgcgCommDestroy(MgcgComm* comm);
 int       MgcgCommRank(const MgcgComm* comm);
