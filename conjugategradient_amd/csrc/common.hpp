@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstring>
 #include <cmath>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -123,6 +124,7 @@ struct DcsrMatrix {
     double* tileVals = nullptr; int* tileCols = nullptr; int* tileRowIds = nullptr; int nTiles = 0; long long tileRows = 0;
     std::vector<int> tileStart;
     bool usable = false;
+    bool stale = false;          // a write through the library touched the arrays the analysis was made from: analyse again at the next use
     void release();
     DcsrView view() const
     {
@@ -235,6 +237,10 @@ int launch_spmv_tiled(hipStream_t s, int epilogue, const SpmvArgs& a, const Dcsr
 // Cached analysis of a matrix on a handle (nullptr: compression off, not applicable, or the build failed).
 const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* rowOffsets, const int* columnIndeces,
                               long long rows, long long nnz, long long rowBase, long long columns = 0);   // columns: length of x (0: unknown, no column tiling)
+// Every export that writes device memory (or frees it) names the range here: analyses made from arrays it overlaps go stale
+// and are rebuilt at their next use (the reference re-uploads A into the same vectors on every Initialize():
+// Mgcg/cuBlas/Mgcg/ConjugateGradientSingleGpu.cs:134-147).  Costs one relaxed atomic load when nothing is analysed.
+void analysis_note_write(const void* p, size_t bytes);
 // CSR or compressed, whichever the handle has for this matrix.
 int launch_spmv_auto(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg, const DcsrMatrix* dc);
 // Rows [r0, r1) of the same matrix (a describes the WHOLE local matrix; y, w, b, dinv are shifted here); partials for

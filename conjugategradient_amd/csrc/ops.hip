@@ -53,6 +53,7 @@ void CsrMV(MgcgSparse* cusparse, MgcgMatDescr* matDescr, double* y,
     a.elementsCount = elementsCount; a.rowCount = rowCount; a.columnCount = columnCount; a.alpha = alpha; a.beta = beta;
     if (const char* ab = getenv("MGCG_SPMV_ABLATE")) a.ablate = atoi(ab);     // timing diagnostics only (wrong results)
     const DcsrMatrix* dc = dcsr_lookup(cusparse, elements, rowOffsets, columnIndeces, rowCount, elementsCount, 0, columnCount);
+    analysis_note_write(y, sizeof(double) * (size_t)rowCount);
     launch_spmv_auto(cusparse->ws.stream, EPI_AXPBY, a, cfg_for(cusparse, a, 0), dc);
     (void)MGCG_HIP(hipGetLastError());
 }
@@ -77,6 +78,7 @@ void Axpy(MgcgBlas* cublas, double* y, const double* x, int count, double alpha)
 {
     NEED_DEVICE();
     if (!cublas || !y || !x) { set_error("Axpy: null argument"); return; }
+    if (count > 0) analysis_note_write(y, sizeof(double) * (size_t)count);
     launch_axpy(cublas->ws.stream, y, x, count, alpha);
     (void)MGCG_HIP(hipGetLastError());
 }
@@ -103,6 +105,7 @@ void Scal(MgcgBlas* cublas, double* x, double alpha, int count)
 {
     NEED_DEVICE();
     if (!cublas || !x) { set_error("Scal: null argument"); return; }
+    if (count > 0) analysis_note_write(x, sizeof(double) * (size_t)count);
     launch_scal(cublas->ws.stream, x, alpha, count);
     (void)MGCG_HIP(hipGetLastError());
 }
@@ -111,6 +114,7 @@ void Xpay(MgcgBlas* cublas, double* y, const double* x, int count, double beta)
 {
     NEED_DEVICE();
     if (!cublas || !y || !x) { set_error("Xpay: null argument"); return; }
+    if (count > 0) analysis_note_write(y, sizeof(double) * (size_t)count);
     launch_xpay(cublas->ws.stream, y, x, count, beta);
     (void)MGCG_HIP(hipGetLastError());
 }
@@ -119,6 +123,7 @@ void Copy(MgcgBlas* cublas, double* y, const double* x, int count, int yOffset, 
 {
     NEED_DEVICE();
     if (!cublas || !y || !x) { set_error("Copy: null argument"); return; }
+    if (count > 0) analysis_note_write(y + yOffset, sizeof(double) * (size_t)count);
     launch_copy(cublas->ws.stream, y + yOffset, x + xOffset, count);
 }
 
@@ -141,6 +146,10 @@ void Initialize(const double elements[], const int rowOffsets[], const int colum
         pVector->size < count) { set_error("Initialize: a device vector is too small for the partition"); return; }
     hipStream_t s = d->stream;
     bool ok = true;
+    // the reference re-uploads A into the same device vectors on every Initialize(): analyses made from them are void
+    analysis_note_write(elementsVector->data, sizeof(double) * (size_t)elementCountForDevice);
+    analysis_note_write(columnIndecesVector->data, sizeof(int) * (size_t)elementCountForDevice);
+    analysis_note_write(rowOffsetsVector->data, sizeof(int) * ((size_t)countForDevice + 1));
     if (elementCountForDevice > 0) {
         ok = ok && MGCG_HIP(hipMemcpyAsync(elementsVector->data, elements + elementOffsetForDevice, sizeof(double) * (size_t)elementCountForDevice, hipMemcpyHostToDevice, s));
         ok = ok && MGCG_HIP(hipMemcpyAsync(columnIndecesVector->data, columnIndeces + elementOffsetForDevice, sizeof(int) * (size_t)elementCountForDevice, hipMemcpyHostToDevice, s));
@@ -295,6 +304,9 @@ int MgcgGeneratePoisson(Vector* elementsVector, VectorInt* rowOffsetsVector, Vec
     if (!elementsVector || !rowOffsetsVector || !columnIndecesVector || elementsVector->size < nnz || columnIndecesVector->size < nnz || rowOffsetsVector->size < rows + 1) {
         set_error("MgcgGeneratePoisson: vectors too small (need %lld nnz, %lld rows)", nnz, rows); return -1;
     }
+    analysis_note_write(elementsVector->data, sizeof(double) * (size_t)nnz);
+    analysis_note_write(columnIndecesVector->data, sizeof(int) * (size_t)nnz);
+    analysis_note_write(rowOffsetsVector->data, sizeof(int) * ((size_t)rows + 1));
     launch_poisson(d->stream, nx, ny, nz, zBegin, zEnd, elementsVector->data, rowOffsetsVector->data, columnIndecesVector->data);
     return MGCG_HIP(hipGetLastError()) ? 0 : -1;
 }

@@ -102,17 +102,59 @@ bool Workspace::ensure_trace(int cap)
     return true;
 }
 
+// ---------------------------------------------------------------- analysed matrices: registry and invalidation
+// All analysed entries of all handles, so that a write through ANY handle or export can find the analyses it invalidates.
+static std::mutex g_analysedMutex;
+static std::vector<DcsrMatrix*> g_analysed;
+static std::atomic<int> g_analysedCount{0};
+
+static void registry_add(DcsrMatrix* m)
+{
+    std::lock_guard<std::mutex> lock(g_analysedMutex);
+    g_analysed.push_back(m);
+    g_analysedCount.store((int)g_analysed.size(), std::memory_order_relaxed);
+}
+void registry_remove(DcsrMatrix* m)
+{
+    std::lock_guard<std::mutex> lock(g_analysedMutex);
+    for (size_t i = 0; i < g_analysed.size(); ++i) if (g_analysed[i] == m) { g_analysed.erase(g_analysed.begin() + (long)i); break; }
+    g_analysedCount.store((int)g_analysed.size(), std::memory_order_relaxed);
+}
+void analysis_note_write(const void* p, size_t bytes)
+{
+    if (g_analysedCount.load(std::memory_order_relaxed) == 0 || p == nullptr || bytes == 0) return;
+    const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+    auto hits = [&](const void* base, size_t n) { const uintptr_t b = (uintptr_t)base; return base != nullptr && b < hi && lo < b + n; };
+    std::lock_guard<std::mutex> lock(g_analysedMutex);
+    for (DcsrMatrix* m : g_analysed)
+        if (hits(m->elements, sizeof(double) * (size_t)m->nnz) || hits(m->columnIndeces, sizeof(int) * (size_t)m->nnz) ||
+            hits(m->rowOffsets, sizeof(int) * (size_t)(m->rows + 1)))
+            m->stale = true;
+}
+
 const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* rowOffsets, const int* columnIndeces,
                               long long rows, long long nnz, long long rowBase, long long columns)
 {
     if (!h || h->compression == 0) return nullptr;
-    for (const DcsrMatrix* m : h->analysed)
-        if (m->elements == elements && m->rowOffsets == rowOffsets && m->columnIndeces == columnIndeces && m->rows == rows && m->nnz == nnz && m->rowBase == rowBase)
-            return m->usable ? m : nullptr;
-    if (rows <= 0 || nnz < 8) return nullptr;
-    const double avg = (double)nnz / (double)rows;
-    if (avg > 64.0) return nullptr;
-    DcsrMatrix* m = new DcsrMatrix();
+    DcsrMatrix* m = nullptr;
+    for (DcsrMatrix* q : h->analysed)
+        if (q->elements == elements && q->rowOffsets == rowOffsets && q->columnIndeces == columnIndeces && q->rows == rows && q->nnz == nnz && q->rowBase == rowBase) {
+            if (!q->stale) return q->usable ? q : nullptr;
+            m = q;                                          // written to since: same slot, new analysis
+            break;
+        }
+    if (m == nullptr && (rows <= 0 || nnz < 8)) return nullptr;
+    const double avg = rows > 0 ? (double)nnz / (double)rows : 0.0;
+    if (m == nullptr && avg > 64.0) return nullptr;
+    if (m != nullptr) {
+        (void)hipStreamSynchronize(h->ws.stream);           // kernels that still read the old form
+        m->release();
+        m->stale = false;
+    } else {
+        m = new DcsrMatrix();
+        h->analysed.push_back(m);
+        registry_add(m);
+    }
     auto identify = [&] { m->elements = elements; m->rowOffsets = rowOffsets; m->columnIndeces = columnIndeces; m->rows = rows; m->nnz = nnz; m->rowBase = rowBase; };
     identify();
     // 1. one byte per row (few distinct rows-as-sequences), 2. one or two bytes per nonzero (few distinct offsets / values;
@@ -126,7 +168,6 @@ const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* 
     if (!m->usable && h->compression == 1 && columns > 0) {
         if (tiled_build(h->ws.stream, elements, rowOffsets, columnIndeces, rows, nnz, rowBase, columns, m) && m->tileVals != nullptr) m->usable = true;
     }
-    h->analysed.push_back(m);
     h->analysedMode = h->compression;                  // (also when the mode came from MGCG_COMPRESSION, not from the setter)
     return m->usable ? m : nullptr;
 }
@@ -231,6 +272,7 @@ static void copy_from_array(V* dst, const T* src, int count, int srcOff, int dst
     if (!src || !dst) { set_error("%s: null argument", name); return; }
     if (count < 0 || dstOff < 0 || (long long)dstOff + count > dst->size) { set_error("%s: range [%d,+%d) outside vector of %lld", name, dstOff, count, dst->size); return; }
     if (count == 0) return;
+    analysis_note_write(dst->data + dstOff, sizeof(T) * (size_t)count);
     if (!MGCG_HIP(hipMemcpyAsync(dst->data + dstOff, src + srcOff, sizeof(T) * (size_t)count, hipMemcpyHostToDevice, d->stream))) return;
     (void)MGCG_HIP(hipStreamSynchronize(d->stream));   // pageable source must stay valid: complete before returning
 }
@@ -270,7 +312,7 @@ MgcgSparse* CreateSparse(void)
     const char* g = getenv("MGCG_SPMV_GRID");         if (g) h->gridBlocks = atoi(g);
     const char* tr = getenv("MGCG_SPMV_TILE_ROWS");   if (tr) h->tileRows = atoi(tr);
     const char* tp = getenv("MGCG_SPMV_TILE_PLANES"); if (tp) h->tilePlanes = atoi(tp);
-    const char* cm = getenv("MGCG_COMPRESSION");      if (cm) h->compression = atoi(cm) != 0;
+    const char* cm = getenv("MGCG_COMPRESSION");      if (cm) { const int v = atoi(cm); const int mode = v < 0 ? 0 : (v > 2 ? 1 : v); h->compression = mode; if (mode != 0) h->analysedMode = mode; }   // as MgcgSetMatrixCompression
     const char* p = getenv("MGCG_SPMV_PERIOD");       if (p) { h->periodRows = atoi(p); if (h->periodRows > 0) h->flags |= 4; }
     return h;
 }
@@ -278,7 +320,7 @@ void DestroySparse(MgcgSparse* h)
 {
     if (!h) return;
     if (h->ws.stream) (void)hipStreamSynchronize(h->ws.stream);      // kernels that still read the analysed forms
-    for (auto* m : h->analysed) { m->release(); delete m; }
+    for (auto* m : h->analysed) { registry_remove(m); m->release(); delete m; }
     for (hipEvent_t e : h->prof.start) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->prof.stop) (void)hipEventDestroy(e);
     h->ws.destroy();
@@ -299,7 +341,7 @@ void MgcgAnalysisClear(MgcgSparse* h)
     if (!h) return;
     DeviceState* d = device_state();
     if (d) (void)hipStreamSynchronize(d->stream);
-    for (auto* m : h->analysed) { m->release(); delete m; }
+    for (auto* m : h->analysed) { registry_remove(m); m->release(); delete m; }
     h->analysed.clear();
 }
 int MgcgAnalysisInfo(MgcgSparse* h, int index, int* distinctOffsets, int* distinctValues, long long* rows, long long* nnz)
@@ -391,13 +433,13 @@ void CopyFromArray_Int(VectorInt* d, int s[], int count, int so, int dofs) { cop
 void Delete_Double(Vector* v)
 {
     if (!v) return;
-    if (v->data) { DeviceState* d = device_state(); if (d) (void)hipStreamSynchronize(d->stream); (void)hipFree(v->data); }
+    if (v->data) { analysis_note_write(v->data, sizeof(double) * (size_t)v->size); DeviceState* d = device_state(); if (d) (void)hipStreamSynchronize(d->stream); (void)hipFree(v->data); }
     delete v;
 }
 void Delete_Int(VectorInt* v)
 {
     if (!v) return;
-    if (v->data) { DeviceState* d = device_state(); if (d) (void)hipStreamSynchronize(d->stream); (void)hipFree(v->data); }
+    if (v->data) { analysis_note_write(v->data, sizeof(int) * (size_t)v->size); DeviceState* d = device_state(); if (d) (void)hipStreamSynchronize(d->stream); (void)hipFree(v->data); }
     delete v;
 }
 double* ToRawPtr_Double(Vector* v) { return v ? v->data : nullptr; }
@@ -410,6 +452,7 @@ void CopyFromDevice_Double(const double* source, double* destination, int count,
     if (!source || !destination || count < 0) { set_error("CopyFromDevice_Double: bad argument"); return; }
     if (count == 0) return;
     // device-to-device, possibly across devices (hipMemcpyDefault resolves the peers); count in ELEMENTS
+    analysis_note_write(destination + destinationOffset, sizeof(double) * (size_t)count);
     if (!MGCG_HIP(hipMemcpyAsync(destination + destinationOffset, source + sourceOffset, sizeof(double) * (size_t)count, hipMemcpyDefault, d->stream))) return;
     (void)MGCG_HIP(hipStreamSynchronize(d->stream));
 }
@@ -418,6 +461,7 @@ void MgcgFill(Vector* v, double value)
 {
     DeviceState* d = device_state();
     if (!d || !v) return;
+    analysis_note_write(v->data, sizeof(double) * (size_t)v->size);
     launch_fill(d->stream, v->data, value, v->size);
 }
 

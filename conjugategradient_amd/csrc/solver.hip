@@ -672,7 +672,11 @@ void MgDestroy(MgcgMg* mg)
     if (!mg) return;
     if (mg->stream) (void)hipStreamSynchronize(mg->stream);
     for (auto& L : mg->lv) {
-        if (L.ownsMatrix) { if (L.elements) (void)hipFree(L.elements); if (L.rowOffsets) (void)hipFree(L.rowOffsets); if (L.columnIndeces) (void)hipFree(L.columnIndeces); }
+        if (L.ownsMatrix) {       // freed addresses may be handed out again: analyses keyed by them are void
+            if (L.elements) { analysis_note_write(L.elements, sizeof(double) * (size_t)(L.nnz > 0 ? L.nnz : 1)); (void)hipFree(L.elements); }
+            if (L.rowOffsets) { analysis_note_write(L.rowOffsets, sizeof(int) * (size_t)(L.n + 1)); (void)hipFree(L.rowOffsets); }
+            if (L.columnIndeces) { analysis_note_write(L.columnIndeces, sizeof(int) * (size_t)(L.nnz > 0 ? L.nnz : 1)); (void)hipFree(L.columnIndeces); }
+        }
         if (L.dinv) (void)hipFree(L.dinv);
         if (L.xa) (void)hipFree(L.xa);
         if (L.xb) (void)hipFree(L.xb);

@@ -404,6 +404,90 @@ __global__ __launch_bounds__(64 * WPB) void v2_rows(Args a, int map, int planeBl
     if (tid == 0) a.partials[blockIdx.x * WPB + wv] = dot;
 }
 
+// ------------------------------------------------------------------ V4: as V2 (RPT 1, KCH 1) with the y stores of B consecutive trips kept in
+// registers and flushed together at trip numbers = 0 mod B -- the same trip numbers in every workgroup, so that (while the workgroups
+// stay roughly in step) the whole chip writes in bursts and reads in between
+template <int WPB, int NG, int B>
+__global__ __launch_bounds__(64 * WPB) void v4_rows(Args a, int map, int planeBlocks)
+{
+    __shared__ double s_pendAll[B * 64 * WPB];
+    __shared__ int s_prowAll[B * WPB];
+    constexpr int CAP = 512;
+    __shared__ __attribute__((aligned(16))) int s_colAll[CAP * WPB];
+    __shared__ __attribute__((aligned(16))) double s_valAll[CAP * WPB];
+    const int tid = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int* s_col = s_colAll + wv * CAP; double* s_val = s_valAll + wv * CAP;
+    double* s_pend = s_pendAll + wv * B * 64; int* s_prow = s_prowAll + wv * B;
+    const int nB = a.nBlocks;
+    const int kMax4 = (a.nnz - 4) & ~3, kMax2 = (a.nnz - 2) & ~1;
+    const int wg = blockIdx.x, WG = gridDim.x;
+    const int nTrips = nB / (WG * WPB);             // lab: exact
+    auto block_of = [&](int t) -> int {
+        t = t < nTrips ? t : nTrips - 1;
+        if (map == 5) {
+            const int T = planeBlocks / WPB, nzp = nB / planeBlocks;
+            const int h = t / nzp, pz = t - h * nzp;
+            return (pz * T + h * WG + (wg & 7) * (WG >> 3) + (wg >> 3)) * WPB + wv;
+        }
+        return (wg + WG * t) * WPB + wv;
+    };
+    int roA_s, roA_e, roB_s, roB_e;
+    i4 c0, c1; d2 v0, v1, v2, v3;
+    auto load_ro = [&](int b, int& rs, int& re) { const int r = b * 64 + tid; rs = a.ro[r]; re = a.ro[r + 1]; };
+    auto raw = [&](int s) {
+        const int tb = s & ~3;
+        int k0 = tb + 4 * tid, k1 = k0 + 256; k0 = k0 < kMax4 ? k0 : kMax4; k1 = k1 < kMax4 ? k1 : kMax4;
+        c0 = *(const i4*)(a.col + k0); c1 = *(const i4*)(a.col + k1);
+        int j0 = tb + 2 * tid, j1 = j0 + 128, j2 = j0 + 256, j3 = j0 + 384;
+        j0 = j0 < kMax2 ? j0 : kMax2; j1 = j1 < kMax2 ? j1 : kMax2; j2 = j2 < kMax2 ? j2 : kMax2; j3 = j3 < kMax2 ? j3 : kMax2;
+        v0 = *(const d2*)(a.val + j0); v1 = *(const d2*)(a.val + j1); v2 = *(const d2*)(a.val + j2); v3 = *(const d2*)(a.val + j3);
+    };
+    int bCur = block_of(0), bNext = block_of(1);
+    load_ro(bCur, roA_s, roA_e);
+    raw(__builtin_amdgcn_readfirstlane(roA_s));
+    load_ro(bNext, roB_s, roB_e);
+    double dot = 0.0;
+    int nPend = 0;
+    for (int t = 0; t < nTrips; ++t) {
+        {
+            const int b = t % B;
+            const int tb = __builtin_amdgcn_readfirstlane(roA_s) & ~3;
+            const int my_s = roA_s, cnt = roA_e - roA_s;
+            *(i4*)(s_col + 4 * tid) = c0; *(i4*)(s_col + 256 + 4 * tid) = c1;
+            *(d2*)(s_val + 2 * tid) = v0; *(d2*)(s_val + 128 + 2 * tid) = v1; *(d2*)(s_val + 256 + 2 * tid) = v2; *(d2*)(s_val + 384 + 2 * tid) = v3;
+            __syncthreads();
+            const int row = bCur * 64 + tid;
+            int cc[NG]; double vv[NG], xg[NG];
+#pragma unroll
+            for (int j = 0; j < NG; ++j) { int idx = my_s - tb + j; idx = j < cnt ? idx : 0; cc[j] = s_col[idx & 511]; vv[j] = s_val[idx & 511]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NG; ++j) xg[j] = a.x[cc[j]];
+            const double w = a.w[row];
+            if (b == 0 && nPend > 0) {               // wavefront-uniform: flush the B results of the previous batch
+                for (int q = 0; q < B; ++q) __builtin_nontemporal_store(s_pend[q * 64 + tid], a.y + s_prow[q] + tid);
+            }
+            raw(__builtin_amdgcn_readfirstlane(roB_s));
+            roA_s = roB_s; roA_e = roB_e;
+            const int bAfter = block_of(t + 2);
+            load_ro(bAfter, roB_s, roB_e);
+            __builtin_amdgcn_sched_barrier(0);
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < NG; ++j) { const double p = vv[j] * xg[j]; acc += (j < cnt) ? p : 0.0; }
+            dot += w * acc;
+            s_pend[b * 64 + tid] = acc; if (tid == 0) s_prow[b] = bCur * 64; nPend = 1;
+            __syncthreads();
+            bCur = bNext; bNext = bAfter;
+        }
+    }
+    __syncthreads();
+    for (int q = 0; q < B; ++q) __builtin_nontemporal_store(s_pend[q * 64 + tid], a.y + s_prow[q] + tid);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dot += __shfl_down(dot, off, 64);
+    if (tid == 0) a.partials[blockIdx.x * WPB + wv] = dot;
+}
+
 template <typename F>
 static double time_ms(F f, int reps)
 {
@@ -562,6 +646,25 @@ int main(int argc, char** argv)
             RUNW(false, 8, 0, "W K8 no store")
             RUNW(false, 8, 7, "W K8 4 x 1 KiB (16 B/lane)")
             RUNW(false, 8, 8, "W K8 4 x 1 KiB nt")
+        }
+        return 0;
+    }
+#define RUNV4(NGv, Bv, mapv, label) \
+    { CK(hipMemset(d_y, 0xff, N * 8)); \
+        double ms = time_ms([&] { hipLaunchKernelGGL((v4_rows<4, NGv, Bv>), dim3(512), dim3(256), 0, 0, a, mapv, n * n / 64); }, reps); \
+        bool ok = check(label); report(label, 8, ms, ok); }
+    if (argc > 3 && !strcmp(argv[3], "batch")) {
+        for (int rep = 0; rep < 2; ++rep) {
+            RUNV4(7, 1, 5, "V4 NG7 B1 sweep")
+            RUNV4(7, 2, 5, "V4 NG7 B2 sweep")
+            RUNV4(7, 4, 5, "V4 NG7 B4 sweep")
+            RUNV4(7, 8, 5, "V4 NG7 B8 sweep")
+            RUNV4(7, 16, 5, "V4 NG7 B16 sweep")
+            RUNV4(7, 32, 5, "V4 NG7 B32 sweep")
+            RUNV4(7, 64, 5, "V4 NG7 B64 sweep")
+            RUNV4(8, 1, 5, "V4 NG8 B1 sweep")
+            RUNV4(7, 1, 0, "V4 NG7 B1 map0")
+            RUNV4(7, 8, 0, "V4 NG7 B8 map0")
         }
         return 0;
     }

@@ -288,3 +288,65 @@ def test_column_tiles_on_row_slices_over_loopback(oracle, monkeypatch):
         x[off: off + cnt] = xs
         assert it == ref["iteration"]
     assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_reinitialize_with_other_values_reanalyses(oracle, mode):
+    """The reference re-uploads A into the SAME device vectors on every Initialize()
+    (Mgcg/cuBlas/Mgcg/ConjugateGradientSingleGpu.cs:134-147); an analysis made from the old values must not survive it."""
+    L = _lib.lib()
+    s1 = problems.poisson(14, 12, 10)
+    cg = ConjugateGradientSingleGpu(s1.Count, 7, 0, 5000, 1e-8).load(s1)
+    L.MgcgSetMatrixCompression(cg.cusparse, mode)
+    cg.Initialize()
+    cg.Solve()
+    cg.Read()
+    ref1 = oracle.cg(s1, rule=oracle.RULE_NATIVE, max_iteration=5000, hard_cap=5000)
+    assert cg.Iteration == ref1["iteration"] and np.abs(cg.x - ref1["x"]).max() <= 1e-10 * np.abs(ref1["x"]).max()
+    assert _info(cg.cusparse)[0] in (1, 2, 3)
+    # same sparsity, same nnz, other values (diagonal 7, off-diagonals -1): same device vectors, same sizes
+    e2 = s1.Elements.copy()
+    e2[e2 > 0] = 7.0
+    s2 = problems.LinearSystem(e2, s1.ColumnIndeces.copy(), s1.RowOffsets.copy(), np.zeros(s1.Count), np.ones(s1.Count), "poisson+I", grid=s1.grid)
+    cg.A.Elements[: s2.nnz] = e2[: s2.nnz]
+    cg.x[:] = 0.0
+    cg.Initialize()
+    cg.Solve()
+    cg.Read()
+    ref2 = oracle.cg(s2, rule=oracle.RULE_NATIVE, max_iteration=5000, hard_cap=5000)
+    assert ref2["iteration"] != ref1["iteration"]
+    assert cg.Iteration == ref2["iteration"], (cg.Iteration, ref2["iteration"], ref1["iteration"])
+    assert np.abs(cg.x - ref2["x"]).max() <= 1e-10 * np.abs(ref2["x"]).max()
+    cg.Dispose()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_raw_pointer_writes_invalidate(oracle, mode):
+    """CopyFromArray / Scal / Copy onto an analysed array, and a freed-and-reallocated array, all void the cached analysis."""
+    L = _lib.lib()
+    s = problems.poisson(16, 9, 7)
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal(s.Count)
+    h = Handles()
+    A = DeviceCsr(s)
+    L.MgcgSetMatrixCompression(h.sparse, mode)
+    ref = oracle.spmv(s.Elements, s.ColumnIndeces, s.RowOffsets, x)
+    assert np.array_equal(A.spmv(h, x), ref)
+    L.Scal(h.blas, A.e.ToRawPtr(), 2.0, s.nnz)                               # every value doubled in place
+    assert np.array_equal(A.spmv(h, x), oracle.spmv(2.0 * s.Elements, s.ColumnIndeces, s.RowOffsets, x))
+    e3 = s.Elements[: s.nnz] * np.linspace(1.0, 2.0, s.nnz)
+    A.e.CopyFrom(e3, s.nnz)                                                  # CopyFromArray_Double
+    assert np.array_equal(A.spmv(h, x), oracle.spmv(e3, s.ColumnIndeces, s.RowOffsets, x))
+    h.close()
+
+
+def test_environment_selects_per_nonzero_codes(monkeypatch):
+    """MGCG_COMPRESSION=2 means mode 2 (per-nonzero codes), as the setter does -- not 'anything non-zero is mode 1'."""
+    L = _lib.lib()
+    monkeypatch.setenv("MGCG_COMPRESSION", "2")
+    s = problems.poisson(12, 10, 8)
+    h = Handles()
+    A = DeviceCsr(s)
+    A.spmv(h, np.ones(s.Count))
+    assert _info(h.sparse)[0] in (1, 2)
+    h.close()

@@ -40,6 +40,8 @@ def test_csrmv_stream_kernel_is_bit_exact(h, oracle, system):
         assert np.array_equal(y, ref), f"tuning {tuning}"
     for grid in (0, 7, 4096):                          # "stage raw, multiply by row" form of the row-block kernel
         assert np.array_equal(A.spmv(h, x, kernel=9, tuning=(64, 0, grid)), ref), f"rows kernel grid {grid}"
+    for grid in (0, 4, 40, 4096):                      # row-tile kernel (the default for short rows); long rows take its slow path
+        assert np.array_equal(A.spmv(h, x, kernel=10, tuning=(64, 0, grid)), ref), f"row-tile kernel grid {grid}"
     y = A.spmv(h, x)                                   # auto selection
     np.testing.assert_allclose(y, ref, rtol=1e-13, atol=1e-13 * np.abs(ref).max())
 
@@ -75,6 +77,51 @@ def test_csrmv_banded_schedule_is_bit_exact(h, oracle, dims, rows, grid, period,
     assert np.array_equal(y, ref)
     y = DeviceCsr(s).spmv(h, x, kernel=1, tuning=(rows, 1, grid), period=period, tile=tile)      # + non-temporal loads
     assert np.array_equal(y, ref)
+
+
+@pytest.mark.parametrize("dims,grid,period", [
+    ((64, 32, 5), 0, 2048),          # one tile per XCD per plane, z sweep over 5 planes
+    ((64, 64, 7), 64, 4096),         # 2 tiles per XCD per plane, 8 workgroups per XCD: every plane in one trip
+    ((128, 64, 6), 32, 8192),        # 4 tiles per XCD per plane, 1 workgroup slot per XCD: 4 slices
+    ((64, 96, 4), 64, 6144),         # 3 tiles per XCD per plane
+    ((64, 32, 5), 0, 0),             # no hint: the far band is read off the matrix (2048)
+    ((64, 32, 5), 0, 4096),          # a wrong hint that still tiles: another order, same bits
+    ((64, 32, 5), 0, 640),           # a hint the kernel cannot use: plain order
+    ((20, 17, 13), 0, 340),          # rows not a multiple of the tile: tail rows by workgroup 0
+    ((64, 32, 2), 0, 2048),          # fewer than 3 planes: plain order
+])
+def test_csrmv_rowtile_orders_are_bit_exact(h, oracle, dims, grid, period):
+    """Row-tile kernel: grid-stride order or the z sweep (XCD-contiguous plane slices); every epilogue variant of CsrMV."""
+    s = problems.poisson(*dims)
+    rng = np.random.default_rng(23)
+    x, y0 = rng.standard_normal(s.Count), rng.standard_normal(s.Count)
+    ref = oracle.spmv(s.Elements, s.ColumnIndeces, s.RowOffsets, x)
+    A = DeviceCsr(s)
+    assert np.array_equal(A.spmv(h, x, kernel=10, tuning=(64, 0, grid), period=period), ref)
+    assert np.array_equal(A.spmv(h, x, alpha=-0.5, beta=1.75, y0=y0, kernel=10, tuning=(64, 0, grid), period=period), -0.5 * ref + 1.75 * y0)
+    assert np.array_equal(A.spmv(h, x, alpha=1.0, beta=0.0, y0=np.full(s.Count, np.nan), kernel=10, tuning=(64, 0, grid), period=period), ref)
+
+
+def test_csrmv_rowtile_slow_blocks_and_ragged_ends(h, oracle):
+    """Blocks the fast path must decline: a row of more than 8 nonzeros, a 64-row span of more than 512 nonzeros, the last
+    nonzeros of arrays whose length is not a multiple of four, matrices smaller than a tile, empty rows."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(29)
+    cases = []
+    base = problems.poisson(24, 20, 9).to_scipy().tolil()
+    base[1000, 5:40] = 0.25                                   # one long row inside a short-row matrix
+    base[3000:3064, 100:110] = -0.5                           # 64 consecutive rows of 15+: span > 512
+    cases.append(base.tocsr())
+    for n in (1, 7, 63, 64, 255, 256, 257, 511, 777):         # below / at / above one tile, nnz of any residue mod 4
+        cases.append(sp.random(n, n, density=min(1.0, 5.0 / n), random_state=n, format="csr") + sp.eye(n, format="csr") * (n % 3 == 0))
+    for M in cases:
+        M = M.tocsr()
+        M.sort_indices()
+        sysm = problems.LinearSystem(M.data.astype(np.float64), M.indices.astype(np.int32), M.indptr.astype(np.int32), np.zeros(M.shape[0]), np.zeros(M.shape[0]), "case")
+        xv = rng.standard_normal(M.shape[0])
+        ref = oracle.spmv(sysm.Elements, sysm.ColumnIndeces, sysm.RowOffsets, xv)
+        got = DeviceCsr(sysm).spmv(h, xv, kernel=10)
+        assert np.array_equal(got, ref), (M.shape, M.nnz)
 
 
 def test_csrmv_alpha_beta_and_edges(h, oracle):
