@@ -244,20 +244,11 @@ def main():
     if world > 1 and n % world:
         raise SystemExit("grid extent must be divisible by the number of GPUs (z-slab partition)")
 
-    if a.solver == "mgcg":
-        from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu
-
-        # fixed-length runs: rule NATIVE with an infinite tolerance stops exactly at index minIteration
-        cg = ConjugateGradientMgRankGpu(N, 7, 0, 10**9, 1e300, (n, n, n), rank=rank, world=world, device=local_rank,
-                                        rule=_lib.RULE_NATIVE, levels=3, nu=1, nuCoarse=4)
-    else:
-        cg = ConjugateGradientRankGpu(N, 7, 0, 10**9, 1e-8, rank=rank, world=world, device=local_rank)
-    if a.compression is None:
-        a.compression = 0
-    a.no_compression = a.compression == 0
-    L.MgcgSetMatrixCompression(cg.cusparse, a.compression)
+    # The RCCL communicator is formed BEFORE any other GPU work of this rank (handles, vectors, the matrix).
     transport = "single rank"
+    comm = None
     if world > 1:
+        L.SetDevice(local_rank)
         # RCCL communicator (the unique id travels over gloo).  Should it fail to form on this host, every rank falls back
         # to the library's host-staged callback transport over the same gloo group: slow, but the scaling line stays valid.
         import torch
@@ -283,9 +274,8 @@ def main():
                 ok, why = 0, pre_why or "another rank failed the RCCL precondition"
             else:
                 try:
-                    cg.comm = create_comm(rank, world)
-                    cg._own_comm = True
-                    probe = L.MgcgCommAllReduceSum(cg.comm, 1.0)
+                    comm = create_comm(rank, world)
+                    probe = L.MgcgCommAllReduceSum(comm, 1.0)
                     if probe != float(world):
                         ok, why = 0, f"RCCL all-reduce probe returned {probe}"
                 except Exception as ex:     # noqa: BLE001 -- any failure of the RCCL bootstrap
@@ -296,23 +286,36 @@ def main():
         if int(flag[0]) == 1:
             transport = "rccl"
         else:
-            if not a.allow_fallback:
+            if not a.allow_fallback and os.environ.get("MGCG_BENCH_TRANSPORT", "rccl") == "rccl":
                 if rank == 0:
                     print(f"bench.py: RCCL transport unavailable ({why or 'another rank failed'}); refusing to report a scaling line over a fallback "
                           "(pass --allow-fallback to run over host-staged gloo)", file=sys.stderr, flush=True)
-                if cg.comm:
-                    L.MgcgCommDestroy(cg.comm)
-                    cg.comm = None
+                if comm:
+                    L.MgcgCommDestroy(comm)
                 dist.barrier()
                 dist.destroy_process_group()
                 raise SystemExit(3)
             if rank == 0:
                 print(f"bench.py: RCCL transport unavailable ({why or 'another rank failed'}); using the host-staged gloo transport (--allow-fallback)", file=sys.stderr, flush=True)
-            if cg.comm:
-                L.MgcgCommDestroy(cg.comm)
-            cg.comm = create_callback_comm(rank, world)
-            cg._own_comm = True
+            if comm:
+                L.MgcgCommDestroy(comm)
+            comm = create_callback_comm(rank, world)
             transport = "host-staged callbacks over torch.distributed gloo (RCCL FALLBACK: not a scaling result)"
+    if a.solver == "mgcg":
+        from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu
+
+        # fixed-length runs: rule NATIVE with an infinite tolerance stops exactly at index minIteration
+        cg = ConjugateGradientMgRankGpu(N, 7, 0, 10**9, 1e300, (n, n, n), rank=rank, world=world, device=local_rank,
+                                        rule=_lib.RULE_NATIVE, levels=3, nu=1, nuCoarse=4)
+    else:
+        cg = ConjugateGradientRankGpu(N, 7, 0, 10**9, 1e-8, rank=rank, world=world, device=local_rank)
+    if a.compression is None:
+        a.compression = 0
+    a.no_compression = a.compression == 0
+    L.MgcgSetMatrixCompression(cg.cusparse, a.compression)
+    if comm is not None:
+        cg.comm = comm
+        cg._own_comm = True
     if a.spmv_kernel is not None:
         L.MgcgSetSpmvKernel(cg.cusparse, a.spmv_kernel)
     if a.spmv_rows is not None or a.spmv_flags is not None or a.spmv_grid is not None:

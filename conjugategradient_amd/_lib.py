@@ -114,6 +114,7 @@ SIGNATURES = {
     "SolveParallel": (_i, [_vp] * 12 + [_i, _i, _i, _i, _i, _i, _d, _i, _i, _i, _pi, _pd, _vp, _i]),
     "CgSteps": (_d, [_vp] * 11 + [_i, _i, _i, _i, _i, _i, _i, _i]),
     "MgcgLastOverlap": (_i, [_vp]),
+    "MgcgLastHalo": (_i, [_vp]),
     "MgcgCommInitCallbacks": (_vp, [_i, _i, _vp, _vp, _vp, _vp]),
     "MgcgEstimateSpectrum": (_i, [_vp] * 5 + [_i, _i, _i, _i, C.c_uint, _vp, _vp, _vp, _vp]),
 }

@@ -137,11 +137,92 @@ bool comm_allreduce_sum(MgcgComm* c, double* devPtr, int count, hipStream_t s)
 struct HaloPlan {
     int nranks = 1;
     std::vector<long long> sendBegin, sendCount, recvBegin, recvCount;
+    // Index-list form (unstructured slices): per peer, the entries of p this rank sends / receives are lists of global ids
+    // instead of one contiguous range.  The lists of all peers are concatenated (peer q's part starts at sendAt[q] / recvAt[q]);
+    // pack gathers p[sendIdx] into sendBuf, unpack scatters recvBuf into p[recvIdx].
+    bool indexed = false;
+    std::vector<long long> sendAt, recvAt;
+    int* sendIdx = nullptr; int* recvIdx = nullptr;
+    double* sendBuf = nullptr; double* recvBuf = nullptr;
+    long long sendTotal = 0, recvTotal = 0, contiguousRecv = 0;
 };
 
-HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long long countLocal, int minJ, int maxJ)
+__global__ __launch_bounds__(kBlock) void halo_mark_kernel(const int* __restrict__ columnIndeces, long long nnz, long long ownBegin, long long ownEnd, unsigned char* __restrict__ flags)
 {
-    (void)count;
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long k = (long long)blockIdx.x * kBlock + threadIdx.x; k < nnz; k += stride) {
+        const int col = columnIndeces[k];
+        if (col < ownBegin || col >= ownEnd) flags[col] = 1;       // (benign race: every writer stores the same byte)
+    }
+}
+__global__ __launch_bounds__(kBlock) void halo_pack_kernel(const double* __restrict__ p, const int* __restrict__ idx, long long n, double* __restrict__ buf)
+{
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) buf[i] = p[idx[i]];
+}
+__global__ __launch_bounds__(kBlock) void halo_unpack_kernel(double* __restrict__ p, const int* __restrict__ idx, long long n, const double* __restrict__ buf)
+{
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) p[idx[i]] = buf[i];
+}
+static int halo_grid(long long n) { const long long b = (n + kBlock - 1) / kBlock; return (int)(b < 1 ? 1 : (b > kMaxGrid ? kMaxGrid : b)); }
+
+static thread_local long long t_lastHalo[3] = { 0, 0, 0 };       // indexed?, entries received per exchange, entries of the contiguous plan
+
+// One exchange of host vectors of doubles between all ranks (plan set-up only): recv[q] must be sized to what q sends.
+static bool exchange_host(MgcgComm* c, const std::vector<std::vector<double>>& send, std::vector<std::vector<double>>& recv)
+{
+    const int n = c->nranks;
+    if (c->loop) {
+        MgcgLoopback* g = c->loop;
+        for (int q = 0; q < n; ++q) g->mailbox[(size_t)c->rank * n + q] = send[(size_t)q];
+        g->barrier();
+        bool ok = true;
+        for (int q = 0; q < n; ++q) {
+            const std::vector<double>& box = g->mailbox[(size_t)q * n + c->rank];
+            if (box.size() != recv[(size_t)q].size()) { set_error("loopback exchange: size mismatch with rank %d", q); ok = false; continue; }
+            recv[(size_t)q] = box;
+        }
+        g->barrier();
+        return ok;
+    }
+    if (c->cbExchange) {
+        std::vector<const double*> sp((size_t)n, nullptr); std::vector<double*> rp((size_t)n, nullptr);
+        std::vector<long long> sc((size_t)n, 0), rc((size_t)n, 0);
+        for (int q = 0; q < n; ++q) { sp[(size_t)q] = send[(size_t)q].data(); rp[(size_t)q] = recv[(size_t)q].data(); sc[(size_t)q] = (long long)send[(size_t)q].size(); rc[(size_t)q] = (long long)recv[(size_t)q].size(); }
+        c->cbExchange(n, sp.data(), sc.data(), rp.data(), rc.data(), c->cbUser);
+        return true;
+    }
+    Rccl* r = rccl();
+    if (!r) return false;
+    size_t sTot = 0, rTot = 0;
+    for (int q = 0; q < n; ++q) { sTot += send[(size_t)q].size(); rTot += recv[(size_t)q].size(); }
+    double *dS = nullptr, *dR = nullptr;
+    bool ok = MGCG_HIP(hipMalloc((void**)&dS, sizeof(double) * (sTot + 1))) && MGCG_HIP(hipMalloc((void**)&dR, sizeof(double) * (rTot + 1)));
+    size_t at = 0;
+    for (int q = 0; ok && q < n; ++q) { if (!send[(size_t)q].empty()) ok = MGCG_HIP(hipMemcpyAsync(dS + at, send[(size_t)q].data(), sizeof(double) * send[(size_t)q].size(), hipMemcpyHostToDevice, c->stream)); at += send[(size_t)q].size(); }
+    ok = ok && nccl_ok(r->GroupStart(), "ncclGroupStart");
+    size_t sa = 0, ra = 0;
+    for (int q = 0; ok && q < n; ++q) {
+        if (!send[(size_t)q].empty()) ok = ok && nccl_ok(r->Send(dS + sa, send[(size_t)q].size(), NCCL_DOUBLE, q, c->comm, c->stream), "ncclSend");
+        if (!recv[(size_t)q].empty()) ok = ok && nccl_ok(r->Recv(dR + ra, recv[(size_t)q].size(), NCCL_DOUBLE, q, c->comm, c->stream), "ncclRecv");
+        sa += send[(size_t)q].size(); ra += recv[(size_t)q].size();
+    }
+    ok = nccl_ok(r->GroupEnd(), "ncclGroupEnd") && ok;
+    ra = 0;
+    for (int q = 0; ok && q < n; ++q) { if (!recv[(size_t)q].empty()) ok = MGCG_HIP(hipMemcpyAsync(recv[(size_t)q].data(), dR + ra, sizeof(double) * recv[(size_t)q].size(), hipMemcpyDeviceToHost, c->stream)); ra += recv[(size_t)q].size(); }
+    ok = MGCG_HIP(hipStreamSynchronize(c->stream)) && ok;
+    if (dS) (void)hipFree(dS);
+    if (dR) (void)hipFree(dR);
+    return ok;
+}
+
+static bool halo_plan_index(MgcgComm* c, HaloPlan* h, const std::vector<long long>& all, long long count, long long offset, long long countLocal,
+                            const int* columnIndeces, long long nnz);
+
+HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long long countLocal, int minJ, int maxJ,
+                           const int* columnIndeces, long long nnz)
+{
     HaloPlan* h = new HaloPlan();
     if (!c || c->nranks == 1) return h;
     const int n = c->nranks;
@@ -186,14 +267,110 @@ HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long 
         // what q needs from me: my rows inside [qMin, qMax]
         if (qCnt > 0 && qMax >= qMin) clip(qMin, qMax + 1, offset, offset + countLocal, h->sendBegin[q], h->sendCount[q]);
     }
+    for (int q = 0; q < n; ++q) h->contiguousRecv += h->recvCount[q];
+    // Unstructured slices: the contiguous ranges degenerate to (nearly) the whole vector.  Whether index lists pay is a
+    // collective decision (every rank must take the same path): all ranks look at the same table.
+    static const bool noIndex = getenv("MGCG_NO_INDEXED_HALO") != nullptr;
+    bool wide = false;
+    for (int q = 0; q < n; ++q) {
+        const long long qCnt = all[4 * q + 1], qMin = all[4 * q + 2], qMax = all[4 * q + 3];
+        if (qCnt > 0 && qMax >= qMin && (qMax - qMin + 1 - qCnt) * 4 >= count) wide = true;     // some rank asks for >= a quarter of the vector from others
+    }
+    if (wide && !noIndex && columnIndeces != nullptr && count < 0x7fffffffLL) {
+        if (!halo_plan_index(c, h, all, count, offset, countLocal, columnIndeces, nnz)) { halo_plan_destroy(h); return nullptr; }
+    }
     return h;
 }
 
-void halo_plan_destroy(HaloPlan* h) { delete h; }
+// Replace the contiguous ranges by index lists if (collectively) that at least halves the entries moved.
+static bool halo_plan_index(MgcgComm* c, HaloPlan* h, const std::vector<long long>& all, long long count, long long offset, long long countLocal,
+                            const int* columnIndeces, long long nnz)
+{
+    const int n = c->nranks;
+    // 1. which columns outside my rows does my slice reference?
+    std::vector<unsigned char> flags((size_t)count, 0);
+    unsigned char* dFlags = nullptr;
+    bool ok = MGCG_HIP(hipMalloc((void**)&dFlags, (size_t)count)) && MGCG_HIP(hipMemsetAsync(dFlags, 0, (size_t)count, c->stream));
+    if (ok && nnz > 0) hipLaunchKernelGGL(halo_mark_kernel, dim3(halo_grid(nnz)), dim3(kBlock), 0, c->stream, columnIndeces, nnz, offset, offset + countLocal, dFlags);
+    ok = ok && MGCG_HIP(hipMemcpyAsync(flags.data(), dFlags, (size_t)count, hipMemcpyDeviceToHost, c->stream)) && MGCG_HIP(hipStreamSynchronize(c->stream));
+    if (dFlags) (void)hipFree(dFlags);
+    if (!ok) return false;
+    // 2. per owner, the sorted list of what I need
+    std::vector<std::vector<double>> need((size_t)n), give((size_t)n), cnt((size_t)n, std::vector<double>(1, 0.0)), cntIn((size_t)n, std::vector<double>(1, 0.0));
+    for (int q = 0; q < n; ++q) {
+        if (q == c->rank) continue;
+        const long long qOff = all[4 * q], qCnt = all[4 * q + 1];
+        for (long long j = qOff; j < qOff + qCnt; ++j) if (flags[(size_t)j]) need[(size_t)q].push_back((double)j);
+        cnt[(size_t)q][0] = (double)need[(size_t)q].size();
+    }
+    cnt[(size_t)c->rank].clear(); cntIn[(size_t)c->rank].clear();
+    // 3. tell every owner how many and which (two rounds over the transport)
+    if (!exchange_host(c, cnt, cntIn)) return false;
+    for (int q = 0; q < n; ++q) if (q != c->rank) give[(size_t)q].resize((size_t)cntIn[(size_t)q][0]);
+    if (!exchange_host(c, need, give)) return false;
+    // 4. collective decision: total entries moved with lists vs with ranges
+    double mine[2] = { 0.0, (double)h->contiguousRecv };
+    for (int q = 0; q < n; ++q) mine[0] += (double)need[(size_t)q].size();
+    double* dTot = nullptr;
+    ok = MGCG_HIP(hipMalloc((void**)&dTot, 2 * sizeof(double))) && MGCG_HIP(hipMemcpyAsync(dTot, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
+    ok = ok && comm_allreduce_sum(c, dTot, 2, c->stream);
+    ok = ok && MGCG_HIP(hipMemcpyAsync(mine, dTot, sizeof(mine), hipMemcpyDeviceToHost, c->stream)) && MGCG_HIP(hipStreamSynchronize(c->stream));
+    if (dTot) (void)hipFree(dTot);
+    if (!ok) return false;
+    if (!(mine[0] * 2.0 <= mine[1])) return true;                 // lists do not halve the volume: keep the ranges
+    // 5. device lists and staging buffers
+    h->sendAt.assign((size_t)n + 1, 0); h->recvAt.assign((size_t)n + 1, 0);
+    std::vector<int> sIdx, rIdx;
+    for (int q = 0; q < n; ++q) {
+        h->sendAt[(size_t)q] = (long long)sIdx.size(); h->recvAt[(size_t)q] = (long long)rIdx.size();
+        for (double v : give[(size_t)q]) {
+            const long long j = (long long)v;
+            if (j < offset || j >= offset + countLocal) { set_error("indexed halo: rank %d asked rank %d for entry %lld it does not own", q, c->rank, j); return false; }
+            sIdx.push_back((int)j);
+        }
+        for (double v : need[(size_t)q]) rIdx.push_back((int)(long long)v);
+    }
+    h->sendAt[(size_t)n] = (long long)sIdx.size(); h->recvAt[(size_t)n] = (long long)rIdx.size();
+    h->sendTotal = (long long)sIdx.size(); h->recvTotal = (long long)rIdx.size();
+    ok = MGCG_HIP(hipMalloc((void**)&h->sendIdx, sizeof(int) * (sIdx.size() + 1))) && MGCG_HIP(hipMalloc((void**)&h->recvIdx, sizeof(int) * (rIdx.size() + 1))) &&
+         MGCG_HIP(hipMalloc((void**)&h->sendBuf, sizeof(double) * (sIdx.size() + 1))) && MGCG_HIP(hipMalloc((void**)&h->recvBuf, sizeof(double) * (rIdx.size() + 1)));
+    if (ok && !sIdx.empty()) ok = MGCG_HIP(hipMemcpyAsync(h->sendIdx, sIdx.data(), sizeof(int) * sIdx.size(), hipMemcpyHostToDevice, c->stream));
+    if (ok && !rIdx.empty()) ok = MGCG_HIP(hipMemcpyAsync(h->recvIdx, rIdx.data(), sizeof(int) * rIdx.size(), hipMemcpyHostToDevice, c->stream));
+    ok = ok && MGCG_HIP(hipStreamSynchronize(c->stream));
+    if (!ok) return false;
+    for (int q = 0; q < n; ++q) { h->sendBegin[q] = h->sendAt[(size_t)q]; h->sendCount[q] = h->sendAt[(size_t)q + 1] - h->sendAt[(size_t)q]; h->recvBegin[q] = h->recvAt[(size_t)q]; h->recvCount[q] = h->recvAt[(size_t)q + 1] - h->recvAt[(size_t)q]; }
+    h->indexed = true;                                            // from here on send/recv Begin/Count address sendBuf / recvBuf
+    return true;
+}
+
+void halo_plan_destroy(HaloPlan* h)
+{
+    if (!h) return;
+    if (h->sendIdx) (void)hipFree(h->sendIdx);
+    if (h->recvIdx) (void)hipFree(h->recvIdx);
+    if (h->sendBuf) (void)hipFree(h->sendBuf);
+    if (h->recvBuf) (void)hipFree(h->recvBuf);
+    delete h;
+}
+void halo_last(long long out[3]) { out[0] = t_lastHalo[0]; out[1] = t_lastHalo[1]; out[2] = t_lastHalo[2]; }
+
+static bool halo_exchange_ranges(MgcgComm* c, HaloPlan* h, const double* src, double* dst, hipStream_t s);
 
 bool halo_exchange(MgcgComm* c, HaloPlan* h, double* p, hipStream_t s)
 {
     if (!c || c->nranks == 1 || !h) return true;
+    t_lastHalo[0] = h->indexed ? 1 : 0; t_lastHalo[1] = h->indexed ? h->recvTotal : h->contiguousRecv; t_lastHalo[2] = h->contiguousRecv;
+    if (!h->indexed) return halo_exchange_ranges(c, h, p, p, s);
+    if (h->sendTotal > 0) hipLaunchKernelGGL(halo_pack_kernel, dim3(halo_grid(h->sendTotal)), dim3(kBlock), 0, s, (const double*)p, (const int*)h->sendIdx, h->sendTotal, h->sendBuf);
+    if (!halo_exchange_ranges(c, h, h->sendBuf, h->recvBuf, s)) return false;
+    if (h->recvTotal > 0) hipLaunchKernelGGL(halo_unpack_kernel, dim3(halo_grid(h->recvTotal)), dim3(kBlock), 0, s, p, (const int*)h->recvIdx, h->recvTotal, (const double*)h->recvBuf);
+    return MGCG_HIP(hipGetLastError());
+}
+
+// per peer: src[sendBegin, +sendCount) goes out, dst[recvBegin, +recvCount) comes in
+static bool halo_exchange_ranges(MgcgComm* c, HaloPlan* h, const double* src, double* dst, hipStream_t s)
+{
+    const double* p = src;
     if (c->loop) {
         MgcgLoopback* g = c->loop;
         bool ok = true;
@@ -208,7 +385,7 @@ bool halo_exchange(MgcgComm* c, HaloPlan* h, double* p, hipStream_t s)
             const std::vector<double>& box = g->mailbox[(size_t)q * g->nranks + c->rank];
             if (h->recvCount[q] > 0) {
                 if ((long long)box.size() != h->recvCount[q]) { set_error("loopback halo: rank %d sent %zu values, rank %d expected %lld", q, box.size(), c->rank, h->recvCount[q]); ok = false; continue; }
-                ok = ok && MGCG_HIP(hipMemcpyAsync(p + h->recvBegin[q], box.data(), sizeof(double) * box.size(), hipMemcpyHostToDevice, s));
+                ok = ok && MGCG_HIP(hipMemcpyAsync(dst + h->recvBegin[q], box.data(), sizeof(double) * box.size(), hipMemcpyHostToDevice, s));
             }
         }
         ok = MGCG_HIP(hipStreamSynchronize(s)) && ok;
@@ -229,7 +406,7 @@ bool halo_exchange(MgcgComm* c, HaloPlan* h, double* p, hipStream_t s)
         if (!ok) return false;
         c->cbExchange(n, sp.data(), h->sendCount.data(), rp.data(), h->recvCount.data(), c->cbUser);
         for (int q = 0; q < n; ++q)
-            if (h->recvCount[q] > 0) ok = ok && MGCG_HIP(hipMemcpyAsync(p + h->recvBegin[q], c->cbRecv[(size_t)q].data(), sizeof(double) * (size_t)h->recvCount[q], hipMemcpyHostToDevice, s));
+            if (h->recvCount[q] > 0) ok = ok && MGCG_HIP(hipMemcpyAsync(dst + h->recvBegin[q], c->cbRecv[(size_t)q].data(), sizeof(double) * (size_t)h->recvCount[q], hipMemcpyHostToDevice, s));
         return MGCG_HIP(hipStreamSynchronize(s)) && ok;
     }
     Rccl* r = rccl();
@@ -237,7 +414,7 @@ bool halo_exchange(MgcgComm* c, HaloPlan* h, double* p, hipStream_t s)
     bool ok = nccl_ok(r->GroupStart(), "ncclGroupStart");
     for (int q = 0; ok && q < h->nranks; ++q) {
         if (h->sendCount[q] > 0) ok = ok && nccl_ok(r->Send(p + h->sendBegin[q], (size_t)h->sendCount[q], NCCL_DOUBLE, q, c->comm, s), "ncclSend");
-        if (h->recvCount[q] > 0) ok = ok && nccl_ok(r->Recv(p + h->recvBegin[q], (size_t)h->recvCount[q], NCCL_DOUBLE, q, c->comm, s), "ncclRecv");
+        if (h->recvCount[q] > 0) ok = ok && nccl_ok(r->Recv(dst + h->recvBegin[q], (size_t)h->recvCount[q], NCCL_DOUBLE, q, c->comm, s), "ncclRecv");
     }
     ok = nccl_ok(r->GroupEnd(), "ncclGroupEnd") && ok;
     return ok;

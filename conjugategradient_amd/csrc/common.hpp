@@ -2,6 +2,7 @@
 // gfx950 (MI355X, CDNA4) only: 64-wide wavefronts, 256 CUs in 8 XCDs.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdarg>
@@ -61,6 +62,8 @@ struct CgScalars {
     int status;
     int pad;          // "x pending": set by the finalisation kernel for update_xp, cleared when no iteration ran
 };
+
+static_assert(offsetof(CgScalars, rzNew) == offsetof(CgScalars, rrNew) + sizeof(double), "{rrNew, rzNew} are all-reduced as one pair");
 
 // What the host polls (pinned, device-written).
 struct HostMirror {
@@ -279,7 +282,7 @@ struct FinalizeArgs {
     HostMirror* mirror;
     double* trace; int traceCap;
     double tol; int minIt; int maxIt; int rule;
-    int preconditioned;     // beta = rzNew/rr(rz) computed by finalize_precond instead
+    int preconditioned;     // 1: beta = rzNew/rr(rz) computed by finalize_precond instead; 2: by this kernel from the all-reduced sc->rzNew
 };
 // Single-workgroup kernels that turn partial sums into the loop's scalars.
 void launch_reduce_to(hipStream_t s, const double* partials, int n, double* dst, const int* done);          // dst = sum
@@ -311,7 +314,11 @@ void launch_halo_rows(hipStream_t s, const int* rowOffsets, const int* columnInd
 struct CommImpl;
 bool comm_allreduce_sum(MgcgComm* c, double* devPtr, int count, hipStream_t s);
 struct HaloPlan;  // per-peer contiguous send/recv ranges of p
-HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long long countLocal, int minJ, int maxJ);
+// columnIndeces / nnz (device; may be null): when the slice is unstructured (the contiguous ranges come to a quarter of the vector or
+// more) the plan is rebuilt from the column ids actually referenced -- per-peer index lists, packed and unpacked around the exchange.
+HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long long countLocal, int minJ, int maxJ,
+                           const int* columnIndeces = nullptr, long long nnz = 0);
+void halo_last(long long out[3]);   // calling thread's last exchange: {index lists used, entries received, entries the contiguous plan receives}
 void halo_plan_destroy(HaloPlan* h);
 bool halo_exchange(MgcgComm* c, HaloPlan* h, double* p, hipStream_t s);
 // interior rows on a side stream while the halo travels on the main stream (all RCCL calls stay on the main stream)

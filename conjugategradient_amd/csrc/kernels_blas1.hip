@@ -466,6 +466,7 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const double* __restri
         f.mirror->done = 1;
     } else {
         if (!f.preconditioned) { sc->beta = rrNew / sc->rr; sc->rr = rrNew; }
+        else if (f.preconditioned == 2) { const double rz = sc->rzNew; sc->beta = rz / sc->rr; sc->rr = rz; }   // (all-reduced r.z already in place)
         sc->iteration = it + 1;
         f.mirror->residual = res; f.mirror->iteration = it + 1;
     }

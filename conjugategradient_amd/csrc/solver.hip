@@ -322,6 +322,21 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
     f.sc = sc; f.mirror = R.ws->mirror; f.trace = R.ws->trace; f.traceCap = R.ws->traceCap;
     f.tol = R.tol; f.minIt = R.minIt; f.maxIt = R.maxIt; f.rule = R.rule; f.preconditioned = R.mg ? 1 : 0;
     if (!withStopTest) { f.tol = -1.0; f.minIt = 0; f.maxIt = 0x7fffffff; f.rule = MGCG_RULE_NATIVE; }   // never converges
+    if (R.nranks > 1 && R.mg) {
+        // Preconditioned, several ranks: r.r (stop test) and r.z (beta) travel in ONE all-reduce of two doubles behind the
+        // V-cycle ("[r.z, r.r] batched"); the stop decision of an iteration is taken one V-cycle later,
+        // which costs one wasted V-cycle at the very end and saves a collective per iteration.
+        launch_reduce_to(s, rrPartials, n, &sc->rrNew, done);                        // local r.r (before the V-cycle reuses the partial sums)
+        int nz = 0;
+        if (!mg_apply(R.mg, R.r, R.z, done, nullptr, &nz)) return false;             // z = M^-1 r
+        n = nz > 0 ? nz : launch_dot_partials(s, R.r, R.z, R.nLocal, R.ws->partials);
+        launch_reduce_to(s, R.ws->partials, n, &sc->rzNew, done);                    // local r.z
+        if (!comm_allreduce_sum(R.comm, &sc->rrNew, 2, s)) return false;             // {rrNew, rzNew} are adjacent in CgScalars  (:525 and the PCG's r.z)
+        f.preconditioned = 2;                                                        // finalize also does beta = rzNew / rz, rz = rzNew
+        launch_finalize(s, rrPartials, pInf, n, false, f);
+        launch_update_xp(s, sc, R.x, pLoc, R.z, R.nLocal);                           // x += a p (:246) ; p = z + beta p
+        return MGCG_HIP(hipGetLastError());
+    }
     if (R.nranks > 1) {
         launch_reduce_to(s, rrPartials, n, &sc->rrNew, done);
         if (!comm_allreduce_sum(R.comm, &sc->rrNew, 1, s)) return false;             // (:525)
@@ -478,7 +493,7 @@ int SolveParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMa
     R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice;
     R.tol = allowableResidual; R.minIt = minIteration; R.maxIt = maxIteration; R.rule = rule;
     if (R.nranks > 1) {
-        R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ);
+        R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, R.columnIndeces, R.elementsCount);
         if (!R.halo) return MGCG_ERROR;
         if (!cg_plan_overlap(R)) { halo_plan_destroy(R.halo); return MGCG_ERROR; }
     }
@@ -505,7 +520,7 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     double* savedTrace = R.ws->trace; const int savedCap = R.ws->traceCap;
     R.ws->trace = nullptr; R.ws->traceCap = 0;
     bool ok = true;
-    if (R.nranks > 1) { R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ); ok = R.halo != nullptr && cg_plan_overlap(R); }
+    if (R.nranks > 1) { R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, R.columnIndeces, R.elementsCount); ok = R.halo != nullptr && cg_plan_overlap(R); }
     R.dcsr = dcsr_lookup(cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset, R.count);
     if (R.cfg.periodRows == 0 && R.elementsCount >= 8) R.cfg.periodRows = spmv_period(cusparse, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset);
     if (ok && restart) ok = cg_enqueue_init(R);
@@ -516,6 +531,13 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     if (R.halo) halo_plan_destroy(R.halo);
     R.ws->trace = savedTrace; R.ws->traceCap = savedCap;
     return ok ? (double)R.ws->mirror->residual : NAN;
+}
+
+int MgcgLastHalo(long long volume[2])
+{
+    long long v[3]; halo_last(v);
+    if (volume) { volume[0] = v[1]; volume[1] = v[2]; }
+    return (int)v[0];
 }
 
 int MgcgLastOverlap(long long interior[2])
@@ -739,7 +761,7 @@ int SolveMgParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, Mgcg
     R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice;
     R.tol = allowableResidual; R.minIt = minIteration; R.maxIt = maxIteration; R.rule = rule;
     if (R.nranks > 1) {
-        R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ);
+        R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, R.columnIndeces, R.elementsCount);
         if (!R.halo) return MGCG_ERROR;
         if (!cg_plan_overlap(R)) { halo_plan_destroy(R.halo); return MGCG_ERROR; }
     }

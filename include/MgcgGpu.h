@@ -375,6 +375,11 @@ int MgcgEstimateSpectrum(MgcgBlas* cublas, MgcgSparse* cusparse,
  * (rows outside it wait for the halo), or 0 when the exchange ran in line (single rank, MGCG_OVERLAP=0, or the
  * slice has too few rows that reference local columns only).  interior may be NULL. */
 int MgcgLastOverlap(long long interior[2]);
+/* The calling thread's last halo exchange: returns 1 if it moved per-peer index lists (unstructured slices: only the entries
+ * of p the slice's column ids reference -- plan built once from them), 0 if contiguous ranges (banded / stencil slices,
+ * the reference's [minJ, offset) and [offset + count, maxJ]: Mgcg.cu:83-84, ConjugateGradientParallelGpu.cs:397-398);
+ * volume[0] = entries this rank received per exchange, volume[1] = entries the contiguous ranges would have received. */
+int MgcgLastHalo(long long volume[2]);
 
 #ifdef __cplusplus
 }

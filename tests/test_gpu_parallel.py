@@ -247,3 +247,48 @@ def test_distributed_multigrid_over_loopback(oracle, monkeypatch, world, dims, l
         assert_trace_close(tr, ref["trace"])
     assert np.array_equal(z, zref)                       # the preconditioner does not depend on the partition
     assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
+
+
+@pytest.mark.parametrize("world,mean_upper,expect_lists", [(4, 0.0, True), (5, 0.0, True), (3, 0.3, False), (2, 6.0, False)])
+def test_unstructured_halo_moves_index_lists(oracle, monkeypatch, world, mean_upper, expect_lists):
+    """Unstructured slices (BASELINE config 5 in miniature): the reference's contiguous halo ranges [minJ, offset) and
+    [offset + count, maxJ] (Mgcg.cu:83-84) come to the whole vector; the plan built from the slice's column ids moves only
+    the entries that are referenced -- when that at least halves the volume (collective decision), else the ranges stay."""
+    import ctypes as C
+
+    monkeypatch.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    s = problems.random_spd(4000, mean_upper=mean_upper, seed=77)
+    s.b[:] = np.cos(np.arange(s.Count) * 0.37) * (1.0 + np.arange(s.Count) % 7)
+    ref = oracle.cg_parallel(s, world, max_iteration=s.Count, trace=True)
+    assert ref["iteration"] >= 4
+    maxnz = int(np.diff(s.RowOffsets).max())
+
+    def make_rank(rank, comm):
+        cg = ConjugateGradientRankGpu(s.Count, maxnz, 0, s.Count, 1e-8, rank=rank, world=world, comm=comm, device=rank).load(s)
+        cg.Initialize()
+        cg.Solve(trace=True)
+        vol = (C.c_longlong * 2)(0, 0)
+        lists = _lib.lib().MgcgLastHalo(vol)
+        cg.Read()
+        # what this rank's slice really references outside its own rows
+        lo, hi = cg.part.offset, cg.part.offset + cg.part.count
+        cols = s.ColumnIndeces[s.RowOffsets[lo]: s.RowOffsets[hi]]
+        needed = np.unique(cols[(cols < lo) | (cols >= hi)]).size
+        out = (lo, cg.part.count, cg.x[lo:hi].copy(), cg.Iteration, cg.trace, lists, int(vol[0]), int(vol[1]), needed)
+        cg.Dispose()
+        return out
+
+    res = _run_ranks_in_threads(world, make_rank)
+    x = np.zeros(s.Count)
+    from tests.gpu_util import assert_trace_close
+    for off, cnt, xs, it, tr, lists, moved, contiguous, needed in res:
+        x[off: off + cnt] = xs
+        assert it == ref["iteration"]
+        assert_trace_close(tr, ref["trace"], loose=1.0)
+        assert bool(lists) == expect_lists
+        if expect_lists:
+            assert moved == needed and moved < s.Count - cnt      # exactly the referenced entries, fewer than the rest of the vector
+            assert contiguous > moved
+        else:
+            assert moved == contiguous
+    assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
