@@ -143,3 +143,111 @@ def test_config3_mgcg_at_full_size():
     for v in (y, ones):
         v.Dispose()
     mg.Dispose()
+
+
+def test_config4_rank_slabs_at_full_size(monkeypatch):
+    """BASELINE config 4's per-rank problem at true size on ONE GPU: 512 x 512 z-slabs of 32 planes, three loopback ranks
+    (the middle one has a halo plane on BOTH sides, as six of the eight ranks of the 8-GPU run have), 3-level V(1,1) MGCG.
+    Properties (no oracle can run 25 M rows in seconds): the partitioned solve takes exactly as many iterations as the
+    single-domain solve of the same grid and agrees with it, the preconditioner is independent of the partition bit for bit,
+    and the reported recurrence residual equals ||b - A x|| recomputed from the gathered x."""
+    from conjugategradient_amd.multigrid import ConjugateGradientMgGpu
+    from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu
+    from tests.test_gpu_parallel import _run_ranks_in_threads
+
+    world, nx, nz = 3, 512, 96
+    dims = (nx, nx, nz)
+    N = nx * nx * nz
+    L = _lib.lib()
+    tol = 1e-8 * np.sqrt(N)
+    rng = np.random.default_rng(4)
+    rvec = rng.standard_normal(N)
+    # single domain
+    mg = ConjugateGradientMgGpu(N, 7, 0, 1000, tol, dims, levels=3, rule=_lib.RULE_CSHARP)
+    mg.InitializePoisson()
+    z1 = mg.Apply(rvec)
+    mg.Solve()
+    it1, res1 = mg.Iteration, mg.Residual
+    x1 = np.empty(N)
+    mg.vectorX.CopyTo(x1, N, 0)
+    mg.Dispose()
+    assert res1 < tol and 20 < it1 < 400
+
+    monkeypatch.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    monkeypatch.setenv("MGCG_OVERLAP", "2")
+
+    def make_rank(rank, comm):
+        cg = ConjugateGradientMgRankGpu(N, 7, 0, 1000, tol, dims, rank=rank, world=world, comm=comm, device=rank, levels=3, rule=_lib.RULE_CSHARP)
+        cg.InitializePoisson(*dims)
+        cg.Setup()
+        off, cnt = cg.part.offset, cg.part.count
+        assert cnt == nx * nx * (nz // world)
+        z = cg.Apply(rvec[off: off + cnt])
+        cg.Solve()
+        xs = np.empty(cnt)
+        cg.vectorX.CopyTo(xs, cnt, 0)
+        out = (off, cnt, z, xs, cg.Iteration, cg.Residual)
+        cg.Dispose()
+        return out
+
+    res = _run_ranks_in_threads(world, make_rank)
+    x, z = np.empty(N), np.empty(N)
+    for off, cnt, zs, xs, it, resid in res:
+        z[off: off + cnt] = zs
+        x[off: off + cnt] = xs
+        assert it == it1
+        assert resid == res[0][5]                             # every rank holds the same all-reduced bits
+    assert np.array_equal(z, z1)                              # M^-1 does not depend on the partition
+    assert np.abs(x - x1).max() <= 1e-10 * np.abs(x1).max()
+    # ||b - A x|| recomputed with the closed-form stencil (b = 1)
+    X = x.reshape(nz, nx, nx)
+    AX = 6.0 * X
+    AX[1:] -= X[:-1]; AX[:-1] -= X[1:]
+    AX[:, 1:] -= X[:, :-1]; AX[:, :-1] -= X[:, 1:]
+    AX[:, :, 1:] -= X[:, :, :-1]; AX[:, :, :-1] -= X[:, :, 1:]
+    true_res = float(np.sqrt(np.sum((1.0 - AX) ** 2)))
+    assert abs(true_res - res[0][5]) <= 0.05 * res[0][5], (true_res, res[0][5])
+
+
+def test_config5_at_full_size(oracle):
+    """BASELINE config 5 at 10 M rows (random SPD, ~31 nonzeros per row, rows of up to ~240): the automatic kernel against
+    the oracle's product (the C oracle multiplies 310 M nonzeros in about a second), the row sums (A.1 = 1 by construction),
+    and the whole solve against a manufactured solution with the residual recomputed."""
+    import conjugategradient_amd.problems as problems
+    from conjugategradient_amd.solver import ConjugateGradientSingleGpu, VectorInt
+
+    s = problems.random_spd(10_000_000, mean_upper=14.0, seed=12345)
+    N, nnz = s.Count, s.nnz
+    assert 29 < nnz / N < 33
+    L = _lib.lib()
+    xs = np.cos(np.arange(N) * 0.01)
+    ref = oracle.spmv(s.Elements, s.ColumnIndeces, s.RowOffsets, xs)
+    cg = ConjugateGradientSingleGpu(N, int(np.diff(s.RowOffsets).max()), 0, 1000, 1e-8, rule=_lib.RULE_CSHARP)
+    cg.A = type("M", (), {})()
+    cg.A.Elements, cg.A.ColumnIndeces, cg.A.RowOffsets = s.Elements, s.ColumnIndeces, s.RowOffsets
+    cg.vectorA.Dispose(); cg.vectorColumnIndeces.Dispose()
+    cg.vectorA, cg.vectorColumnIndeces = VectorDouble(nnz), VectorInt(nnz)
+    cg.x[:] = 0.0
+    cg.b[:] = ref + 2.0                                      # A.(xs + 2) = A.xs + 2 A.1 = ref + 2
+    cg.Initialize()
+    dx, dy = VectorDouble(N), VectorDouble(N)
+    args = lambda xin: (cg.cusparse, cg.matDescr, dy.ToRawPtr(), cg.vectorA.ToRawPtr(), cg.vectorRowOffsets.ToRawPtr(), cg.vectorColumnIndeces.ToRawPtr(), xin.ToRawPtr(), nnz, N, N, 1.0, 0.0)
+    dx.CopyFrom(xs, N)
+    L.CsrMV(*args(dx))
+    _lib.check("CsrMV")
+    np.testing.assert_allclose(dy.to_numpy(), ref, rtol=1e-13, atol=1e-13 * np.abs(ref).max())
+    L.MgcgFill(dx.Ptr, 1.0)
+    L.CsrMV(*args(dx))
+    assert np.abs(dy.to_numpy() - 1.0).max() <= 1e-12       # row sums: 1 + sum|off| - sum|off|
+    cg.Solve()
+    cg.Read()
+    assert 20 < cg.Iteration < 1000 and cg.Residual < 1e-8
+    assert np.abs(cg.x - (xs + 2.0)).max() <= 1e-7
+    L.Copy(cg.cublas, dx.ToRawPtr(), cg.vectorX.ToRawPtr(), N, 0, 0)
+    L.CsrMV(*args(dx))
+    r = cg.b - dy.to_numpy()
+    true_res = float(np.sqrt(np.dot(r, r)))
+    assert abs(true_res - cg.Residual) <= 0.05 * cg.Residual + 1e-10, (true_res, cg.Residual)
+    for v in (dx, dy):
+        v.Dispose()
+    cg.Dispose()
