@@ -317,9 +317,10 @@ __global__ __launch_bounds__(kBlock) void update_r_kernel(CgScalars* __restrict_
         };
         chunk_pairs(n >> 1, [&](long long i, bool two) {
             const long long j = two ? i + kBlock : i;
-            d2 av0 = a2[i], rv0 = r2[i], av1 = a2[j], rv1 = r2[j];
-            fin(rv0, av0); r2[i] = rv0;
-            if (two) { fin(rv1, av1); r2[j] = rv1; }
+            // streaming hints as in update_xp (measured there: 5.2 -> 6.3 TB/s): Ap is not read again, r not before 2 GB of other traffic
+            d2 av0 = __builtin_nontemporal_load(a2 + i), rv0 = __builtin_nontemporal_load(r2 + i), av1 = __builtin_nontemporal_load(a2 + j), rv1 = __builtin_nontemporal_load(r2 + j);
+            fin(rv0, av0); __builtin_nontemporal_store(rv0, r2 + i);
+            if (two) { fin(rv1, av1); __builtin_nontemporal_store(rv1, r2 + j); }
         });
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) one(n - 1);
     } else {

@@ -282,18 +282,19 @@ __global__ __launch_bounds__(64 * WPB) void v2_rows(Args a, int map, int planeBl
     int nMine;
     const int xcd = g & 7, wx = g >> 3, GX = G >> 3;
     const int eighth = planeBlocks / 8 / KCH;      // super blocks per plane-eighth (map 2)
-    if (map == 0 || map == 3 || map == 5 || map >= 16) nMine = (nSuper + G - 1) / G;   // (lab: nSuper is a multiple of G)
+    if (map == 0 || map == 3 || (map & 255) == 5 || (map & 255) == 6 || map >= 16) nMine = (nSuper + G - 1) / G;   // (lab: nSuper is a multiple of G)
     if (map == 0) nMine = nSuper > g ? (nSuper - g + G - 1) / G : 0;
-    else if (map == 1 || map == 3 || map == 5 || map >= 16) { nMine = (nSuper + G - 1) / G; }
+    else if (map == 1 || map == 3 || (map & 255) == 5 || (map & 255) == 6 || map >= 16) { nMine = (nSuper + G - 1) / G; }
     else { const int per = nSuper / 8; nMine = per > wx ? (per - wx + GX - 1) / GX : 0; }
     auto super_of = [&](int q) -> int {
-        if (map == 5) {      // sweep z for one y-slice of the planes at a time: trip q = h * nz + p covers tiles [p*T + h*WG, +WG) of plane p, XCD k a contiguous eighth of them
+        if ((map & 255) == 5) {      // sweep z for one y-slice of the planes at a time: trip q = h * nz + p covers tiles [p*T + h*WG, +WG) of plane p, XCD k a contiguous eighth of them
             const int wg = blockIdx.x, WG = gridDim.x, T = planeBlocks / WPB, nzp = nB / planeBlocks;
             const int h = q / nzp, pz = q - h * nzp;
             const int tile = pz * T + h * WG + (wg & 7) * (WG >> 3) + (wg >> 3);
             return tile * WPB + wv;
         }
-        if (map >= 16) { const int CH = map >> 4; const int wg = blockIdx.x, WG = gridDim.x; return ((wg + WG * (q / CH)) * CH + q % CH) * WPB + wv; }   // a workgroup walks CH * WPB consecutive blocks
+        if ((map & 255) == 6) { const int wg = blockIdx.x, WG = gridDim.x; return (q * WG + (wg & 7) * (WG >> 3) + (wg >> 3)) * WPB + wv; }   // memory order, XCD k a contiguous eighth of every trip
+        if (map >= 16 && map < 256) { const int CH = map >> 4; const int wg = blockIdx.x, WG = gridDim.x; return ((wg + WG * (q / CH)) * CH + q % CH) * WPB + wv; }   // a workgroup walks CH * WPB consecutive blocks
         if (map == 0) return g + G * q;
         if (map == 1) return q * G + xcd * GX + wx;
         if (map == 3) { const int wg = blockIdx.x, WG = gridDim.x; const int k8 = wg & 7, j = wg >> 3; return q * G + (j * WPB + wv) * 8 + k8; }   // workgroup wg (XCD wg % 8): blocks = k8 mod 8, WPB of them 8 apart
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(64 * WPB) void v2_rows(Args a, int map, int planeBl
             else if (STORE >= 4) { pend[u] = acc; pendRow[u] = row[u]; }
             else if (acc == 1.2345e300) a.y[row[u]] = acc;
         }
-        __syncthreads();
+        if (!(map & 256)) __syncthreads();           // (map bit 8: one barrier per trip -- LDS slices are private to a wavefront)
         bCur = bNext; bNext = bAfter;
     }
     if (STORE >= 4) {
@@ -483,6 +484,150 @@ __global__ __launch_bounds__(64 * WPB) void v4_rows(Args a, int map, int planeBl
     }
     __syncthreads();
     for (int q = 0; q < B; ++q) __builtin_nontemporal_store(s_pend[q * 64 + tid], a.y + s_prow[q] + tid);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dot += __shfl_down(dot, off, 64);
+    if (tid == 0) a.partials[blockIdx.x * WPB + wv] = dot;
+}
+
+// ------------------------------------------------------------------ I: one interleaved stream.  Per 256-row tile a record of 22528 B = [256 row
+// offsets... (1 KiB)][cols 7 KiB][vals 14 KiB] (interior tile of the 7-point matrix): the same bytes as the three CSR streams,
+// contiguous.  Bare streaming (no product), WPB4-style: 4 waves x 5632 B per trip, + optional y store and x,w reads.
+template <int W, int XR>
+__global__ __launch_bounds__(256) void i_stream(const d2* __restrict__ rec, long long recBytes, int nTiles, Args a)
+{
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+        const d2* base = (const d2*)((const char*)rec + (long long)tile * 22528);
+        d2 v[6];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) v[q] = base[tid + 256 * q];          // 5 x 4096 B
+        v[5] = tid < 128 ? base[tid + 1280] : v[4];                       // + 2048 B = 22528
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) t += v[q].x + v[q].y;
+        const int r = tile * 256 + tid;
+        if (XR) t += a.x[r] + a.w[r];
+        acc += t;
+        if (W) __builtin_nontemporal_store(t, a.y + r);
+    }
+    if (acc == 1.2345e300) a.partials[blockIdx.x] = acc;
+}
+// the same bytes from the three CSR arrays, same workgroup shape
+template <int W, int XR>
+__global__ __launch_bounds__(256) void c_stream(Args a, int nTiles)
+{
+    const int tid = threadIdx.x;
+    const int kMax4 = (a.nnz - 4) & ~3, kMax2 = (a.nnz - 2) & ~1;
+    double acc = 0.0;
+    for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+        const int r = tile * 256 + tid;
+        const int rs = a.ro[r];
+        const int tb = (tile * 1792) & ~3;
+        int k0 = tb + 4 * tid, k1 = k0 + 1024; k0 = k0 < kMax4 ? k0 : kMax4; k1 = k1 < kMax4 ? k1 : kMax4;
+        const i4 c0 = *(const i4*)(a.col + k0), c1 = *(const i4*)(a.col + k1);
+        d2 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { int j = tb + 2 * tid + 512 * q; j = j < kMax2 ? j : kMax2; v[q] = *(const d2*)(a.val + j); }
+        double t = (double)(rs + c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t += v[q].x + v[q].y;
+        if (XR) t += a.x[r] + a.w[r];
+        acc += t;
+        if (W) __builtin_nontemporal_store(t, a.y + r);
+    }
+    if (acc == 1.2345e300) a.partials[blockIdx.x] = acc;
+}
+
+// ------------------------------------------------------------------ V5: block records.  Per 64-row block one contiguous, 16-byte aligned record
+//   [65 int32: start of every row relative to the block, then the block's nnz][pad to 272 B][cols, padded to a multiple of 4][vals]
+// = the CSR numbers of the block in one piece (12 B per nonzero + 4.25 B per row); recOff[b] = byte offset of block b's record / 16.
+__global__ void rec_size_kernel(const int* __restrict__ ro, int nBlocks, int rows, unsigned* __restrict__ units)
+{
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nBlocks; b += gridDim.x * blockDim.x) {
+        const int r0 = b * 64, r1 = (r0 + 64 < rows) ? r0 + 64 : rows;
+        const int nnzB = ro[r1] - ro[r0];
+        const int P = (nnzB + 3) & ~3;
+        units[b] = (272 + 12 * P) / 16;
+    }
+}
+__global__ __launch_bounds__(64) void rec_fill_kernel(const int* __restrict__ ro, const int* __restrict__ col, const double* __restrict__ val, int nBlocks, int rows,
+                                                      const long long* __restrict__ recOff, char* __restrict__ rec)
+{
+    for (int b = blockIdx.x; b < nBlocks; b += gridDim.x) {
+        const int r0 = b * 64, r1 = (r0 + 64 < rows) ? r0 + 64 : rows;
+        const int s = ro[r0], nnzB = ro[r1] - s, P = (nnzB + 3) & ~3;
+        char* base = rec + recOff[b] * 16;
+        int* hdr = (int*)base;
+        const int l = threadIdx.x;
+        { const int r = r0 + l < r1 ? r0 + l : r1; hdr[l] = ro[r] - s; }
+        if (l == 0) { hdr[64] = nnzB; hdr[65] = 0; hdr[66] = 0; hdr[67] = 0; }
+        int* c = (int*)(base + 272); double* v = (double*)(base + 272 + 4 * P);
+        for (int k = l; k < P; k += 64) { c[k] = k < nnzB ? col[s + k] : 0; v[k] = k < nnzB ? val[s + k] : 0.0; }
+    }
+}
+template <int NG>
+__global__ __launch_bounds__(256) void v5_rows(Args a, const long long* __restrict__ recOff, const char* __restrict__ rec, int map, int planeBlocks)
+{
+    constexpr int WPB = 4;
+    __shared__ __attribute__((aligned(16))) char s_recAll[6144 * WPB];
+    const int tid = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    char* s_rec = s_recAll + wv * 6144;
+    const int* s_hdr = (const int*)s_rec; const int* s_col = (const int*)(s_rec + 272);
+    const int nB = a.nBlocks;
+    const int wg = blockIdx.x, WG = gridDim.x;
+    const int nTrips = nB / (WG * WPB);
+    auto block_of = [&](int t) -> int {
+        t = t < nTrips ? t : nTrips - 1;
+        if (map == 5) {
+            const int T = planeBlocks / WPB, nzp = nB / planeBlocks;
+            const int h = t / nzp, pz = t - h * nzp;
+            return (pz * T + h * WG + (wg & 7) * (WG >> 3) + (wg >> 3)) * WPB + wv;
+        }
+        return (wg + WG * t) * WPB + wv;
+    };
+    typedef int i4v __attribute__((ext_vector_type(4)));
+    i4v raw[6];
+    auto load_raw = [&](long long off16, long long end16) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { long long u = off16 + tid + 64 * q; u = u < end16 ? u : end16 - 1; raw[q] = *(const i4v*)(rec + u * 16); }
+    };
+    int bCur = block_of(0), bNext = block_of(1);
+    long long oA = recOff[bCur], eA = recOff[bCur + 1];
+    load_raw(oA, eA);
+    long long oB = recOff[bNext], eB = recOff[bNext + 1];
+    double dot = 0.0, pend = 0.0;
+    int pendRow = bCur * 64 + tid;
+    for (int t = 0; t < nTrips; ++t) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) *(i4v*)(s_rec + 16 * (tid + 64 * q)) = raw[q];
+        __syncthreads();
+        const int my_s = s_hdr[tid], my_e = s_hdr[tid + 1], nnzB = s_hdr[64];
+        const int cnt = my_e - my_s;
+        const int P = (nnzB + 3) & ~3;
+        const double* s_val = (const double*)(s_rec + 272 + 4 * P);
+        const int row = bCur * 64 + tid;
+        int cc[NG]; double vv[NG], xg[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) { int idx = my_s + j; idx = j < cnt ? idx : 0; cc[j] = s_col[idx]; vv[j] = s_val[idx]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NG; ++j) xg[j] = a.x[cc[j]];
+        const double w = a.w[row];
+        __builtin_nontemporal_store(pend, a.y + pendRow);
+        load_raw(oB, eB);
+        const int bAfter = block_of(t + 2);
+        oB = recOff[bAfter]; eB = recOff[bAfter + 1];
+        __builtin_amdgcn_sched_barrier(0);
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) { const double p = vv[j] * xg[j]; acc += (j < cnt) ? p : 0.0; }
+        dot += w * acc;
+        pend = acc; pendRow = row;
+        __syncthreads();
+        bCur = bNext; bNext = bAfter;
+    }
+    __builtin_nontemporal_store(pend, a.y + pendRow);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) dot += __shfl_down(dot, off, 64);
     if (tid == 0) a.partials[blockIdx.x * WPB + wv] = dot;
@@ -653,6 +798,64 @@ int main(int argc, char** argv)
     { CK(hipMemset(d_y, 0xff, N * 8)); \
         double ms = time_ms([&] { hipLaunchKernelGGL((v4_rows<4, NGv, Bv>), dim3(512), dim3(256), 0, 0, a, mapv, n * n / 64); }, reps); \
         bool ok = check(label); report(label, 8, ms, ok); }
+    if (argc > 3 && !strcmp(argv[3], "interleave")) {
+        const int nTiles = (int)(N / 256);
+        const long long recBytes = (long long)nTiles * 22528;
+        d2* rec; CK(hipMalloc(&rec, recBytes + 4096)); CK(hipMemset(rec, 0x11, recBytes + 4096));
+        printf("one interleaved stream (%.2f GB) vs the three CSR arrays (%.2f GB), bare streaming, 512 workgroups of 256\n", recBytes / 1e9, (12.0 * nnz + 4.0 * N) / 1e9);
+        for (int rep = 0; rep < 3; ++rep) {
+            for (int g : { 512, 1024 }) {
+                double a0 = time_ms([&] { hipLaunchKernelGGL((i_stream<0, 0>), dim3(g), dim3(256), 0, 0, rec, recBytes, nTiles, a); }, reps);
+                double a1 = time_ms([&] { hipLaunchKernelGGL((i_stream<1, 1>), dim3(g), dim3(256), 0, 0, rec, recBytes, nTiles, a); }, reps);
+                double b0 = time_ms([&] { hipLaunchKernelGGL((c_stream<0, 0>), dim3(g), dim3(256), 0, 0, a, nTiles); }, reps);
+                double b1 = time_ms([&] { hipLaunchKernelGGL((c_stream<1, 1>), dim3(g), dim3(256), 0, 0, a, nTiles); }, reps);
+                printf("  grid %4d: interleaved %.3f ms, + y store + x,w %.3f ms | three arrays %.3f ms, + y store + x,w %.3f ms\n", g, a0, a1, b0, b1);
+            }
+        }
+        return 0;
+    }
+    if (argc > 3 && !strcmp(argv[3], "records")) {
+        const int nBlk = (int)(N / 64);
+        unsigned* d_units; long long* d_off; CK(hipMalloc(&d_units, nBlk * 4)); CK(hipMalloc(&d_off, (nBlk + 1) * 8));
+        hipLaunchKernelGGL(rec_size_kernel, dim3(2048), dim3(256), 0, 0, d_ro, nBlk, (int)N, d_units);
+        std::vector<unsigned> units(nBlk); CK(hipMemcpy(units.data(), d_units, nBlk * 4, hipMemcpyDeviceToHost));
+        std::vector<long long> off(nBlk + 1); off[0] = 0; for (int b = 0; b < nBlk; ++b) off[b + 1] = off[b] + units[b];
+        CK(hipMemcpy(d_off, off.data(), (nBlk + 1) * 8, hipMemcpyHostToDevice));
+        char* d_rec; CK(hipMalloc(&d_rec, off[nBlk] * 16 + 4096));
+        double tb = time_ms([&] { hipLaunchKernelGGL(rec_fill_kernel, dim3(16384), dim3(64), 0, 0, d_ro, d_col, d_val, nBlk, (int)N, d_off, d_rec); }, 3);
+        printf("block records: %.3f GB (CSR arrays %.3f GB), built in %.2f ms\n", off[nBlk] * 16 / 1e9, (12.0 * nnz + 4.0 * (N + 1)) / 1e9, tb);
+        for (int rep = 0; rep < 3; ++rep) {
+            wpcs = { 8 };
+            RUNV3(false, 5, 1, 1, 4, 5, "CSR arrays, NG8, z sweep", true)
+            { CK(hipMemset(d_y, 0xff, N * 8)); double ms = time_ms([&] { hipLaunchKernelGGL((v5_rows<8>), dim3(512), dim3(256), 0, 0, a, d_off, d_rec, 5, n * n / 64); }, reps); bool ok = check("v5"); report("block records, NG8, z sweep", 8, ms, ok); }
+            { CK(hipMemset(d_y, 0xff, N * 8)); double ms = time_ms([&] { hipLaunchKernelGGL((v5_rows<7>), dim3(512), dim3(256), 0, 0, a, d_off, d_rec, 5, n * n / 64); }, reps); bool ok = check("v5"); report("block records, NG7, z sweep", 8, ms, ok); }
+            { CK(hipMemset(d_y, 0xff, N * 8)); double ms = time_ms([&] { hipLaunchKernelGGL((v5_rows<8>), dim3(512), dim3(256), 0, 0, a, d_off, d_rec, 0, n * n / 64); }, reps); bool ok = check("v5"); report("block records, NG8, grid-stride", 8, ms, ok); }
+            { CK(hipMemset(d_y, 0xff, N * 8)); double ms = time_ms([&] { hipLaunchKernelGGL((v5_rows<8>), dim3(1024), dim3(256), 0, 0, a, d_off, d_rec, 0, n * n / 64); }, reps); bool ok = check("v5"); report("block records, NG8, grid-stride", 16, ms, ok); }
+        }
+        return 0;
+    }
+    if (argc > 3 && !strcmp(argv[3], "order")) {
+        wpcs = { 8 };
+        for (int rep = 0; rep < 3; ++rep) {
+            RUNV3(false, 5, 1, 1, 4, 0, "grid-stride (tile = wg + WG t)", true)
+            RUNV3(false, 5, 1, 1, 4, 5, "z sweep (plane by plane per half)", true)
+            RUNV3(false, 5, 1, 1, 4, 6, "memory order, XCD-contiguous eighths", true)
+        }
+        wpcs = { 16 };
+        RUNV3(false, 5, 1, 1, 4, 0, "grid-stride", true)
+        RUNV3(false, 5, 1, 1, 4, 5, "z sweep (H = 1: whole planes)", true)
+        return 0;
+    }
+    if (argc > 3 && !strcmp(argv[3], "micro")) {
+        wpcs = { 8 };
+        for (int rep = 0; rep < 3; ++rep) {
+            RUNV3(false, 5, 1, 1, 4, 5, "NG8 two barriers", true)
+            RUNV3(false, 5, 1, 1, 4, 5 + 256, "NG8 one barrier", true)
+            { CK(hipMemset(d_y, 0xff, N * 8)); double ms = time_ms([&] { hipLaunchKernelGGL((v2_rows<false, 5, 1, 1, 4, 7>), dim3(512), dim3(256), 0, 0, a, 5, n * n / 64); }, reps); bool ok = check("ng7"); report("NG7 two barriers", 8, ms, ok); }
+            { CK(hipMemset(d_y, 0xff, N * 8)); double ms = time_ms([&] { hipLaunchKernelGGL((v2_rows<false, 5, 1, 1, 4, 7>), dim3(512), dim3(256), 0, 0, a, 5 + 256, n * n / 64); }, reps); bool ok = check("ng7"); report("NG7 one barrier", 8, ms, ok); }
+        }
+        return 0;
+    }
     if (argc > 3 && !strcmp(argv[3], "batch")) {
         for (int rep = 0; rep < 2; ++rep) {
             RUNV4(7, 1, 5, "V4 NG7 B1 sweep")

@@ -45,6 +45,7 @@ def main():
                 ("wave R64 g4096 nt", 1, 64, 1, 4096, 0, 0), ("wave R32 g6144", 1, 32, 0, 6144, 0, 0),
                 ("wave R64 band", 1, 64, 4, 0, 0, 0), ("wave R32 band", 1, 32, 4, 0, 0, 0), ("wave R32 band 8Lx8", 1, 32, 4, 0, 8 * n, 8),
                 ("wg256 band 64Lx1", 1, 128, 4, 0, 64 * n, 1), ("vector 4 lanes", 4, 128, 0, 0, 0, 0),
+                ("rowtile", 10, 64, 0, 0, 0, 0), ("DOT rowtile", 10, 64, 0, 0, 0, 0), ("rowtile no sweep", 10, 64, 0, 0, 0, 0), ("rowtile g4096", 10, 64, 0, 4096, 0, 0),
                 ("rows", 9, 64, 0, 0, 0, 0), ("rows g2048", 9, 64, 0, 2048, 0, 0), ("rows g5120", 9, 64, 0, 5120, 0, 0), ("DOT rows", 9, 64, 0, 0, 0, 0),
                 ("dcsr", 1, 64, 0, 0, 0, 0), ("dcsr g2048", 1, 64, 0, 2048, 0, 0), ("dcsr g8192", 1, 64, 0, 8192, 0, 0), ("dcsr g5120", 1, 64, 0, 5120, 0, 0), ("dcsr g6144", 1, 64, 0, 6144, 0, 0), ("DOT dcsr", 1, 64, 0, 0, 0, 0), ("pattern", 1, 64, 0, 0, 0, 0), ("DOT pattern", 1, 64, 0, 0, 0, 0),
                 ("DOT wave R64 g4096", 1, 64, 0, 4096, 0, 0), ("DOT wave R64 band", 1, 64, 4, 0, 0, 0), ("DOT wg256 R128", 1, 128, 0, 0, 0, 0)]
@@ -64,7 +65,7 @@ def main():
         L.MgcgSetMatrixCompression(sparse, 2 if "dcsr" in v[0] else (1 if "pattern" in v[0] else 0))
         L.MgcgSetSpmvKernel(sparse, v[1])
         L.MgcgSetSpmvTuning(sparse, v[2], v[3], v[4])
-        L.MgcgSetSpmvPeriod(sparse, n * n if (v[3] & 4) else 0)
+        L.MgcgSetSpmvPeriod(sparse, n * n if (v[3] & 4) else (640 if v[0] == "rowtile no sweep" else 0))   # 640: a hint the row-tile kernel cannot use -> grid-stride order
         L.MgcgSetSpmvTile(sparse, v[5], v[6])
         L.MgcgEventRecord(ev0)
         for _ in range(a.reps):
