@@ -158,7 +158,7 @@ struct MgcgSparse {
     std::vector<mgcg::DcsrMatrix*> analysed;
     // far-band distance found per matrix (the tile order of the row-tile kernel; any value gives the same results, so a stale
     // entry can only cost locality): keyed by the array pointers and the row count
-    struct PeriodEntry { const int* rowOffsets; const int* columnIndeces; long long rows, rowBase; int period; };
+    struct PeriodEntry { const int* rowOffsets; const int* columnIndeces; long long rows, rowBase; int period; int maxRow; };
     std::vector<PeriodEntry> periods;
 };
 struct MgcgMatDescr { int type = 0; int base = 0; };
@@ -214,17 +214,19 @@ inline int spmv_auto_kernel(double avgRow)
     return 7;
 }
 
-struct SpmvConfig { int kernel = 0; int rowsPerBlock = 64; int flags = 0; int gridBlocks = 0; int periodRows = 0; int tileRows = 0; int tilePlanes = 0; };
+struct SpmvConfig { int kernel = 0; int rowsPerBlock = 64; int flags = 0; int gridBlocks = 0; int periodRows = 0; int tileRows = 0; int tilePlanes = 0;
+                    int maxRow = 0; /* longest row if known (row-tile kernel: 7 gathers per row when <= 7), 0 = unknown */ };
 
 // Launches the SpMV; returns the number of partials written (grid size) for dot epilogues.
 int launch_spmv(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg);
 // Row-tile kernel for short rows on plain CSR (kernels_rowtile.hip); periodRows = distance of the far band in rows (0: unknown),
 // gridReq = wavefronts (0: 8 per CU).  Needs 16-byte aligned elements / columnIndeces and elementsCount >= 8.
-int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int periodRows, int gridReq);
-// Distance (in rows) of the farthest band of the matrix, read off one row in the middle of the slice (one tiny kernel and a
-// 4-byte read, remembered per handle); the caller's hint (MgcgSetSpmvPeriod) wins.  0: not found.
-int spmv_period(MgcgSparse* h, const int* rowOffsets, const int* columnIndeces, long long rows, long long rowBase);
-void launch_far_band(hipStream_t s, const int* rowOffsets, const int* columnIndeces, long long row, long long rowBase, int* out);
+int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int periodRows, int gridReq, int maxRow = 0);
+// Distance (in rows) of the farthest band of the matrix, read off one row in the middle of the slice, and the longest row (one pass
+// over the row offsets; both remembered per handle -- stale values can only cost speed: any period gives the same results, and rows
+// longer than the remembered maximum take the kernel's slow path); the caller's hint (MgcgSetSpmvPeriod) wins for the period.
+int spmv_period(MgcgSparse* h, const int* rowOffsets, const int* columnIndeces, long long rows, long long rowBase, int* maxRow = nullptr);
+void launch_matrix_shape(hipStream_t s, const int* rowOffsets, const int* columnIndeces, long long rows, long long row, long long rowBase, int* out2);
 // The same on the dictionary-compressed form of the matrix (a.elements / a.columnIndeces still serve array tails and long rows).
 int launch_spmv_rows(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView* m, int gridReq);   // m == nullptr: plain CSR
 bool dcsr_build(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces,

@@ -64,7 +64,9 @@ __device__ __forceinline__ RowsEpi tile_epi_prefetch(const SpmvArgs& a, int row)
     return o;
 }
 
-template <int EPI>
+// NG = gathers issued per row in the fast path: 8, or 7 when no row of the matrix is longer (a 7-point stencil: one LDS read
+// pair, one gather and one product fewer per row, 1-2.5 % -- profiles/r2/spmv_lab_lab15_micro.log, spmv_lab_lab17_records.log).
+template <int EPI, int NG>
 __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, TileMap tm, int nTiles)
 {
     __shared__ __attribute__((aligned(16))) int s_colAll[kTCap * kTW];
@@ -143,31 +145,31 @@ __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, Tile
         const int tb = s & ~3;
         const int my_s = roA_s, cnt = roA_e - roA_s;
         const int row = tileCur * kTRows + wv * 64 + tid;
-        // the fast path holds the whole span in one pass and every row in one batch of gathers
+        // the fast path holds the whole span in one pass and every row in one batch of NG gathers
         const bool spanOk = (e - tb <= kTCap) && (e <= kMax4 + 4);
-        const bool short8 = __ballot(cnt > 8) == 0ull;
+        const bool short8 = __ballot(cnt > NG) == 0ull;
         const bool fast = spanOk && short8;                        // wavefront-uniform
 
         *(i4*)(s_col + 4 * tid) = c0; *(i4*)(s_col + 256 + 4 * tid) = c1;
         *(d2*)(s_val + 2 * tid) = v0; *(d2*)(s_val + 128 + 2 * tid) = v1; *(d2*)(s_val + 256 + 2 * tid) = v2; *(d2*)(s_val + 384 + 2 * tid) = v3;
         __syncthreads();
-        int cc[8]; double vv[8], xg[8];
+        int cc[NG]; double vv[NG], xg[NG];
         double accSlow = 0.0;
         if (fast) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NG; ++j) {
                 int idx = my_s - tb + j;
                 idx = j < cnt ? idx : 0;                           // masked slots read entry 0 of the span (a valid column)
                 cc[j] = s_col[idx]; vv[j] = s_val[idx];
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { cc[j] = 0; vv[j] = 0.0; }
+            for (int j = 0; j < NG; ++j) { cc[j] = 0; vv[j] = 0.0; }
             for (int k = my_s; k < roA_e; ++k) { const double p = a.elements[k] * a.x[a.columnIndeces[k]]; accSlow += p; }
         }
         __builtin_amdgcn_sched_barrier(0);                         // all LDS reads in flight before the first gather waits for its column id
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xg[j] = a.x[cc[j]];
+        for (int j = 0; j < NG; ++j) xg[j] = a.x[cc[j]];
         const RowsEpi eo = tile_epi_prefetch<EPI>(a, row);
         // the previous trip's result, then the next trip's raw stream and the row offsets of the trip after it
         __builtin_nontemporal_store(pend, a.y + pendRow);
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, Tile
         __builtin_amdgcn_sched_barrier(0);                         // no product in front of the prefetch: its wait would hold the raw loads back
         double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const double p = vv[j] * xg[j]; acc += (j < cnt) ? p : 0.0; }
+        for (int j = 0; j < NG; ++j) { const double p = vv[j] * xg[j]; acc += (j < cnt) ? p : 0.0; }
         acc = fast ? acc : accSlow;
         pend = rows_epilogue_value<EPI>(a, acc, eo, dot);
         pendRow = row;
@@ -189,19 +191,31 @@ __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, Tile
     finish();
 }
 
-__global__ void far_band_kernel(const int* rowOffsets, const int* columnIndeces, long long row, long long rowBase, int* out)
+// out[0] = distance of the farthest entry of row `row` from the diagonal, out[1] = longest row of the matrix (out zeroed by the caller)
+__global__ __launch_bounds__(kBlock) void matrix_shape_kernel(const int* __restrict__ rowOffsets, const int* __restrict__ columnIndeces, long long rows, long long row, long long rowBase, int* out)
 {
-    long long far = 0;
-    for (int k = rowOffsets[row]; k < rowOffsets[row + 1]; ++k) {
-        long long d = (long long)columnIndeces[k] - (rowBase + row);
-        d = d < 0 ? -d : d;
-        far = d > far ? d : far;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        long long far = 0;
+        for (int k = rowOffsets[row]; k < rowOffsets[row + 1]; ++k) {
+            long long d = (long long)columnIndeces[k] - (rowBase + row);
+            d = d < 0 ? -d : d;
+            far = d > far ? d : far;
+        }
+        out[0] = far > 0x7fffffffLL ? 0 : (int)far;
     }
-    *out = far > 0x7fffffffLL ? 0 : (int)far;
+    int longest = 0;
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < rows; i += stride) { const int len = rowOffsets[i + 1] - rowOffsets[i]; longest = len > longest ? len : longest; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_down(longest, off, 64); longest = o > longest ? o : longest; }
+    if ((threadIdx.x & 63) == 0 && longest > 0) atomicMax(&out[1], longest);
 }
-void launch_far_band(hipStream_t s, const int* rowOffsets, const int* columnIndeces, long long row, long long rowBase, int* out)
+void launch_matrix_shape(hipStream_t s, const int* rowOffsets, const int* columnIndeces, long long rows, long long row, long long rowBase, int* out2)
 {
-    hipLaunchKernelGGL(far_band_kernel, dim3(1), dim3(1), 0, s, rowOffsets, columnIndeces, row, rowBase, out);
+    long long blocks = (rows + kBlock - 1) / kBlock;
+    if (blocks > kMaxGrid) blocks = kMaxGrid;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(matrix_shape_kernel, dim3((int)blocks), dim3(kBlock), 0, s, rowOffsets, columnIndeces, rows, row, rowBase, out2);
 }
 
 // Tile order for a matrix of `rows` rows whose far band lies periodRows rows from the diagonal (0: unknown).
@@ -221,7 +235,7 @@ static TileMap make_tile_map(long long rows, int periodRows, int nWG)
 }
 
 template <int EPI>
-static int launch_rowtile_epi(hipStream_t s, const SpmvArgs& a, int periodRows, int gridReq)
+static int launch_rowtile_epi(hipStream_t s, const SpmvArgs& a, int periodRows, int gridReq, int maxRow)
 {
     const int nTiles = a.rowCount / kTRows;                       // full tiles; the kernel's workgroup 0 takes the rows behind them
     DeviceState* d = device_state();
@@ -232,21 +246,22 @@ static int launch_rowtile_epi(hipStream_t s, const SpmvArgs& a, int periodRows, 
     if (nWG < 1) nWG = 1;
     static const bool noSweep = getenv("MGCG_NO_ZSWEEP") != nullptr;
     const TileMap tm = make_tile_map(a.rowCount, noSweep ? 0 : periodRows, nWG);
-    hipLaunchKernelGGL((spmv_rowtile_kernel<EPI>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
+    if (maxRow > 0 && maxRow <= 7) hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 7>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
+    else hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 8>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
     return nWG * kTW;
 }
 
 // Requires 16-byte aligned elements and columnIndeces and elementsCount >= 8 (checked by the caller).
-int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int periodRows, int gridReq)
+int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int periodRows, int gridReq, int maxRow)
 {
     if (a.rowCount <= 0) return 0;
     switch (epilogue) {
-    case EPI_AXPBY:        return a.beta != 0.0 ? launch_rowtile_epi<EPI_AXPBY_BETA>(s, a, periodRows, gridReq) : launch_rowtile_epi<EPI_AXPBY>(s, a, periodRows, gridReq);
-    case EPI_DOT:          return launch_rowtile_epi<EPI_DOT>(s, a, periodRows, gridReq);
-    case EPI_RESIDUAL:     return launch_rowtile_epi<EPI_RESIDUAL>(s, a, periodRows, gridReq);
-    case EPI_RESIDUAL_DOT: return launch_rowtile_epi<EPI_RESIDUAL_DOT>(s, a, periodRows, gridReq);
-    case EPI_JACOBI:       return launch_rowtile_epi<EPI_JACOBI>(s, a, periodRows, gridReq);
-    case EPI_JACOBI_DOT:   return launch_rowtile_epi<EPI_JACOBI_DOT>(s, a, periodRows, gridReq);
+    case EPI_AXPBY:        return a.beta != 0.0 ? launch_rowtile_epi<EPI_AXPBY_BETA>(s, a, periodRows, gridReq, maxRow) : launch_rowtile_epi<EPI_AXPBY>(s, a, periodRows, gridReq, maxRow);
+    case EPI_DOT:          return launch_rowtile_epi<EPI_DOT>(s, a, periodRows, gridReq, maxRow);
+    case EPI_RESIDUAL:     return launch_rowtile_epi<EPI_RESIDUAL>(s, a, periodRows, gridReq, maxRow);
+    case EPI_RESIDUAL_DOT: return launch_rowtile_epi<EPI_RESIDUAL_DOT>(s, a, periodRows, gridReq, maxRow);
+    case EPI_JACOBI:       return launch_rowtile_epi<EPI_JACOBI>(s, a, periodRows, gridReq, maxRow);
+    case EPI_JACOBI_DOT:   return launch_rowtile_epi<EPI_JACOBI_DOT>(s, a, periodRows, gridReq, maxRow);
     }
     return 0;
 }

@@ -20,7 +20,7 @@ static SpmvConfig cfg_of(const MgcgSparse* h)
 static SpmvConfig cfg_for(MgcgSparse* h, const SpmvArgs& a, long long rowBase)
 {
     SpmvConfig c = cfg_of(h);
-    if (c.periodRows == 0 && a.elementsCount >= 8) c.periodRows = spmv_period(h, a.rowOffsets, a.columnIndeces, a.rowCount, rowBase);
+    if (a.elementsCount >= 8) c.periodRows = spmv_period(h, a.rowOffsets, a.columnIndeces, a.rowCount, rowBase, &c.maxRow);
     return c;
 }
 

@@ -172,20 +172,24 @@ const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* 
     return m->usable ? m : nullptr;
 }
 
-int spmv_period(MgcgSparse* h, const int* rowOffsets, const int* columnIndeces, long long rows, long long rowBase)
+int spmv_period(MgcgSparse* h, const int* rowOffsets, const int* columnIndeces, long long rows, long long rowBase, int* maxRow)
 {
-    if (!h || rows < 4096) return 0;
-    if (h->periodRows > 0) return h->periodRows;
+    if (maxRow) *maxRow = 0;
+    if (!h || rows < 4096) return h ? h->periodRows : 0;
     for (const auto& e : h->periods)
-        if (e.rowOffsets == rowOffsets && e.columnIndeces == columnIndeces && e.rows == rows && e.rowBase == rowBase) return e.period;
-    int period = 0;
-    int* slot = (int*)&h->ws.hostScalar[3];                 // pinned, device-visible
-    *slot = 0;
-    launch_far_band(h->ws.stream, rowOffsets, columnIndeces, rows / 2, rowBase, slot);
-    if (MGCG_HIP(hipGetLastError()) && MGCG_HIP(hipStreamSynchronize(h->ws.stream))) period = *slot;
+        if (e.rowOffsets == rowOffsets && e.columnIndeces == columnIndeces && e.rows == rows && e.rowBase == rowBase) {
+            if (maxRow) *maxRow = e.maxRow;
+            return h->periodRows > 0 ? h->periodRows : e.period;
+        }
+    int period = 0, longest = 0;
+    int* slot = (int*)&h->ws.hostScalar[2];                 // pinned, device-visible: two ints
+    slot[0] = 0; slot[1] = 0;
+    launch_matrix_shape(h->ws.stream, rowOffsets, columnIndeces, rows, rows / 2, rowBase, slot);
+    if (MGCG_HIP(hipGetLastError()) && MGCG_HIP(hipStreamSynchronize(h->ws.stream))) { period = slot[0]; longest = slot[1]; }
     if (h->periods.size() >= 64) h->periods.clear();
-    h->periods.push_back({ rowOffsets, columnIndeces, rows, rowBase, period });
-    return period;
+    h->periods.push_back({ rowOffsets, columnIndeces, rows, rowBase, period, longest });
+    if (maxRow) *maxRow = longest;
+    return h->periodRows > 0 ? h->periodRows : period;
 }
 
 int launch_spmv_auto(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg, const DcsrMatrix* dc)

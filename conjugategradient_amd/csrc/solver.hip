@@ -249,7 +249,7 @@ static bool cg_enqueue_init(CgRun& R)
 {
     hipStream_t s = R.ws->stream;
     if (R.cusparse) R.dcsr = dcsr_lookup(R.cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset, R.count);
-    if (R.cusparse && R.cfg.periodRows == 0 && R.elementsCount >= 8) R.cfg.periodRows = spmv_period(R.cusparse, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset);
+    if (R.cusparse && R.elementsCount >= 8) R.cfg.periodRows = spmv_period(R.cusparse, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.cfg.maxRow);
     CgScalars* sc = R.ws->scalars;
     double* pLoc = R.p + R.offset;
     if (R.rule == MGCG_RULE_SIMPLE) launch_fill(s, R.x, 0.0, R.nLocal);             // SimpleConjugateGradient.cu:53
@@ -522,7 +522,7 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     bool ok = true;
     if (R.nranks > 1) { R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, R.columnIndeces, R.elementsCount); ok = R.halo != nullptr && cg_plan_overlap(R); }
     R.dcsr = dcsr_lookup(cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset, R.count);
-    if (R.cfg.periodRows == 0 && R.elementsCount >= 8) R.cfg.periodRows = spmv_period(cusparse, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset);
+    if (R.elementsCount >= 8) R.cfg.periodRows = spmv_period(cusparse, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.cfg.maxRow);
     if (ok && restart) ok = cg_enqueue_init(R);
     else if (ok) hipLaunchKernelGGL(clear_done_kernel, dim3(1), dim3(1), 0, R.ws->stream, R.ws->scalars);
     for (int k = 0; ok && k < steps; ++k) ok = cg_enqueue_iteration(R, false);
@@ -659,6 +659,7 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
         }
         if (ok) L.dcsr = dcsr_lookup(cusparse, L.elements, L.rowOffsets, L.columnIndeces, L.n, L.nnz, L.offset);
         L.cfg = mg->cfg;
+        if (ok && L.nnz >= 8) (void)spmv_period(cusparse, L.rowOffsets, L.columnIndeces, L.n, L.offset, &L.cfg.maxRow);   // longest row of the level (7 on every Galerkin level of a 7-point operator)
         L.cfg.periodRows = (L.nz > 1) ? L.nx * L.ny : 0;       // far band of a 3-D stencil = one grid plane (used only if the caller switched the banded schedule on)
         if (ok && nranks > 1) {
             int init[2] = { 0x7fffffff, (int)0x80000000 }, out[2] = { 0, -1 };
