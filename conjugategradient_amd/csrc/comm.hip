@@ -465,19 +465,24 @@ int MgcgCommGetUniqueId(void* id128)
 
 MgcgComm* MgcgCommInitRank(const void* id128, int nranks, int rank)
 {
-    DeviceState* d = device_state();
-    if (!d) return nullptr;
     if (nranks < 1 || rank < 0 || rank >= nranks) { set_error("MgcgCommInitRank: bad rank %d of %d", rank, nranks); return nullptr; }
+    // ncclCommInitRank comes first: before this rank creates its stream or allocates anything (only the device is selected)
+    if (!select_device_only()) return nullptr;
     MgcgComm* c = new MgcgComm();
-    c->nranks = nranks; c->rank = rank; c->stream = d->stream;
-    if (!MGCG_HIP(hipMalloc((void**)&c->scratch, 8 * sizeof(double)))) { delete c; return nullptr; }
+    c->nranks = nranks; c->rank = rank;
     if (nranks > 1 || id128 != nullptr) {          // a unique id with nranks == 1 builds a real one-rank communicator
         Rccl* r = rccl();
-        if (!r || !id128) { if (r) set_error("MgcgCommInitRank: null unique id"); (void)hipFree(c->scratch); delete c; return nullptr; }
+        if (!r || !id128) { if (r) set_error("MgcgCommInitRank: null unique id"); delete c; return nullptr; }
         NcclUniqueId id;
         memcpy(&id, id128, sizeof(id));
-        if (!nccl_ok(r->CommInitRank(&c->comm, nranks, id, rank), "ncclCommInitRank")) { (void)hipFree(c->scratch); delete c; return nullptr; }
+        if (!nccl_ok(r->CommInitRank(&c->comm, nranks, id, rank), "ncclCommInitRank")) { delete c; return nullptr; }
     }
+    DeviceState* d = device_state();
+    if (!d || !MGCG_HIP(hipMalloc((void**)&c->scratch, 8 * sizeof(double)))) {
+        if (c->comm) { Rccl* r = rccl(); if (r && r->CommDestroy) (void)r->CommDestroy(c->comm); }
+        delete c; return nullptr;
+    }
+    c->stream = d->stream;
     return c;
 }
 

@@ -45,6 +45,7 @@ struct DeviceState {
 };
 DeviceState* device_state();   // for the calling thread's current device (lazily created)
 int current_device();
+bool select_device_only();       // hipSetDevice for the calling thread's device; creates nothing
 
 // Device scalars of one CG run (lives in the handle's workspace).
 struct CgScalars {
@@ -82,6 +83,7 @@ struct Workspace {
     CgScalars* scalars = nullptr;    // device
     HostMirror* mirror = nullptr;    // pinned host, device-visible
     double* hostScalar = nullptr;    // pinned host, 4 doubles (Dot results)
+    int* devInts = nullptr;          // device, 4 ints (small integer results: far band, longest row)
     double* trace = nullptr;         // device residual trace
     int traceCap = 0;
     bool init();

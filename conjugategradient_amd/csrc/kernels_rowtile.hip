@@ -208,7 +208,13 @@ __global__ __launch_bounds__(kBlock) void matrix_shape_kernel(const int* __restr
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < rows; i += stride) { const int len = rowOffsets[i + 1] - rowOffsets[i]; longest = len > longest ? len : longest; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_down(longest, off, 64); longest = o > longest ? o : longest; }
-    if ((threadIdx.x & 63) == 0 && longest > 0) atomicMax(&out[1], longest);
+    __shared__ int s_max[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = longest;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) longest = s_max[w] > longest ? s_max[w] : longest;
+        if (longest > 0) atomicMax(&out[1], longest);          // one atomic per workgroup, device memory
+    }
 }
 void launch_matrix_shape(hipStream_t s, const int* rowOffsets, const int* columnIndeces, long long rows, long long row, long long rowBase, int* out2)
 {

@@ -48,6 +48,14 @@ static DeviceState g_dev[kMaxDevices];
 
 int current_device() { return t_device; }
 
+// hipSetDevice for the calling thread's (virtual) device and nothing else: no stream, no allocation
+bool select_device_only()
+{
+    const int phys = physical_count();
+    if (phys <= 0) { set_error("no HIP device available (hipGetDeviceCount = %d): the HIP path cannot run", phys); return false; }
+    return MGCG_HIP(hipSetDevice(t_device % phys));
+}
+
 DeviceState* device_state()
 {
     const int phys = physical_count();
@@ -80,6 +88,7 @@ bool Workspace::init()
     if (!MGCG_HIP(hipHostMalloc((void**)&mirror, sizeof(HostMirror), hipHostMallocMapped))) return false;
     memset((void*)mirror, 0, sizeof(HostMirror));
     if (!MGCG_HIP(hipHostMalloc((void**)&hostScalar, sizeof(double) * 4, hipHostMallocMapped))) return false;
+    if (!MGCG_HIP(hipMalloc((void**)&devInts, sizeof(int) * 4))) return false;
     return true;
 }
 void Workspace::destroy()
@@ -89,8 +98,9 @@ void Workspace::destroy()
     if (scalars) (void)hipFree(scalars);
     if (mirror) (void)hipHostFree((void*)mirror);
     if (hostScalar) (void)hipHostFree(hostScalar);
+    if (devInts) (void)hipFree(devInts);
     if (trace) (void)hipFree(trace);
-    partials = nullptr; scalars = nullptr; mirror = nullptr; hostScalar = nullptr; trace = nullptr; traceCap = 0;
+    partials = nullptr; scalars = nullptr; mirror = nullptr; hostScalar = nullptr; devInts = nullptr; trace = nullptr; traceCap = 0;
 }
 bool Workspace::ensure_trace(int cap)
 {
@@ -182,10 +192,11 @@ int spmv_period(MgcgSparse* h, const int* rowOffsets, const int* columnIndeces, 
             return h->periodRows > 0 ? h->periodRows : e.period;
         }
     int period = 0, longest = 0;
-    int* slot = (int*)&h->ws.hostScalar[2];                 // pinned, device-visible: two ints
-    slot[0] = 0; slot[1] = 0;
-    launch_matrix_shape(h->ws.stream, rowOffsets, columnIndeces, rows, rows / 2, rowBase, slot);
-    if (MGCG_HIP(hipGetLastError()) && MGCG_HIP(hipStreamSynchronize(h->ws.stream))) { period = slot[0]; longest = slot[1]; }
+    int got[2] = { 0, 0 };
+    bool ok = MGCG_HIP(hipMemsetAsync(h->ws.devInts, 0, 2 * sizeof(int), h->ws.stream));
+    if (ok) launch_matrix_shape(h->ws.stream, rowOffsets, columnIndeces, rows, rows / 2, rowBase, h->ws.devInts);
+    ok = ok && MGCG_HIP(hipGetLastError()) && MGCG_HIP(hipMemcpyAsync(got, h->ws.devInts, sizeof(got), hipMemcpyDeviceToHost, h->ws.stream)) && MGCG_HIP(hipStreamSynchronize(h->ws.stream));
+    if (ok) { period = got[0]; longest = got[1]; }
     if (h->periods.size() >= 64) h->periods.clear();
     h->periods.push_back({ rowOffsets, columnIndeces, rows, rowBase, period, longest });
     if (maxRow) *maxRow = longest;
