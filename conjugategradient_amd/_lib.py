@@ -115,6 +115,7 @@ SIGNATURES = {
     "CgSteps": (_d, [_vp] * 11 + [_i, _i, _i, _i, _i, _i, _i, _i]),
     "MgcgLastOverlap": (_i, [_vp]),
     "MgcgLastHalo": (_i, [_vp]),
+    "MgcgDebugTileOrder": (_i, [_ll, _i, _i, _i, _vp, _i]),
     "MgcgCommInitCallbacks": (_vp, [_i, _i, _vp, _vp, _vp, _vp]),
     "MgcgEstimateSpectrum": (_i, [_vp] * 5 + [_i, _i, _i, _i, C.c_uint, _vp, _vp, _vp, _vp]),
 }

@@ -216,6 +216,10 @@ inline int spmv_auto_kernel(double avgRow)
     return 7;
 }
 
+// Order in which a lane = row kernel walks its tiles of `tileRows` rows (kernels_rowtile.hip explains the modes).
+struct TileMap { int mode; int tilesPerPlane; int nPlanes; int per; };
+TileMap make_tile_map(long long rows, int periodRows, int nWG, int tileRows);
+
 struct SpmvConfig { int kernel = 0; int rowsPerBlock = 64; int flags = 0; int gridBlocks = 0; int periodRows = 0; int tileRows = 0; int tilePlanes = 0;
                     int maxRow = 0; /* longest row if known (row-tile kernel: 7 gathers per row when <= 7), 0 = unknown */ };
 
@@ -230,7 +234,7 @@ int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int peri
 int spmv_period(MgcgSparse* h, const int* rowOffsets, const int* columnIndeces, long long rows, long long rowBase, int* maxRow = nullptr);
 void launch_matrix_shape(hipStream_t s, const int* rowOffsets, const int* columnIndeces, long long rows, long long row, long long rowBase, int* out2);
 // The same on the dictionary-compressed form of the matrix (a.elements / a.columnIndeces still serve array tails and long rows).
-int launch_spmv_rows(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView* m, int gridReq);   // m == nullptr: plain CSR
+int launch_spmv_rows(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView* m, int gridReq, int periodRows = 0);   // m == nullptr: plain CSR; periodRows: z sweep of the row-pattern kernel
 bool dcsr_build(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces,
                 long long rows, long long nnz, long long rowBase, DcsrMatrix* out);
 // Row-pattern form: usable (out->patternId != nullptr) when the matrix has <= 256 distinct rows-as-sequences.

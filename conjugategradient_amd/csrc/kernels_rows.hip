@@ -242,7 +242,7 @@ static int launch_rows_epi(hipStream_t s, const SpmvArgs& a, const DcsrView* m, 
 // Eight gathers per row are issued back to back before the first product is needed; products are added in stored order
 // (masked slots add +0.0, which leaves the sum's bits alone), so the result equals the CSR kernels' bit for bit.
 template <int EPI, int CH>
-__global__ __launch_bounds__(64) void spmv_pattern_kernel(SpmvArgs a, DcsrView m, int nRowBlocks, int groupBlocks)
+__global__ __launch_bounds__(64) void spmv_pattern_kernel(SpmvArgs a, DcsrView m, int nRowBlocks, int groupBlocks, TileMap tm)
 {
     constexpr int RPL = 2;                                        // rows per lane per trip (rows r and r + 64)
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -274,15 +274,20 @@ __global__ __launch_bounds__(64) void spmv_pattern_kernel(SpmvArgs a, DcsrView m
 #pragma unroll
         for (int u = 0; u < RPL; ++u) { long long r = base + u * 64 + tid; r = r <= lastRow ? r : lastRow; r = r >= 0 ? r : 0; pid[u] = m.patternId[r]; }
     };
+    // tm.mode != 0: the z sweep of the row-tile kernel (kernels_rowtile.hip) with tiles of 128 rows -- one contiguous run of row blocks
+    // per trip for the whole chip, XCD k its k-th eighth, plane after plane: x comes from beyond L2 ~1.1 times instead of 2.5
+    const bool sweep = tm.mode != 0;
+    const long long nTrips = sweep ? tile_map_trips(tm, (int)blockIdx.x, (int)gridDim.x, nRowBlocks) : (count > first ? (count - first + step - 1) / step : 0);
+    auto trip_block = [&](long long t) -> long long { return sweep ? (long long)tile_map_tile(tm, (int)t, (int)blockIdx.x, (int)gridDim.x) : block_of(first + t * step); };
     double dotacc = 0.0;
     int pidNext[RPL];
-    if (first < count) load_ids(block_of(first) < nRowBlocks ? block_of(first) : 0, pidNext);
-    for (long long L = first; L < count; L += step) {
-        const long long rb = block_of(L);
+    if (nTrips > 0) load_ids(trip_block(0) < nRowBlocks ? trip_block(0) : 0, pidNext);
+    for (long long t = 0; t < nTrips; ++t) {
+        const long long rb = trip_block(t);
         int pid[RPL];
 #pragma unroll
         for (int u = 0; u < RPL; ++u) pid[u] = pidNext[u];
-        if (L + step < count) { const long long nb = block_of(L + step); load_ids(nb < nRowBlocks ? nb : 0, pidNext); }   // ids of the next trip, in flight behind the gathers
+        if (t + 1 < nTrips) { const long long nb = trip_block(t + 1); load_ids(nb < nRowBlocks ? nb : 0, pidNext); }   // ids of the next trip, in flight behind the gathers
         if (rb >= nRowBlocks) continue;                            // wave-uniform (tail of the grouped enumeration)
         const long long base = rb * (64 * RPL);
         long long row[RPL]; bool live[RPL]; int tb[RPL], cnt[RPL]; double acc[RPL]; RowsEpi eo[RPL];
@@ -379,7 +384,7 @@ static int pattern_waves_per_cu()
 }
 
 template <int EPI>
-static int launch_pattern_epi(hipStream_t s, const SpmvArgs& a, const DcsrView& m, int gridReq)
+static int launch_pattern_epi(hipStream_t s, const SpmvArgs& a, const DcsrView& m, int gridReq, int periodRows)
 {
     const int nRowBlocks = (int)(((long long)a.rowCount + 127) / 128);
     DeviceState* d = device_state();
@@ -389,31 +394,33 @@ static int launch_pattern_epi(hipStream_t s, const SpmvArgs& a, const DcsrView& 
     if (grid < 1) grid = 1;
     const size_t lds = (size_t)m.nPattern * m.patWidth * 12 + (size_t)m.nPattern * 4;
     const int group = (grid % 8 == 0 && nRowBlocks >= 64 * 8) ? pattern_group_blocks() : 0;
+    static const bool noSweep = getenv("MGCG_NO_ZSWEEP") != nullptr;
+    TileMap tm = make_tile_map(a.rowCount, (noSweep || group > 0 || a.rowCount % 128 != 0) ? 0 : periodRows, grid, 128);
     // slots per pass = the longest row when it is 5 or 7 (the 2-D / 3-D stencils), else 8
-    if (m.patWidth == 7) hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 7>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks, group);
-    else if (m.patWidth == 5) hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 5>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks, group);
-    else hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 8>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks, group);
+    if (m.patWidth == 7) hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 7>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks, group, tm);
+    else if (m.patWidth == 5) hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 5>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks, group, tm);
+    else hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 8>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks, group, tm);
     return grid;
 }
 
-static int launch_spmv_pattern(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView& m, int gridReq)
+static int launch_spmv_pattern(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView& m, int gridReq, int periodRows)
 {
     switch (epilogue) {
-    case EPI_AXPBY:        return a.beta != 0.0 ? launch_pattern_epi<EPI_AXPBY_BETA>(s, a, m, gridReq) : launch_pattern_epi<EPI_AXPBY>(s, a, m, gridReq);
-    case EPI_DOT:          return launch_pattern_epi<EPI_DOT>(s, a, m, gridReq);
-    case EPI_RESIDUAL:     return launch_pattern_epi<EPI_RESIDUAL>(s, a, m, gridReq);
-    case EPI_RESIDUAL_DOT: return launch_pattern_epi<EPI_RESIDUAL_DOT>(s, a, m, gridReq);
-    case EPI_JACOBI:       return launch_pattern_epi<EPI_JACOBI>(s, a, m, gridReq);
-    case EPI_JACOBI_DOT:   return launch_pattern_epi<EPI_JACOBI_DOT>(s, a, m, gridReq);
+    case EPI_AXPBY:        return a.beta != 0.0 ? launch_pattern_epi<EPI_AXPBY_BETA>(s, a, m, gridReq, periodRows) : launch_pattern_epi<EPI_AXPBY>(s, a, m, gridReq, periodRows);
+    case EPI_DOT:          return launch_pattern_epi<EPI_DOT>(s, a, m, gridReq, periodRows);
+    case EPI_RESIDUAL:     return launch_pattern_epi<EPI_RESIDUAL>(s, a, m, gridReq, periodRows);
+    case EPI_RESIDUAL_DOT: return launch_pattern_epi<EPI_RESIDUAL_DOT>(s, a, m, gridReq, periodRows);
+    case EPI_JACOBI:       return launch_pattern_epi<EPI_JACOBI>(s, a, m, gridReq, periodRows);
+    case EPI_JACOBI_DOT:   return launch_pattern_epi<EPI_JACOBI_DOT>(s, a, m, gridReq, periodRows);
     }
     return 0;
 }
 
 // m == nullptr: plain CSR.  Requires 16-byte aligned elements, 8-byte aligned columnIndeces and elementsCount >= 8.
-int launch_spmv_rows(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView* m, int gridReq)
+int launch_spmv_rows(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView* m, int gridReq, int periodRows)
 {
     if (a.rowCount <= 0) return 0;
-    if (m != nullptr && m->patternId != nullptr) return launch_spmv_pattern(s, epilogue, a, *m, gridReq);
+    if (m != nullptr && m->patternId != nullptr) return launch_spmv_pattern(s, epilogue, a, *m, gridReq, periodRows);
     switch (epilogue) {
     case EPI_AXPBY:        return a.beta != 0.0 ? launch_rows_epi<EPI_AXPBY_BETA>(s, a, m, gridReq) : launch_rows_epi<EPI_AXPBY>(s, a, m, gridReq);
     case EPI_DOT:          return launch_rows_epi<EPI_DOT>(s, a, m, gridReq);

@@ -45,7 +45,7 @@ constexpr int kTCap = 512;          // nonzeros a wavefront stages per trip
 // Either way the +-line and +-plane neighbours of a row are multiplied on the same XCD in the same or the adjacent trip (x is
 // fetched from beyond L2 ~1.1 times instead of 4.7), and what the whole chip streams during a trip is contiguous in memory.
 // (A variant in which the eight XCDs read eight separate runs per trip measured 6 % slower: profiles/r2/spmv_sweep_rows_vs_rowtile_disjoint_runs.log.)
-struct TileMap { int mode; int tilesPerPlane; int nPlanes; int per; };
+// (struct TileMap: common.hpp; tile_map_trips / tile_map_tile: spmv_epilogue.hpp; make_tile_map below)
 
 template <int EPI>
 __device__ __forceinline__ RowsEpi tile_epi_prefetch(const SpmvArgs& a, int row)
@@ -81,12 +81,7 @@ __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, Tile
     const int kMax2 = (a.elementsCount - 2) & ~1;
 
     // ---- the trips of this workgroup (workgroup-uniform, scalar)
-    const int perXcd = nWG >> 3, xcd = wg & 7, slot = wg >> 3;
-    const int eighth = tm.tilesPerPlane >> 3;                      // mode 2: tiles of one plane per XCD
-    int nTrips;
-    if (tm.mode == 0) nTrips = nTiles > wg ? (nTiles - wg + nWG - 1) / nWG : 0;
-    else if (tm.mode == 1) nTrips = tm.per * tm.nPlanes;
-    else { const int sub = slot / eighth; nTrips = tm.nPlanes > sub ? (tm.nPlanes - sub + tm.per - 1) / tm.per : 0; }
+    const int nTrips = tile_map_trips(tm, wg, nWG, nTiles);
     double dot = 0.0;
     auto finish = [&]() {
         // rows behind the last full tile: workgroup 0, one row per thread, straight from global memory
@@ -106,10 +101,7 @@ __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, Tile
     if (nTrips <= 0) { finish(); return; }                         // (workgroup-uniform)
     auto tile_of = [&](int t) -> int {
         t = t < nTrips ? t : nTrips - 1;                           // past the end: the last tile again (loads only, results unused)
-        if (tm.mode == 0) return wg + nWG * t;
-        if (tm.mode == 1) { const int h = t / tm.nPlanes, p = t - h * tm.nPlanes; return p * tm.tilesPerPlane + h * nWG + xcd * perXcd + slot; }
-        const int sub = slot / eighth, j = slot - sub * eighth;
-        return (t * tm.per + sub) * tm.tilesPerPlane + xcd * eighth + j;
+        return tile_map_tile(tm, t, wg, nWG);
     };
 
     // ---- per-trip pieces
@@ -225,13 +217,13 @@ void launch_matrix_shape(hipStream_t s, const int* rowOffsets, const int* column
 }
 
 // Tile order for a matrix of `rows` rows whose far band lies periodRows rows from the diagonal (0: unknown).
-static TileMap make_tile_map(long long rows, int periodRows, int nWG)
+TileMap make_tile_map(long long rows, int periodRows, int nWG, int tileRows)
 {
     TileMap tm{};
     tm.mode = 0;
     if (periodRows <= 0 || (nWG & 7) != 0 || nWG < 8) return tm;
-    if (periodRows % (kTRows * 8) != 0 || rows % periodRows != 0) return tm;
-    const int tilesPerPlane = periodRows / kTRows;
+    if (tileRows <= 0 || periodRows % (tileRows * 8) != 0 || rows % periodRows != 0) return tm;
+    const int tilesPerPlane = periodRows / tileRows;
     const long long nPlanes = rows / periodRows;
     if (nPlanes < 3 || nPlanes > 65535) return tm;
     tm.tilesPerPlane = tilesPerPlane; tm.nPlanes = (int)nPlanes;
@@ -251,7 +243,7 @@ static int launch_rowtile_epi(hipStream_t s, const SpmvArgs& a, int periodRows, 
     if (nWG > nTiles) nWG = nTiles;
     if (nWG < 1) nWG = 1;
     static const bool noSweep = getenv("MGCG_NO_ZSWEEP") != nullptr;
-    const TileMap tm = make_tile_map(a.rowCount, noSweep ? 0 : periodRows, nWG);
+    const TileMap tm = make_tile_map(a.rowCount, noSweep ? 0 : periodRows, nWG, kTRows);
     if (maxRow > 0 && maxRow <= 7) hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 7>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
     else hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 8>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
     return nWG * kTW;
@@ -273,3 +265,18 @@ int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int peri
 }
 
 } // namespace mgcg
+
+// Host-side view of the tile order (no device needed): the tile every workgroup takes in every trip, for tests of the enumeration.
+// tiles[wg * maxTrips + t] = tile index or -1; returns the TileMap mode (0 memory order, 1 / 2 z sweep), or -1 on bad arguments.
+extern "C" int MgcgDebugTileOrder(long long rows, int periodRows, int workgroups, int tileRows, int* tiles, int maxTrips)
+{
+    if (rows < 0 || workgroups < 1 || tileRows < 1 || maxTrips < 1 || !tiles) return -1;
+    const mgcg::TileMap tm = mgcg::make_tile_map(rows, periodRows, workgroups, tileRows);
+    const int nTiles = (int)(rows / tileRows);
+    for (int wg = 0; wg < workgroups; ++wg) {
+        const int n = mgcg::tile_map_trips(tm, wg, workgroups, nTiles);
+        if (n > maxTrips) return -1;
+        for (int t = 0; t < maxTrips; ++t) tiles[(long long)wg * maxTrips + t] = t < n ? mgcg::tile_map_tile(tm, t, wg, workgroups) : -1;
+    }
+    return tm.mode;
+}

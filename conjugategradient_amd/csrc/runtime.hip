@@ -207,7 +207,7 @@ int launch_spmv_auto(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvC
 {
     if (dc != nullptr && dc->usable && a.elementsCount >= 8) {
         const DcsrView v = dc->view();
-        if (v.tileVals == nullptr) return launch_spmv_rows(s, epilogue, a, &v, cfg.gridBlocks);
+        if (v.tileVals == nullptr) return launch_spmv_rows(s, epilogue, a, &v, cfg.gridBlocks, cfg.periodRows);
         if (!(epilogue == EPI_AXPBY && a.beta != 0.0)) return launch_spmv_tiled(s, epilogue, a, v);   // (beta != 0 reads y: CSR kernels)
     }
     return launch_spmv(s, epilogue, a, cfg);
@@ -238,7 +238,7 @@ int launch_spmv_range(hipStream_t s, int epilogue, const SpmvArgs& whole, const 
             if (c.kernel == 0) c.kernel = spmv_auto_kernel(whole.rowCount > 0 ? (double)whole.elementsCount / (double)whole.rowCount : 0.0);
             return launch_spmv(s, epilogue, a, c);
         }
-        return launch_spmv_rows(s, epilogue, a, &v, c.gridBlocks);
+        return launch_spmv_rows(s, epilogue, a, &v, c.gridBlocks, c.periodRows);
     }
     if (c.kernel == 0) {                                 // the kernel choice follows the whole matrix, not the slice
         c.kernel = spmv_auto_kernel(whole.rowCount > 0 ? (double)whole.elementsCount / (double)whole.rowCount : 0.0);

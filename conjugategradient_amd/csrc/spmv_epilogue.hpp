@@ -33,4 +33,21 @@ __device__ __forceinline__ double rows_epilogue_value(const SpmvArgs& a, double 
     }
 }
 
+// ---- tile order (TileMap, common.hpp): trips of workgroup `wg` of `nWG`, and the tile of its t-th trip
+__host__ __device__ __forceinline__ int tile_map_trips(const TileMap& tm, int wg, int nWG, int nTiles)
+{
+    if (tm.mode == 0) return nTiles > wg ? (nTiles - wg + nWG - 1) / nWG : 0;
+    if (tm.mode == 1) return tm.per * tm.nPlanes;
+    const int eighth = tm.tilesPerPlane >> 3, sub = (wg >> 3) / eighth;
+    return tm.nPlanes > sub ? (tm.nPlanes - sub + tm.per - 1) / tm.per : 0;
+}
+__host__ __device__ __forceinline__ int tile_map_tile(const TileMap& tm, int t, int wg, int nWG)
+{
+    if (tm.mode == 0) return wg + nWG * t;
+    const int xcd = wg & 7, slot = wg >> 3;
+    if (tm.mode == 1) { const int h = t / tm.nPlanes, p = t - h * tm.nPlanes; return p * tm.tilesPerPlane + h * nWG + xcd * (nWG >> 3) + slot; }
+    const int eighth = tm.tilesPerPlane >> 3, sub = slot / eighth, j = slot - sub * eighth;
+    return (t * tm.per + sub) * tm.tilesPerPlane + xcd * eighth + j;
+}
+
 } // namespace mgcg

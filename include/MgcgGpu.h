@@ -380,6 +380,10 @@ int MgcgLastOverlap(long long interior[2]);
  * the reference's [minJ, offset) and [offset + count, maxJ]: Mgcg.cu:83-84, ConjugateGradientParallelGpu.cs:397-398);
  * volume[0] = entries this rank received per exchange, volume[1] = entries the contiguous ranges would have received. */
 int MgcgLastHalo(long long volume[2]);
+/* Test hook (no device needed): the order in which the lane = row SpMV kernels walk their tiles of `tileRows` rows with
+ * `workgroups` workgroups when the far band of the matrix lies `periodRows` rows from the diagonal (0: unknown).
+ * tiles[wg * maxTrips + t] = tile of workgroup wg in trip t, or -1; returns 0 (memory order), 1 / 2 (z sweep), -1 (bad arguments). */
+int MgcgDebugTileOrder(long long rows, int periodRows, int workgroups, int tileRows, int* tiles, int maxTrips);
 
 #ifdef __cplusplus
 }

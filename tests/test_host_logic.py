@@ -92,3 +92,53 @@ def test_problem_generators_shapes():
     off = np.asarray(abs(A).sum(axis=1)).ravel() - abs(d)
     assert np.all(d > off)                                        # strictly diagonally dominant => SPD
     np.testing.assert_allclose(A @ np.ones(2000), r.b)
+
+
+@pytest.mark.parametrize("rows,period,wgs,tile_rows,expect_mode", [
+    (512**3, 512 * 512, 512, 256, 1),        # BASELINE config 2/3: two half-plane slices, swept through 512 planes
+    (512 * 512 * 64, 512 * 512, 512, 256, 1),    # one rank's slab of config 4
+    (256**3, 256 * 256, 512, 256, 2),        # a plane is smaller than the grid: two planes per trip
+    (128**3, 128 * 128, 512, 256, 2),        # eight planes per trip
+    (128 * 128 * 13, 128 * 128, 512, 256, 2),    # planes not a multiple of the planes per trip: ragged last trip
+    (512**3, 512 * 512, 4096, 128, 2),       # the row-pattern kernel's shape (tiles of 128 rows, 16 wavefronts per CU)
+    (384**3, 384 * 384, 512, 256, 0),        # 576 tiles per plane do not split over 512 workgroups: memory order
+    (512**3, 640, 512, 256, 0),              # a period the kernel cannot use
+    (100000, 0, 512, 256, 0),                # unknown period, ragged tail (full tiles only)
+    (256 * 256 * 2, 256 * 256, 512, 256, 0),     # fewer than 3 planes
+])
+def test_tile_order_visits_every_tile_once(rows, period, wgs, tile_rows, expect_mode):
+    """The z sweep of the lane = row SpMV kernels is a permutation of the tiles: every full tile exactly once, whatever the
+    mode (a skipped or doubled tile would be a wrong or racy product); in sweep modes every trip of the whole grid covers one
+    contiguous run of tiles and XCD k = workgroup % 8 owns the k-th eighth of every such run (one run per plane in mode 2,
+    one per slice of the plane in mode 1)."""
+    import ctypes as C
+
+    from conjugategradient_amd import _lib
+
+    L = _lib.lib()
+    n_tiles = rows // tile_rows
+    max_trips = -(-n_tiles // wgs) + 8
+    buf = np.full(wgs * max_trips, -2, dtype=np.int32)
+    mode = L.MgcgDebugTileOrder(rows, period, wgs, tile_rows, buf.ctypes.data_as(C.c_void_p), max_trips)
+    assert mode == expect_mode
+    order = buf.reshape(wgs, max_trips)
+    seen = order[order >= 0]
+    assert seen.size == n_tiles and np.array_equal(np.sort(seen), np.arange(n_tiles))
+    for wg in range(wgs):                                  # trips of a workgroup are a prefix: no holes
+        valid = order[wg] >= 0
+        assert not np.any(valid[1:] & ~valid[:-1])
+    if mode != 0:
+        per_plane = period // tile_rows
+        for t in range(max_trips):
+            col = order[:, t]
+            col = col[col >= 0]
+            if col.size == 0:
+                continue
+            assert col.max() - col.min() + 1 == col.size       # one contiguous run for the whole chip
+        slices = per_plane // wgs if mode == 1 else 1
+        for k in range(8):                                     # an XCD's tiles of a plane: an eighth, in `slices` contiguous runs
+            mine = order[k::8]
+            mine = mine[mine >= 0]
+            in_plane = np.unique(mine % per_plane)
+            assert in_plane.size == per_plane // 8
+            assert int(np.count_nonzero(np.diff(in_plane) != 1)) + 1 == slices
