@@ -633,6 +633,91 @@ __global__ __launch_bounds__(256) void v5_rows(Args a, const long long* __restri
     if (tid == 0) a.partials[blockIdx.x * WPB + wv] = dot;
 }
 
+// ------------------------------------------------------------------ V6: as V4 (results of up to B trips parked in LDS) but the flush is keyed to the
+// chip-wide 100 MHz clock (s_memrealtime): every workgroup flushes at its first trip boundary after the clock crosses a multiple of
+// `period` ticks -- write bursts of the whole chip without any communication.  A flush always stores all B slots (static count:
+// counted waits); slots not refilled since the last flush are stored again with the same values.
+template <int NG, int B>
+__global__ __launch_bounds__(256) void v6_rows(Args a, int map, int planeBlocks, int period)
+{
+    constexpr int WPB = 4, CAP = 512;
+    __shared__ __attribute__((aligned(16))) int s_colAll[CAP * WPB];
+    __shared__ __attribute__((aligned(16))) double s_valAll[CAP * WPB];
+    __shared__ double s_pendAll[B * 64 * WPB];
+    __shared__ int s_prowAll[B * WPB];
+    const int tid = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int* s_col = s_colAll + wv * CAP; double* s_val = s_valAll + wv * CAP;
+    double* s_pend = s_pendAll + wv * B * 64; int* s_prow = s_prowAll + wv * B;
+    const int nB = a.nBlocks;
+    const int kMax4 = (a.nnz - 4) & ~3, kMax2 = (a.nnz - 2) & ~1;
+    const int wg = blockIdx.x, WG = gridDim.x;
+    const int nTrips = nB / (WG * WPB);
+    auto block_of = [&](int t) -> int {
+        t = t < nTrips ? t : nTrips - 1;
+        if (map == 5) { const int T = planeBlocks / WPB, nzp = nB / planeBlocks; const int h = t / nzp, pz = t - h * nzp; return (pz * T + h * WG + (wg & 7) * (WG >> 3) + (wg >> 3)) * WPB + wv; }
+        return (wg + WG * t) * WPB + wv;
+    };
+    int roA_s, roA_e, roB_s, roB_e;
+    i4 c0, c1; d2 v0, v1, v2, v3;
+    auto load_ro = [&](int b, int& rs, int& re) { const int r = b * 64 + tid; rs = a.ro[r]; re = a.ro[r + 1]; };
+    auto raw = [&](int s) {
+        const int tb = s & ~3;
+        int k0 = tb + 4 * tid, k1 = k0 + 256; k0 = k0 < kMax4 ? k0 : kMax4; k1 = k1 < kMax4 ? k1 : kMax4;
+        c0 = *(const i4*)(a.col + k0); c1 = *(const i4*)(a.col + k1);
+        int j0 = tb + 2 * tid, j1 = j0 + 128, j2 = j0 + 256, j3 = j0 + 384;
+        j0 = j0 < kMax2 ? j0 : kMax2; j1 = j1 < kMax2 ? j1 : kMax2; j2 = j2 < kMax2 ? j2 : kMax2; j3 = j3 < kMax2 ? j3 : kMax2;
+        v0 = *(const d2*)(a.val + j0); v1 = *(const d2*)(a.val + j1); v2 = *(const d2*)(a.val + j2); v3 = *(const d2*)(a.val + j3);
+    };
+    int bCur = block_of(0), bNext = block_of(1);
+    load_ro(bCur, roA_s, roA_e);
+    raw(__builtin_amdgcn_readfirstlane(roA_s));
+    load_ro(bNext, roB_s, roB_e);
+    // every slot starts as "row of my first block, value 0": a harmless store until the slot is filled
+    for (int q = 0; q < B; ++q) { s_pend[q * 64 + tid] = 0.0; if (tid == 0) s_prow[q] = bCur * 64; }
+    double dot = 0.0;
+    int nbuf = 0;
+    unsigned long long epoch = __builtin_amdgcn_s_memrealtime() / (unsigned)period;
+    for (int t = 0; t < nTrips; ++t) {
+        const int tb = __builtin_amdgcn_readfirstlane(roA_s) & ~3;
+        const int my_s = roA_s, cnt = roA_e - roA_s;
+        *(i4*)(s_col + 4 * tid) = c0; *(i4*)(s_col + 256 + 4 * tid) = c1;
+        *(d2*)(s_val + 2 * tid) = v0; *(d2*)(s_val + 128 + 2 * tid) = v1; *(d2*)(s_val + 256 + 2 * tid) = v2; *(d2*)(s_val + 384 + 2 * tid) = v3;
+        __syncthreads();
+        const int row = bCur * 64 + tid;
+        int cc[NG]; double vv[NG], xg[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) { int idx = my_s - tb + j; idx = j < cnt ? idx : 0; cc[j] = s_col[idx & 511]; vv[j] = s_val[idx & 511]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NG; ++j) xg[j] = a.x[cc[j]];
+        const double w = a.w[row];
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime() / (unsigned)period;
+        const bool flush = (nbuf == B) || (now != epoch && nbuf >= B / 2);        // wavefront-uniform (workgroup-nearly-uniform: each wave decides alone)
+        if (flush) {
+#pragma unroll
+            for (int q = 0; q < B; ++q) __builtin_nontemporal_store(s_pend[q * 64 + tid], a.y + s_prow[q] + tid);
+            nbuf = 0; epoch = now;
+        }
+        raw(__builtin_amdgcn_readfirstlane(roB_s));
+        roA_s = roB_s; roA_e = roB_e;
+        const int bAfter = block_of(t + 2);
+        load_ro(bAfter, roB_s, roB_e);
+        __builtin_amdgcn_sched_barrier(0);
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) { const double p = vv[j] * xg[j]; acc += (j < cnt) ? p : 0.0; }
+        dot += w * acc;
+        s_pend[nbuf * 64 + tid] = acc; if (tid == 0) s_prow[nbuf] = bCur * 64;
+        ++nbuf;
+        __syncthreads();
+        bCur = bNext; bNext = bAfter;
+    }
+    for (int q = 0; q < B; ++q) __builtin_nontemporal_store(s_pend[q * 64 + tid], a.y + s_prow[q] + tid);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dot += __shfl_down(dot, off, 64);
+    if (tid == 0) a.partials[blockIdx.x * WPB + wv] = dot;
+}
+
 template <typename F>
 static double time_ms(F f, int reps)
 {
@@ -831,6 +916,19 @@ int main(int argc, char** argv)
             { CK(hipMemset(d_y, 0xff, N * 8)); double ms = time_ms([&] { hipLaunchKernelGGL((v5_rows<7>), dim3(512), dim3(256), 0, 0, a, d_off, d_rec, 5, n * n / 64); }, reps); bool ok = check("v5"); report("block records, NG7, z sweep", 8, ms, ok); }
             { CK(hipMemset(d_y, 0xff, N * 8)); double ms = time_ms([&] { hipLaunchKernelGGL((v5_rows<8>), dim3(512), dim3(256), 0, 0, a, d_off, d_rec, 0, n * n / 64); }, reps); bool ok = check("v5"); report("block records, NG8, grid-stride", 8, ms, ok); }
             { CK(hipMemset(d_y, 0xff, N * 8)); double ms = time_ms([&] { hipLaunchKernelGGL((v5_rows<8>), dim3(1024), dim3(256), 0, 0, a, d_off, d_rec, 0, n * n / 64); }, reps); bool ok = check("v5"); report("block records, NG8, grid-stride", 16, ms, ok); }
+        }
+        return 0;
+    }
+    if (argc > 3 && !strcmp(argv[3], "clock")) {
+        wpcs = { 8 };
+        for (int rep = 0; rep < 2; ++rep) {
+            RUNV3(false, 5, 1, 1, 4, 5, "baseline (store every trip), NG8", true)
+            { CK(hipMemset(d_y, 0xff, N * 8)); double ms = time_ms([&] { hipLaunchKernelGGL((v2_rows<false, 5, 1, 1, 4, 7>), dim3(512), dim3(256), 0, 0, a, 5, n * n / 64); }, reps); bool ok = check("b7"); report("baseline (store every trip), NG7", 8, ms, ok); }
+            for (int period : { 500, 1000, 2000, 4000, 100000000 }) {
+                char label[96];
+                { CK(hipMemset(d_y, 0xff, N * 8)); double ms = time_ms([&] { hipLaunchKernelGGL((v6_rows<7, 8>), dim3(512), dim3(256), 0, 0, a, 5, n * n / 64, period); }, reps); bool ok = check("v6"); snprintf(label, sizeof label, "clocked flush B8, period %d ticks", period); report(label, 8, ms, ok); }
+                { CK(hipMemset(d_y, 0xff, N * 8)); double ms = time_ms([&] { hipLaunchKernelGGL((v6_rows<7, 16>), dim3(512), dim3(256), 0, 0, a, 5, n * n / 64, period); }, reps); bool ok = check("v6"); snprintf(label, sizeof label, "clocked flush B16, period %d ticks", period); report(label, 8, ms, ok); }
+            }
         }
         return 0;
     }
