@@ -145,13 +145,19 @@ void launch_fill(hipStream_t s, double* y, double v, long long n)
 }
 
 // ------------------------------------------------------------------ dot partials
-template <bool V2>
+// NT: streaming loads for vectors far larger than the caches (a pure read stream gains 4-10 % from them on this chip,
+// profiles/r2/bw_probe.log; small vectors that the next kernel reads again keep the plain loads)
+template <bool V2, bool NT = false>
 __global__ __launch_bounds__(kBlock) void dot_kernel(const double* __restrict__ x, const double* __restrict__ y, long long n, double* __restrict__ partials)
 {
     __shared__ double s_red[4];
     double acc = 0.0;
     grid_stride<V2>(n,
-        [&](long long i) { d2 xv = *(const d2*)(x + i); d2 yv = *(const d2*)(y + i); double t0 = xv.x * yv.x; double t1 = xv.y * yv.y; acc += t0; acc += t1; },
+        [&](long long i) {
+            d2 xv, yv;
+            if constexpr (NT) { xv = __builtin_nontemporal_load((const d2*)(x + i)); yv = __builtin_nontemporal_load((const d2*)(y + i)); }
+            else { xv = *(const d2*)(x + i); yv = *(const d2*)(y + i); }
+            double t0 = xv.x * yv.x; double t1 = xv.y * yv.y; acc += t0; acc += t1; },
         [&](long long i) { double t = x[i] * y[i]; acc += t; });
     const double t = block_sum(acc, s_red);
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
@@ -160,8 +166,9 @@ int launch_dot_partials(hipStream_t s, const double* x, const double* y, long lo
 {
     const bool v2 = al16(x) && al16(y);
     const int grid = grid_for(n, v2 ? 4 : 2);
-    if (v2) hipLaunchKernelGGL(dot_kernel<true>, dim3(grid), dim3(kBlock), 0, s, x, y, n, partials);
-    else hipLaunchKernelGGL(dot_kernel<false>, dim3(grid), dim3(kBlock), 0, s, x, y, n, partials);
+    if (v2 && n >= (8LL << 20)) hipLaunchKernelGGL((dot_kernel<true, true>), dim3(grid), dim3(kBlock), 0, s, x, y, n, partials);
+    else if (v2) hipLaunchKernelGGL((dot_kernel<true, false>), dim3(grid), dim3(kBlock), 0, s, x, y, n, partials);
+    else hipLaunchKernelGGL((dot_kernel<false, false>), dim3(grid), dim3(kBlock), 0, s, x, y, n, partials);
     return grid;
 }
 
