@@ -124,6 +124,47 @@ def test_csrmv_rowtile_slow_blocks_and_ragged_ends(h, oracle):
         assert np.array_equal(got, ref), (M.shape, M.nnz)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_csrmv_rowtile_random_shapes(h, oracle, seed):
+    """Randomised shapes for the row-tile kernel: sizes around the tile and block boundaries, densities that mix the fast path
+    (rows <= 7 / 8, spans <= 512) with slow blocks, empty rows, unsorted columns, nnz of every residue mod 4; CsrMV and the
+    fused CsrMVDot against the oracle (product bit for bit, dot to summation order)."""
+    import scipy.sparse as sp
+    L = _lib.lib()
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([200, 256, 300, 511, 512, 1000, 4096, 5000, 33333]))
+    per_row = float(rng.choice([0.5, 2.0, 5.0, 7.0, 9.0]))
+    k = rng.poisson(per_row, size=n)                            # row lengths; duplicates are merged below
+    rows = np.repeat(np.arange(n), k)
+    M = sp.coo_matrix((rng.standard_normal(rows.size), (rows, rng.integers(0, n, size=rows.size))), shape=(n, n)).tocsr()
+    if seed % 3 == 0:
+        M = M + sp.eye(n, format="csr")
+    M = M.tocsr()
+    M.sum_duplicates()
+    M.sort_indices()
+    data, indices, indptr = M.data.astype(np.float64), M.indices.astype(np.int32), M.indptr.astype(np.int32)
+    if seed % 2 == 1:                                           # unsorted columns: reverse every row
+        for i in range(n):
+            data[indptr[i]:indptr[i + 1]] = data[indptr[i]:indptr[i + 1]][::-1]
+            indices[indptr[i]:indptr[i + 1]] = indices[indptr[i]:indptr[i + 1]][::-1]
+    sysm = problems.LinearSystem(data, indices, indptr, np.zeros(n), np.zeros(n), "rnd")
+    x, y0 = rng.standard_normal(n), rng.standard_normal(n)
+    ref = oracle.spmv(sysm.Elements, sysm.ColumnIndeces, sysm.RowOffsets, x)
+    A = DeviceCsr(sysm)
+    for grid in (0, 8, 64):
+        assert np.array_equal(A.spmv(h, x, kernel=10, tuning=(64, 0, grid)), ref), (n, per_row, grid)
+    assert np.array_equal(A.spmv(h, x, alpha=0.5, beta=-2.0, y0=y0, kernel=10), 0.5 * ref + (-2.0) * y0)
+    if sysm.nnz >= 8:
+        vx, vy = dvec(x), dvec(np.zeros(n))
+        L.MgcgSetSpmvKernel(h.sparse, 10)
+        got = L.CsrMVDot(h.blas, h.sparse, vy.ToRawPtr(), A.e.ToRawPtr(), A.r.ToRawPtr(), A.c.ToRawPtr(), vx.ToRawPtr(), vx.ToRawPtr(), sysm.nnz, n, n)
+        L.MgcgSetSpmvKernel(h.sparse, 0)
+        _lib.check("CsrMVDot")
+        assert np.array_equal(vy.to_numpy(n), ref)
+        want = float(np.dot(x, ref))
+        assert abs(got - want) <= 1e-12 * max(1.0, float(np.abs(x * ref).sum()))
+
+
 def test_csrmv_alpha_beta_and_edges(h, oracle):
     s = problems.poisson(9, 8, 7)
     rng = np.random.default_rng(11)
