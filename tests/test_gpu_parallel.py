@@ -92,7 +92,7 @@ def test_phased_ranks_share_the_gpu_over_gloo(oracle, tmp_path):
     assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
 
 
-@pytest.mark.parametrize("which", ["banded", "mgcg"])
+@pytest.mark.parametrize("which", ["banded", "mgcg", "unstructured"])
 def test_native_loop_over_the_callback_transport(oracle, tmp_path, which):
     """MgcgCommInitCallbacks: the native multi-rank loop with its all-gather / all-reduce / halo exchange carried by
     torch.distributed gloo on host memory (the fallback transport of bench.py); two processes share the GPU."""
@@ -107,6 +107,20 @@ def test_native_loop_over_the_callback_transport(oracle, tmp_path, which):
     if which == "banded":
         system = problems.mgcg_main(2400, 160)
         ref = oracle.cg_parallel(system, world, max_iteration=system.Count)
+    elif which == "unstructured":
+        import scipy.sparse as sp
+        n = 6000
+        rng = np.random.default_rng(5)
+        i = rng.choice(n, size=n // 3, replace=False)
+        j = rng.integers(0, n, size=i.size)
+        keep = i != j
+        U = sp.coo_matrix((-rng.random(int(keep.sum())), (i[keep], j[keep])), shape=(n, n)).tocsr()
+        A = (U + U.T).tocsr()
+        A = (A + sp.diags(1.0 + np.asarray(abs(A).sum(axis=1)).ravel())).tocsr()
+        A.sort_indices()
+        b = np.cos(np.arange(n) * 0.3) * (1.0 + np.arange(n) % 5)
+        system = problems.LinearSystem(A.data.astype(np.float64), A.indices.astype(np.int32), A.indptr.astype(np.int32), np.zeros(n), b, "sparse-unstructured")
+        ref = oracle.cg_parallel(system, world, max_iteration=system.Count)
     else:
         system = problems.poisson(16, 16, 16)
         system.b[:] = np.random.default_rng(3).standard_normal(system.Count)
@@ -116,6 +130,8 @@ def test_native_loop_over_the_callback_transport(oracle, tmp_path, which):
         d = np.load(tmp_path / f"rank{r}.npz")
         x[int(d["offset"]): int(d["offset"]) + int(d["count"])] = d["x"]
         assert int(d["iteration"]) == ref["iteration"]
+        if which == "unstructured":     # index lists travelled through the callbacks: fewer entries than the contiguous ranges
+            assert int(d["halo_lists"]) == 1 and 0 < int(d["halo_moved"]) * 2 <= int(d["halo_contiguous"])
     assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
 
 
