@@ -142,3 +142,28 @@ def test_tile_order_visits_every_tile_once(rows, period, wgs, tile_rows, expect_
             in_plane = np.unique(mine % per_plane)
             assert in_plane.size == per_plane // 8
             assert int(np.count_nonzero(np.diff(in_plane) != 1)) + 1 == slices
+
+
+def test_bench_vcycle_bytes_formula():
+    """bench.py's algorithmic-byte count of one MGCG iteration (per-pass formulas) -- the denominator of the
+    `mgcg.frac_of_peak` figure -- checked against a hand count on a tiny hierarchy and against the 512^3 figure DESIGN.md quotes."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    def nnz(m):
+        return 7 * m**3 - 6 * m * m
+
+    # two levels, V(1,1), 2 coarse sweeps on 8^3 -> 4^3
+    n, nc = 8, 4
+    N, Nc = n**3, nc**3
+    fine = 24 * N + (12 * nnz(n) + 28 * N) + 2 * (8 * N + 8 * Nc) + (12 * nnz(n) + 36 * N)     # first sweep, residual, R + P, post sweep
+    coarse = 24 * Nc + (12 * nnz(nc) + 36 * Nc)                                                  # first sweep + one more
+    shell = 12 * nnz(n) + 4 * (N + 1) + 16 * N + 72 * N
+    v, s = bench.vcycle_bytes(n, 2, 1, 2)
+    assert (v, s) == (fine + coarse, shell)
+    v, s = bench.vcycle_bytes(512, 3, 1, 4)
+    assert v == 42127196160 and v + s == 65730641924
