@@ -47,8 +47,9 @@ __device__ __forceinline__ double block_max(double v, double* s_red)
 
 static inline int grid_for(long long n, int perThread)
 {
+    static const int cap = [] { const char* e = getenv("MGCG_VEC_GRID"); const int v = e ? atoi(e) : 0; return (v >= 64 && v <= kMaxGrid) ? v : kMaxGrid; }();   // (A/B knob)
     long long blocks = (n + (long long)kBlock * perThread - 1) / ((long long)kBlock * perThread);
-    if (blocks > kMaxGrid) blocks = kMaxGrid;
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
@@ -344,7 +345,13 @@ int launch_update_r(hipStream_t s, CgScalars* sc, double* r, const double* Ap, l
                     const double* pApPartials, int nPAp)
 {
     const bool v2 = al16(r) && al16(Ap);
-    const int grid = grid_for(n, v2 ? 4 : 2);
+    int grid = grid_for(n, v2 ? 4 : 2);
+    // two workgroups per CU measured best for this 2-reads-1-write pass (0.565 ms against 0.59-0.61 for 768 / 1024 / 2048 and 0.72 for 256
+    // workgroups at 512^3; the 3-reads-2-writes x/p pass keeps 2048); MGCG_R_GRID overrides
+    static const int rcap = [] { const char* e = getenv("MGCG_R_GRID"); const int v = e ? atoi(e) : 0; return (v >= 64 && v <= kMaxGrid) ? v : 0; }();
+    DeviceState* d = device_state();
+    const int want = rcap > 0 ? rcap : 2 * (d ? d->numCu : kNumCu);
+    if (grid > want) grid = want;
     const bool inf = partialsInf != nullptr;
 #define GO(V, I) hipLaunchKernelGGL((update_r_kernel<V, I>), dim3(grid), dim3(kBlock), 0, s, sc, r, Ap, n, partials, partialsInf, pApPartials, nPAp)
     if (v2) { if (inf) GO(true, true); else GO(true, false); }
