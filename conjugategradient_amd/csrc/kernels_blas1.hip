@@ -509,4 +509,6 @@ void launch_finalize_precond(hipStream_t s, const double* partials, int n, bool 
     hipLaunchKernelGGL(finalize_precond_kernel, dim3(1), dim3(kBlock), 0, s, partials, n, reduceFirst ? 1 : 0, sc);
 }
 
+void preload_kernels_blas1() { preload_code_object(reinterpret_cast<const void*>(&fill_kernel)); }
+
 } // namespace mgcg

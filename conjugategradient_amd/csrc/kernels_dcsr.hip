@@ -330,4 +330,6 @@ bool dcsr_build(hipStream_t s, const double* elements, const int* rowOffsets, co
     return true;
 }
 
+void preload_kernels_dcsr() { preload_code_object(reinterpret_cast<const void*>(&dcsr_collect_kernel)); }
+
 } // namespace mgcg

@@ -337,4 +337,6 @@ void launch_halo_rows(hipStream_t s, const int* rowOffsets, const int* columnInd
     hipLaunchKernelGGL(halo_rows_kernel, dim3(grid1(n)), dim3(kBlock), 0, s, rowOffsets, columnIndeces, n, offset, out2);
 }
 
+void preload_kernels_mg() { preload_code_object(reinterpret_cast<const void*>(&uniform_check_kernel)); }
+
 } // namespace mgcg

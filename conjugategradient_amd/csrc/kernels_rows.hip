@@ -432,4 +432,6 @@ int launch_spmv_rows(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrV
     return 0;
 }
 
+void preload_kernels_rows() { preload_code_object(reinterpret_cast<const void*>(&(spmv_rows_kernel<EPI_DOT, FMT_CSR>))); }
+
 } // namespace mgcg

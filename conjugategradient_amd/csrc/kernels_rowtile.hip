@@ -264,6 +264,8 @@ int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int peri
     return 0;
 }
 
+void preload_kernels_rowtile() { preload_code_object(reinterpret_cast<const void*>(&matrix_shape_kernel)); }
+
 } // namespace mgcg
 
 // Host-side view of the tile order (no device needed): the tile every workgroup takes in every trip, for tests of the enumeration.

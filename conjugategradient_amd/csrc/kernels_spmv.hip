@@ -546,4 +546,6 @@ int launch_spmv(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig
     return 0;
 }
 
+void preload_kernels_spmv() { preload_code_object(reinterpret_cast<const void*>(&(spmv_vector_kernel<EPI_DOT, 32>))); }
+
 } // namespace mgcg

@@ -311,4 +311,6 @@ bool tiled_build(hipStream_t s, const double* elements, const int* rowOffsets, c
     return true;
 }
 
+void preload_kernels_tiled() { preload_code_object(reinterpret_cast<const void*>(&scan_totals_kernel)); }
+
 } // namespace mgcg

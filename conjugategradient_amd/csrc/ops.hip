@@ -32,6 +32,8 @@ static double finish_reduction(Workspace& ws, int n, int mode)
     if (!MGCG_HIP(hipStreamSynchronize(ws.stream))) return NAN;
     return ws.hostScalar[0];
 }
+void preload_ops() { preload_code_object(reinterpret_cast<const void*>(&set_alpha_kernel)); }
+
 } // namespace mgcg
 
 using namespace mgcg;

@@ -71,6 +71,10 @@ DeviceState* device_state()
         if (!MGCG_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking))) return nullptr;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, pd) == hipSuccess) d->numCu = prop.multiProcessorCount;
+        if (!getenv("MGCG_LAZY_CODE_OBJECTS")) {
+            preload_kernels_spmv(); preload_kernels_rowtile(); preload_kernels_blas1(); preload_solver(); preload_ops();
+            preload_kernels_rows(); preload_kernels_mg(); preload_kernels_dcsr(); preload_kernels_tiled(); preload_comm(); preload_spectrum();
+        }
     }
     return d;
 }

@@ -430,6 +430,8 @@ static bool check_vectors(const char* who, Vector* e, VectorInt* ro, VectorInt* 
     return true;
 }
 
+void preload_solver() { preload_code_object(reinterpret_cast<const void*>(&snapshot_kernel)); }
+
 } // namespace mgcg
 
 using namespace mgcg;

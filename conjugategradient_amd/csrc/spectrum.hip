@@ -67,6 +67,8 @@ static double tridiagonal_eigenvalue(const std::vector<double>& a, const std::ve
     return 0.5 * (lo + hi);
 }
 
+void preload_spectrum() { preload_code_object(reinterpret_cast<const void*>(&lanczos_start_kernel)); }
+
 } // namespace mgcg
 
 using namespace mgcg;

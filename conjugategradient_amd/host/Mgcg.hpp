@@ -12,7 +12,13 @@
 // The CPU solver of the reference (ConjugateGradientCpu.cs) is NOT here: its restatement is the test
 // oracle (oracle/cg_oracle.c), and the product has no CPU compute path.
 #pragma once
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -55,6 +61,73 @@ public:
     void CopyFrom(int* array, int count, int arrayOffset = 0, int vectorOffset = 0) { CopyFromArray_Int(Ptr, array, count, arrayOffset, vectorOffset); Check("CopyFromArray_Int"); }
     void CopyTo(int* array, int count, int arrayOffset = 0, int vectorOffset = 0) const { CopyToArray_Int(Ptr, array, count, vectorOffset, arrayOffset); Check("CopyToArray_Int"); }
     int* ToRawPtr() { return ToRawPtr_Int(Ptr); }
+};
+
+// Parallel.For of the reference (ConjugateGradientParallelGpu.cs:427-530: five of them per iteration) runs its bodies on the
+// .NET thread pool.  Here: one long-lived worker per device, woken per phase -- a phase of the 207 402-row driver is 5-80 us of
+// GPU work, and creating and joining a std::thread per phase cost 45 us each (five per iteration: 2/3 of the iteration).  With
+// one device the body runs on the calling thread, as Parallel.For does for a single index.
+class DeviceWorkers {
+    const int n;
+    std::vector<std::thread> threads;
+    std::vector<std::string> errors;
+    std::mutex m;
+    std::condition_variable go, finished;
+    std::atomic<unsigned long> generation{0};
+    std::atomic<int> pending{0};
+    std::atomic<bool> quit{false};
+    const std::function<void(int)>* job = nullptr;
+
+    template <typename P> static bool SpinUntil(P ready)
+    {
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(100);
+        for (int i = 0;; ++i) {
+            if (ready()) return true;
+            if ((i & 63) == 63 && std::chrono::steady_clock::now() > until) return false;
+        }
+    }
+    void Body(int d)
+    {
+        try { (*job)(d); } catch (std::exception& e) { errors[(size_t)d] = e.what(); }
+    }
+    void Loop(int d)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            auto ready = [&] { return generation.load(std::memory_order_acquire) != seen || quit.load(std::memory_order_acquire); };
+            if (!SpinUntil(ready)) { std::unique_lock<std::mutex> lock(m); go.wait(lock, ready); }
+            if (quit.load(std::memory_order_acquire)) return;
+            seen = generation.load(std::memory_order_acquire);
+            Body(d);
+            if (pending.fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> lock(m); finished.notify_one(); }
+        }
+    }
+public:
+    explicit DeviceWorkers(int count) : n(count), errors((size_t)count)
+    {
+        if (n > 1) for (int d = 0; d < n; d++) threads.emplace_back([this, d] { Loop(d); });
+    }
+    ~DeviceWorkers()
+    {
+        { std::lock_guard<std::mutex> lock(m); quit.store(true, std::memory_order_release); }
+        go.notify_all();
+        for (auto& t : threads) t.join();
+    }
+    DeviceWorkers(const DeviceWorkers&) = delete;
+    DeviceWorkers& operator=(const DeviceWorkers&) = delete;
+    void Run(const std::function<void(int)>& f)
+    {
+        job = &f;
+        if (n == 1) Body(0);
+        else {
+            { std::lock_guard<std::mutex> lock(m); pending.store(n, std::memory_order_release); generation.fetch_add(1, std::memory_order_acq_rel); }
+            go.notify_all();
+            auto done = [&] { return pending.load(std::memory_order_acquire) == 0; };
+            if (!SpinUntil(done)) { std::unique_lock<std::mutex> lock(m); finished.wait(lock, done); }
+        }
+        job = nullptr;
+        for (auto& e : errors) if (!e.empty()) { std::string msg; msg.swap(e); for (auto& r : errors) r.clear(); throw MgcgError(msg); }
+    }
 };
 
 class SparseMatrix {
@@ -152,13 +225,11 @@ class ConjugateGradientParallelGpu : public ConjugateGradientGpu {
     std::vector<VectorInt*> vectorColumnIndeces, vectorRowOffsets;
     std::vector<double> bufferHost, resultsDot;
 
+    std::unique_ptr<DeviceWorkers> workers;
     template <typename F> void ParallelFor(F f)
     {
-        std::vector<std::thread> ts;
-        std::vector<std::string> errs((size_t)deviceCount);
-        for (int d = 0; d < deviceCount; d++) ts.emplace_back([&, d] { try { SetDevice(d); f(d); Check("device phase"); } catch (std::exception& e) { errs[(size_t)d] = e.what(); } });
-        for (auto& t : ts) t.join();
-        for (auto& e : errs) if (!e.empty()) throw MgcgError(e);
+        if (!workers) workers.reset(new DeviceWorkers(deviceCount));
+        workers->Run([&](int d) { SetDevice(d); f(d); Check("device phase"); });
     }
     int CountForDevice(int d) const { return (0 <= d && d < deviceCount) ? offsetsForDevice[(size_t)d + 1] - offsetsForDevice[(size_t)d] : 0; }
     int ElementCount(int d) const { return A->RowOffsets[(size_t)offsetsForDevice[(size_t)d + 1]] - A->RowOffsets[(size_t)offsetsForDevice[(size_t)d]]; }
