@@ -47,7 +47,8 @@ static Rccl* rccl()
 #undef SYM
     });
     if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd || !r.AllGather) {
-        set_error("RCCL is not available (dlopen librccl.so.1 failed: %s)", dlerror() ? dlerror() : "missing symbols");
+        const char* why = r.lib ? nullptr : dlerror();        // dlerror() clears itself: read it once
+        set_error("RCCL is not available (%s)", r.lib ? "librccl lacks a needed symbol" : (why ? why : "dlopen librccl.so.1 failed"));
         return nullptr;
     }
     return &r;

@@ -98,16 +98,19 @@ def create_comm(rank: int, world: int):
     import torch.distributed as dist
 
     buf = (C.c_char * 128)()
-    if rank == 0:
-        if L.MgcgCommGetUniqueId(buf) != 0:
-            check("MgcgCommGetUniqueId")
-            raise MgcgError("MgcgCommGetUniqueId failed")
-    t = torch.tensor(list(bytes(buf)), dtype=torch.uint8)
+    failed = 0
+    if rank == 0 and L.MgcgCommGetUniqueId(buf) != 0:
+        failed = 1                      # still take part in the broadcast: the other ranks are waiting in it
+    t = torch.tensor(list(bytes(buf)) + [failed], dtype=torch.uint8)
     if dist.get_backend() == "nccl":
         t = t.cuda()
     dist.broadcast(t, src=0)
     raw = bytes(t.cpu().tolist())
-    idbuf = (C.c_char * 128).from_buffer_copy(raw)
+    if raw[128]:
+        if rank == 0:
+            check("MgcgCommGetUniqueId")
+        raise MgcgError("MgcgCommGetUniqueId failed on rank 0")
+    idbuf = (C.c_char * 128).from_buffer_copy(raw[:128])
     c = L.MgcgCommInitRank(idbuf, world, rank)
     check("MgcgCommInitRank")
     if not c:
