@@ -93,6 +93,7 @@ SIGNATURES = {
     "MgSetup": (_vp, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _i, _d]),
     "MgSetupParallel": (_vp, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _d, _i, _i, _d]),
     "MgDestroy": (None, [_vp]),
+    "MgSetInterpolation": (_i, [_vp, _i]),
     "MgLevels": (_i, [_vp]),
     "MgLevelRows": (_ll, [_vp, _i]),
     "MgLevelNnz": (_ll, [_vp, _i]),

@@ -314,6 +314,8 @@ void launch_uniform_check(hipStream_t s, const double* v, long long n, int* flag
 void launch_restrict(hipStream_t s, int nx, int ny, int nz, const double* r, double* bc, const int* done);
 void launch_prolong_add(hipStream_t s, int nx, int ny, int nz, double* x, const double* e, const int* done);
 // x[i] = outer * (inner * b[i]) + e[parent(i)]   (prolong_add onto a first Jacobi sweep that was never stored)
+void launch_prolong_linear_add(hipStream_t s, int nx, int ny, int nz, int z0, int z1, double* x, const double* eFull, const int* done);
+void launch_restrict_linear(hipStream_t s, int nx, int ny, int nz, int z0, int z1, const double* rFull, double* bc, const int* done);
 void launch_prolong_scaled(hipStream_t s, int nx, int ny, int nz, double* x, const double* b, double inner, double outer, const double* e, const int* done);
 void launch_extract_dinv(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces,
                          long long n, long long rowBase, double* dinv);

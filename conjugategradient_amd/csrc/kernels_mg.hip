@@ -134,6 +134,183 @@ void launch_prolong_scaled(hipStream_t s, int nx, int ny, int nz, double* x, con
     hipLaunchKernelGGL(prolong_scaled_kernel, dim3(grid1((long long)nx * ny * nz)), dim3(kBlock), 0, s, nx, ny, nz, x, b, inner, outer, e, done);
 }
 
+// ---- cell-centred linear transfer (MgSetInterpolation(mg, 1)); arithmetic order of oracle_mg_prolong_add_linear /
+// oracle_mg_restrict_linear (oracle/mg_oracle.c): per coarsened dimension child i takes 3/4 of parent i/2 and 1/4 of the
+// parent's neighbour on the child's side; weights and their products are exact, each term is one rounded product, the terms
+// are summed from zero in (z, y, x) order.  Both kernels address the OTHER grid globally (the caller has exchanged the
+// neighbours' plane of it) and their own grid by the rank's planes [z0, z1).
+__device__ __forceinline__ int lin_terms(int i, int n, int idx[2], double w[2])
+{
+    if (n == 1) { idx[0] = 0; w[0] = 1.0; return 1; }
+    const int I = i >> 1, J = (i & 1) ? I + 1 : I - 1;
+    idx[0] = I; w[0] = 0.75;
+    if (J < 0 || J >= (n >> 1)) return 1;
+    idx[1] = J; w[1] = 0.25;
+    return 2;
+}
+
+// x[i] += sum_k w_k e[c_k] for the fine cells of planes [z0, z1); x is slab-local, eFull the whole coarse vector
+__global__ __launch_bounds__(kBlock) void prolong_linear_add_kernel(int nx, int ny, int nz, int z0, int z1, double* __restrict__ x,
+                                                                    const double* __restrict__ eFull, const int* done)
+{
+    if (done != nullptr && *done != 0) return;
+    const int NX = nx > 1 ? nx / 2 : 1, NY = ny > 1 ? ny / 2 : 1;
+    const long long N = (long long)nx * ny * (z1 - z0);
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < N; i += stride) {
+        const int xx = (int)(i % nx), yy = (int)((i / nx) % ny), zz = z0 + (int)(i / ((long long)nx * ny));
+        int iz[2], iy[2], ix[2]; double wz[2], wy[2], wx[2];
+        const int kz = lin_terms(zz, nz, iz, wz), ky = lin_terms(yy, ny, iy, wy), kx = lin_terms(xx, nx, ix, wx);
+        double sum = 0.0;
+        for (int a = 0; a < kz; ++a)
+            for (int b = 0; b < ky; ++b) {
+                const double wzy = wz[a] * wy[b];
+                const long long base = ((long long)iz[a] * NY + iy[b]) * NX;
+                for (int c = 0; c < kx; ++c) { const double w = wzy * wx[c]; const double t = w * eFull[base + ix[c]]; sum += t; }
+            }
+        x[i] = x[i] + sum;
+    }
+}
+// The same for an even nx with 16-byte aligned x: a workgroup is TX lanes along x by kBlock/TX fine rows; a lane owns the two
+// children of coarse cell X (one 16-byte load and store of x, three coarse values per (z, y) term instead of four) and no
+// index is divided.  Per-cell arithmetic is that of the kernel above.
+__global__ __launch_bounds__(kBlock) void prolong_linear_add_rows_kernel(int nx, int ny, int nz, int z0, int z1, int tx, double* __restrict__ x,
+                                                                         const double* __restrict__ eFull, const int* done)
+{
+    if (done != nullptr && *done != 0) return;
+    const int NX = nx >> 1, NY = ny > 1 ? ny / 2 : 1;
+    const int ty = kBlock / tx;
+    const int lx = threadIdx.x % tx, ly = threadIdx.x / tx;
+    const long long rows = (long long)ny * (z1 - z0);
+    for (long long row = (long long)blockIdx.x * ty + ly; row < rows; row += (long long)gridDim.x * ty) {
+        const int yy = (int)(row % ny), zz = z0 + (int)(row / ny);
+        int iz[2], iy[2]; double wz[2], wy[2];
+        const int kz = lin_terms(zz, nz, iz, wz), ky = lin_terms(yy, ny, iy, wy);
+        d2mg* xr = (d2mg*)(x + row * nx);
+        for (int X = lx; X < NX; X += tx) {
+            const bool hasL = X > 0, hasR = X + 1 < NX;
+            double sumL = 0.0, sumR = 0.0;
+            for (int a = 0; a < kz; ++a)
+                for (int b = 0; b < ky; ++b) {
+                    const double wzy = wz[a] * wy[b];
+                    const double* er = eFull + ((long long)iz[a] * NY + iy[b]) * NX;
+                    const double eC = er[X];
+                    const double eL = hasL ? er[X - 1] : 0.0, eR = hasR ? er[X + 1] : 0.0;
+                    const double w3 = wzy * 0.75, w1 = wzy * 0.25;
+                    const double tC = w3 * eC;
+                    sumL += tC; sumR += tC;
+                    if (hasL) { const double t = w1 * eL; sumL += t; }
+                    if (hasR) { const double t = w1 * eR; sumR += t; }
+                }
+            d2mg v = xr[X];
+            v.x = v.x + sumL; v.y = v.y + sumR;
+            xr[X] = v;
+        }
+    }
+}
+static int rows_tx(int pairs) { int t = 1; while (t < pairs && t < kBlock) t <<= 1; return t; }
+void launch_prolong_linear_add(hipStream_t s, int nx, int ny, int nz, int z0, int z1, double* x, const double* eFull, const int* done)
+{
+    if (nx >= 2 && (nx & 1) == 0 && (((uintptr_t)x) & 15) == 0) {
+        const int tx = rows_tx(nx / 2), ty = kBlock / tx;
+        const long long rows = (long long)ny * (z1 - z0);
+        long long g = (rows + ty - 1) / ty; if (g > kMaxGrid) g = kMaxGrid; if (g < 1) g = 1;
+        hipLaunchKernelGGL(prolong_linear_add_rows_kernel, dim3((int)g), dim3(kBlock), 0, s, nx, ny, nz, z0, z1, tx, x, eFull, done);
+        return;
+    }
+    hipLaunchKernelGGL(prolong_linear_add_kernel, dim3(grid1((long long)nx * ny * (z1 - z0))), dim3(kBlock), 0, s, nx, ny, nz, z0, z1, x, eFull, done);
+}
+
+// bc[I] = sum over the (up to) 4x4x4 fine cells around coarse cell I of w * r, for the coarse planes of the rank's fine
+// planes [z0, z1); rFull is the whole fine vector, bc slab-local
+__global__ __launch_bounds__(kBlock) void restrict_linear_kernel(int nx, int ny, int nz, int z0, int z1, const double* __restrict__ rFull,
+                                                                 double* __restrict__ bc, const int* done)
+{
+    if (done != nullptr && *done != 0) return;
+    const int cz = nz > 1 ? 2 : 1;
+    const int NX = nx > 1 ? nx / 2 : 1, NY = ny > 1 ? ny / 2 : 1;
+    const int Z0 = z0 / cz, ZL = (z1 - z0) / cz;
+    const long long NC = (long long)NX * NY * ZL;
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long I = (long long)blockIdx.x * kBlock + threadIdx.x; I < NC; I += stride) {
+        const int X = (int)(I % NX), Y = (int)((I / NX) % NY), Z = Z0 + (int)(I / ((long long)NX * NY));
+        // per dimension: first fine index, number of terms, and whether the first term is the quarter-weight one
+        auto span = [](int C, int n, int& first, int& count, int& quarterFirst) {
+            if (n == 1) { first = 0; count = 1; quarterFirst = -1; return; }
+            const int lo = 2 * C - 1, hi = 2 * C + 2;
+            first = lo < 0 ? 0 : lo; count = (hi >= n ? n - 1 : hi) - first + 1; quarterFirst = lo < 0 ? 0 : 1;
+        };
+        int fz, nzT, qz, fy, nyT, qy, fx, nxT, qx;
+        span(Z, nz, fz, nzT, qz); span(Y, ny, fy, nyT, qy); span(X, nx, fx, nxT, qx);
+        // weight of term k of a dimension: 1 for an uncoarsened one; else the fine index relative to 2C-1 is k + (1 - q): 0 and 3 -> 1/4
+        auto weight = [](int k, int q) { if (q < 0) return 1.0; const int rel = k + (1 - q); return (rel == 0 || rel == 3) ? 0.25 : 0.75; };
+        double sum = 0.0;
+        for (int a = 0; a < nzT; ++a) {
+            const double wza = weight(a, qz);
+            for (int b = 0; b < nyT; ++b) {
+                const double wzy = wza * weight(b, qy);
+                const long long base = ((long long)(fz + a) * ny + (fy + b)) * nx + fx;
+                for (int c = 0; c < nxT; ++c) { const double w = wzy * weight(c, qx); const double t = w * rFull[base + c]; sum += t; }
+            }
+        }
+        bc[I] = sum;
+    }
+}
+// The same for an even nx with 16-byte aligned r: TX lanes along the coarse x by kBlock/TX coarse rows; a lane reads its two
+// children as one 16-byte load and the two quarter-weight cells beside them; no index is divided.
+__global__ __launch_bounds__(kBlock) void restrict_linear_rows_kernel(int nx, int ny, int nz, int z0, int z1, int tx, const double* __restrict__ rFull,
+                                                                      double* __restrict__ bc, const int* done)
+{
+    if (done != nullptr && *done != 0) return;
+    const int cz = nz > 1 ? 2 : 1;
+    const int NX = nx >> 1, NY = ny > 1 ? ny / 2 : 1;
+    const int Z0 = z0 / cz, ZL = (z1 - z0) / cz;
+    const int ty = kBlock / tx;
+    const int lx = threadIdx.x % tx, ly = threadIdx.x / tx;
+    const long long rows = (long long)NY * ZL;
+    auto span = [](int C, int n, int& first, int& count, int& quarterFirst) {
+        if (n == 1) { first = 0; count = 1; quarterFirst = -1; return; }
+        const int lo = 2 * C - 1, hi = 2 * C + 2;
+        first = lo < 0 ? 0 : lo; count = (hi >= n ? n - 1 : hi) - first + 1; quarterFirst = lo < 0 ? 0 : 1;
+    };
+    auto weight = [](int k, int q) { if (q < 0) return 1.0; const int rel = k + (1 - q); return (rel == 0 || rel == 3) ? 0.25 : 0.75; };
+    for (long long row = (long long)blockIdx.x * ty + ly; row < rows; row += (long long)gridDim.x * ty) {
+        const int Y = (int)(row % NY), Z = Z0 + (int)(row / NY);
+        int fz, nzT, qz, fy, nyT, qy;
+        span(Z, nz, fz, nzT, qz); span(Y, ny, fy, nyT, qy);
+        for (int X = lx; X < NX; X += tx) {
+            const bool hasL = X > 0, hasR = 2 * X + 2 < nx;
+            double sum = 0.0;
+            for (int a = 0; a < nzT; ++a) {
+                const double wza = weight(a, qz);
+                for (int b = 0; b < nyT; ++b) {
+                    const double wzy = wza * weight(b, qy);
+                    const double* rr = rFull + ((long long)(fz + a) * ny + (fy + b)) * nx + 2 * X;
+                    const d2mg mid = *(const d2mg*)rr;
+                    const double w3 = wzy * 0.75, w1 = wzy * 0.25;
+                    if (hasL) { const double t = w1 * rr[-1]; sum += t; }
+                    { const double t = w3 * mid.x; sum += t; }
+                    { const double t = w3 * mid.y; sum += t; }
+                    if (hasR) { const double t = w1 * rr[2]; sum += t; }
+                }
+            }
+            bc[row * NX + X] = sum;
+        }
+    }
+}
+void launch_restrict_linear(hipStream_t s, int nx, int ny, int nz, int z0, int z1, const double* rFull, double* bc, const int* done)
+{
+    if (nx >= 2 && (nx & 1) == 0 && (((uintptr_t)rFull) & 15) == 0) {
+        const int tx = rows_tx(nx / 2), ty = kBlock / tx;
+        const long long rows = (long long)(ny > 1 ? ny / 2 : 1) * ((z1 - z0) / (nz > 1 ? 2 : 1));
+        long long g = (rows + ty - 1) / ty; if (g > kMaxGrid) g = kMaxGrid; if (g < 1) g = 1;
+        hipLaunchKernelGGL(restrict_linear_rows_kernel, dim3((int)g), dim3(kBlock), 0, s, nx, ny, nz, z0, z1, tx, rFull, bc, done);
+        return;
+    }
+    const long long NC = (long long)(nx > 1 ? nx / 2 : 1) * (ny > 1 ? ny / 2 : 1) * ((z1 - z0) / (nz > 1 ? 2 : 1));
+    hipLaunchKernelGGL(restrict_linear_kernel, dim3(grid1(NC)), dim3(kBlock), 0, s, nx, ny, nz, z0, z1, rFull, bc, done);
+}
+
 // dinv[i] = 1 / (first stored entry of local row i whose column is rowBase + i)
 __global__ __launch_bounds__(kBlock) void extract_dinv_kernel(const double* __restrict__ elements, const int* __restrict__ rowOffsets,
                                                               const int* __restrict__ columnIndeces, long long n, long long rowBase, double* __restrict__ dinv)

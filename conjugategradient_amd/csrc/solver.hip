@@ -30,6 +30,7 @@ struct MgLevel {
     SpmvConfig cfg;                        // per level: kernel picked from its nnz/row, banded period = nx*ny
     const DcsrMatrix* dcsr = nullptr;      // compressed form (owned by the MgcgSparse handle's cache)
     HaloPlan* halo = nullptr;              // multi-rank: planes of the iterate owned by the neighbours
+    HaloPlan* transferHalo = nullptr;      // multi-rank, linear transfer: exactly one grid plane from each z-neighbour
     int minJ = 0, maxJ = -1;
     bool overlap = false;                  // interior rows [interior0, interior1) are multiplied while the halo travels
     long long interior0 = 0, interior1 = 0;
@@ -40,6 +41,7 @@ struct MgLevel {
 struct MgcgMg {
     int levels = 0;
     double omega = 0; int nu = 1, nuCoarse = 4; double sigma = 0.5;
+    int interp = 0;                        // 0: piecewise-constant P (slab-local), 1: cell-centred linear P (MgSetInterpolation)
     std::vector<mgcg::MgLevel> lv;
     mgcg::SpmvConfig cfg;
     hipStream_t stream = nullptr;
@@ -146,20 +148,33 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
     double* cur = nullptr;
     // V(1,*) on one rank with a uniform diagonal and the row-pattern form: the first sweep x1 = omega (d0 b) is not stored;
     // the residual pass forms x1[col] per gather and the prolongation forms x1[i] again when it adds the correction
-    const bool fold = mg->nu == 1 && mg->nranks == 1 && L.dinvUniform && L.dcsr != nullptr && L.dcsr->usable && L.dcsr->patternId != nullptr &&
+    const bool linear = mg->interp == 1;
+    const bool fold = mg->nu == 1 && mg->nranks == 1 && !linear && L.dinvUniform && L.dcsr != nullptr && L.dcsr->usable && L.dcsr->patternId != nullptr &&
                       getenv("MGCG_NO_FOLD") == nullptr;
     if (fold) cur = x0;
     else if (!mg_smooth(mg, L, b, x0, x1, mg->nu, true, done, &cur)) return false;
     double* other = (cur == x0) ? x1 : x0;
     SpmvArgs a{};
-    a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = fold ? b : cur; a.y = L.r;
+    // linear transfer on several ranks: the restriction reads one plane of r from each z-neighbour, so r goes to the spare
+    // full-length iterate buffer (dead until the post-smoothing writes it) and that plane is exchanged
+    const bool rFullLength = linear && mg->nranks > 1;
+    a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = fold ? b : cur; a.y = rFullLength ? other + L.offset : L.r;
     a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal; a.b = b; a.doneFlag = done;
     if (fold) { a.xScaled = 1; a.xInner = L.dinvScalar; a.xOuter = mg->omega; }
     if (!mg_spmv(mg, L, EPI_RESIDUAL, a, cur)) return false;                                  // r = b - A x
-    launch_restrict(mg->stream, L.nx, L.ny, L.z1 - L.z0, L.r, C.b, done);                     // b_c = P^T r (slab-local)
+    if (linear) {
+        if (rFullLength && !halo_exchange(mg->comm, L.transferHalo, other, mg->stream)) return false;
+        launch_restrict_linear(mg->stream, L.nx, L.ny, L.nz, L.z0, L.z1, rFullLength ? other : L.r, C.b, done);   // b_c = P^T r
+    } else {
+        launch_restrict(mg->stream, L.nx, L.ny, L.z1 - L.z0, L.r, C.b, done);                 // b_c = P^T r (slab-local)
+    }
     double* e = nullptr;
     if (!mg_vcycle(mg, l + 1, C.b, C.xa, C.xb, done, &e)) return false;
-    if (fold) launch_prolong_scaled(mg->stream, L.nx, L.ny, L.z1 - L.z0, cur + L.offset, b, L.dinvScalar, mg->omega, e + C.offset, done);
+    if (linear) {
+        if (mg->nranks > 1 && !halo_exchange(mg->comm, C.transferHalo, e, mg->stream)) return false;
+        launch_prolong_linear_add(mg->stream, L.nx, L.ny, L.nz, L.z0, L.z1, cur + L.offset, e, done);               // x += P e
+    }
+    else if (fold) launch_prolong_scaled(mg->stream, L.nx, L.ny, L.z1 - L.z0, cur + L.offset, b, L.dinvScalar, mg->omega, e + C.offset, done);
     else launch_prolong_add(mg->stream, L.nx, L.ny, L.z1 - L.z0, cur + L.offset, e + C.offset, done);   // x += P e (slab-local)
     return mg_smooth(mg, L, b, cur, other, mg->nu, false, done, result, l == 0);
 }
@@ -708,8 +723,29 @@ void MgDestroy(MgcgMg* mg)
         if (L.b) (void)hipFree(L.b);
         if (L.r) (void)hipFree(L.r);
         if (L.halo) halo_plan_destroy(L.halo);
+        if (L.transferHalo) halo_plan_destroy(L.transferHalo);
     }
     delete mg;
+}
+
+int MgSetInterpolation(MgcgMg* mg, int mode)
+{
+    if (!mg || (mode != 0 && mode != 1)) { set_error("MgSetInterpolation: mode must be 0 (piecewise constant) or 1 (cell-centred linear)"); return -1; }
+    if (!device_state()) return -1;
+    if (mode == 1 && mg->nranks > 1) {
+        // collective: every rank builds, level by level, the plan that brings one grid plane from each z-neighbour
+        for (MgLevel& L : mg->lv) {
+            if (L.transferHalo) continue;
+            const long long plane = (long long)L.nx * L.ny;
+            long long lo = L.offset - plane, hi = L.offset + L.n + plane - 1;
+            if (lo < 0) lo = 0;
+            if (hi > L.nGlobal - 1) hi = L.nGlobal - 1;
+            L.transferHalo = halo_plan_create(mg->comm, L.nGlobal, L.offset, L.n, (int)lo, (int)hi);
+            if (!L.transferHalo) return -1;
+        }
+    }
+    mg->interp = mode;
+    return 0;
 }
 
 int MgLevels(const MgcgMg* mg) { return mg ? mg->levels : 0; }

@@ -20,8 +20,9 @@ class ConjugateGradientMgGpu(ConjugateGradientSingleGpu):
 
     def __init__(self, count, maxNonZeroCount, _minIteration, _maxIteration, allowableResidual, grid,
                  levels: int = 3, omega: float | None = None, nu: int = 1, nuCoarse: int = 4, sigma: float = 0.5,
-                 rule=_lib.RULE_CSHARP):
+                 rule=_lib.RULE_CSHARP, interpolation: int = 0):
         super().__init__(count, maxNonZeroCount, _minIteration, _maxIteration, allowableResidual, rule=rule)
+        self.interpolation = int(interpolation)          # 0: piecewise constant, 1: cell-centred linear (MgSetInterpolation)
         self.grid = tuple(int(g) for g in grid)
         nx, ny, nz = self.grid
         if nx * ny * nz != count:
@@ -70,6 +71,8 @@ class ConjugateGradientMgGpu(ConjugateGradientSingleGpu):
         check("MgSetup")
         if not self.mg:
             raise MgcgError("MgSetup returned NULL")
+        if self.interpolation and lib().MgSetInterpolation(self.mg, self.interpolation) != 0:
+            check("MgSetInterpolation")
         self.levels = lib().MgLevels(self.mg)
 
     def level_csr(self, l: int):

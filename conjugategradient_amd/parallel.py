@@ -305,9 +305,11 @@ class ConjugateGradientMgRankGpu(ConjugateGradientRankGpu):
 
     def __init__(self, count, maxNonZeroCount, _minIteration, _maxIteration, allowableResidual, grid,
                  rank: int = 0, world: int = 1, comm=None, rule=_lib.RULE_CSHARP, device: int | None = None,
-                 levels: int = 3, omega: float | None = None, nu: int = 1, nuCoarse: int = 4, sigma: float = 0.5):
+                 levels: int = 3, omega: float | None = None, nu: int = 1, nuCoarse: int = 4, sigma: float = 0.5,
+                 interpolation: int = 0):
         super().__init__(count, maxNonZeroCount, _minIteration, _maxIteration, allowableResidual, rank=rank, world=world,
                          comm=comm, rule=rule, device=device)
+        self.interpolation = int(interpolation)          # 0: piecewise constant, 1: cell-centred linear (MgSetInterpolation)
         self.grid = tuple(int(g) for g in grid)
         nx, ny, nz = self.grid
         if nx * ny * nz != count:
@@ -341,6 +343,8 @@ class ConjugateGradientMgRankGpu(ConjugateGradientRankGpu):
         check("MgSetupParallel")
         if not self.mg:
             raise MgcgError("MgSetupParallel returned NULL")
+        if self.interpolation and lib().MgSetInterpolation(self.mg, self.interpolation) != 0:
+            check("MgSetInterpolation")
         self.levels = lib().MgLevels(self.mg)
 
     def Apply(self, r_local: np.ndarray) -> np.ndarray:

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--rel-tol", type=float, default=1e-8, help="stop at ||r||_2 < rel_tol * ||b||_2 (b = 1)")
     ap.add_argument("--max-it", type=int, default=20000)
     ap.add_argument("--skip-cg", action="store_true")
+    ap.add_argument("--interpolation", type=int, default=0, help="0: piecewise-constant transfer, 1: cell-centred linear (MgSetInterpolation)")
     ap.add_argument("--compression", action="store_true", help="MgcgSetMatrixCompression(1): lossless dictionary form of every level")
     a = ap.parse_args()
     L = _lib.lib()
@@ -30,9 +31,9 @@ def main():
     n = a.grid
     N = n**3
     tol = a.rel_tol * (N ** 0.5)
-    out = {"grid": n, "rows": N, "abs_tol": tol, "levels": a.levels, "nu": a.nu, "nu_coarse": a.nu_coarse}
+    out = {"grid": n, "rows": N, "abs_tol": tol, "levels": a.levels, "nu": a.nu, "nu_coarse": a.nu_coarse, "interpolation": a.interpolation}
 
-    mg = ConjugateGradientMgGpu(N, 7, 0, a.max_it, tol, (n, n, n), levels=a.levels, nu=a.nu, nuCoarse=a.nu_coarse, rule=_lib.RULE_CSHARP)
+    mg = ConjugateGradientMgGpu(N, 7, 0, a.max_it, tol, (n, n, n), levels=a.levels, nu=a.nu, nuCoarse=a.nu_coarse, rule=_lib.RULE_CSHARP, interpolation=a.interpolation)
     L.MgcgSetMatrixCompression(mg.cusparse, 1 if a.compression else 0)
     out["compression"] = bool(a.compression)
     t0 = time.perf_counter()

@@ -275,6 +275,11 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
                         int elementsCount, int nx, int ny, int nz, int zBegin, int zEnd,
                         int levels, double omega, int nu, int nuCoarse, double sigma);
 void    MgDestroy(MgcgMg* mg);
+/* Transfer operators of the V-cycle: 0 (default) piecewise-constant P, 1 cell-centred linear P (per coarsened dimension
+ * a child takes 3/4 of its parent and 1/4 of the parent's neighbour on the child's side), R = P^T in both; the coarse
+ * operators are the same.  With several ranks the call is collective (it plans one extra plane exchange per level and
+ * transfer).  Returns 0, or -1 with MgcgGetLastError(). */
+int     MgSetInterpolation(MgcgMg* mg, int mode);
 int     MgLevels(const MgcgMg* mg);
 /* rows / nnz / grid of level l; copy level l's CSR and D^-1 to host arrays (for tests). */
 long long MgLevelRows(const MgcgMg* mg, int level);

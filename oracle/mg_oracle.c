@@ -27,6 +27,11 @@
  *   S  : weighted Jacobi  x <- x + omega * (D^-1 * (b - A x))
  *   V(nu,nu) with zero initial guess on every level, nuC Jacobi sweeps on the
  *   coarsest level.  nu pre == nu post and R = P^T make M^-1 symmetric.
+ *   Optional (oracle_mg_set_interpolation(H, 1)): P = cell-centred (tri)linear
+ *   interpolation -- per coarsened dimension child i takes 3/4 of its parent
+ *   i/2 and 1/4 of the parent's neighbour on the child's side (i even: i/2-1,
+ *   i odd: i/2+1; a neighbour outside the grid contributes nothing) -- and
+ *   R = P^T; the coarse operators stay the ones above.
  * Arithmetic order is fixed (stated at each function) so that the HIP kernels,
  * built with -ffp-contract=off, reproduce M^-1 r bit for bit.
  */
@@ -52,6 +57,7 @@ typedef struct {
     int levels;
     double omega;
     int nu, nuCoarse;
+    int interp;                /* 0: piecewise constant, 1: cell-centred linear */
     mg_level *lv;
 } mg_hierarchy;
 
@@ -149,6 +155,90 @@ void oracle_mg_prolong_add(int nx, int ny, int nz, double *x, const double *e)
                 x[i] += e[((int64_t)(z / cz) * NY + (y / cy)) * NX + (x_ / cx)];
 }
 
+/*
+ * Cell-centred linear transfer, one dimension: fine index i of a coarsened
+ * dimension (fine extent n, coarse extent n/2) touches coarse cells
+ *   i/2 with weight 3/4   and   i/2 - 1 (i even) or i/2 + 1 (i odd) with 1/4
+ * (dropped outside [0, n/2)); a dimension of extent 1 is carried over with
+ * weight 1.  All weights and their products (27/64 ... 1/64) are exact in
+ * binary, so w = (wz * wy) * wx carries no rounding.
+ *
+ * Prolongation x[i] += sum_k w_k * e[c_k]: terms in the order z (parent,
+ * then neighbour), y (parent, neighbour), x (parent, neighbour); each term is
+ * the rounded product w * e, added to a running sum that starts at 0; the
+ * sum is then added to x[i].
+ */
+static int lin_terms(int i, int n, int idx[2], double w[2])
+{
+    if (n == 1) { idx[0] = 0; w[0] = 1.0; return 1; }
+    const int I = i / 2, J = (i % 2 == 0) ? I - 1 : I + 1;
+    idx[0] = I; w[0] = 0.75;
+    if (J < 0 || J >= n / 2) return 1;
+    idx[1] = J; w[1] = 0.25;
+    return 2;
+}
+
+void oracle_mg_prolong_add_linear(int nx, int ny, int nz, double *x, const double *e)
+{
+    const int NX = nx > 1 ? nx / 2 : 1, NY = ny > 1 ? ny / 2 : 1;
+    int64_t i = 0;
+    for (int z = 0; z < nz; z++)
+        for (int y = 0; y < ny; y++)
+            for (int x_ = 0; x_ < nx; x_++, i++) {
+                int iz[2], iy[2], ix[2]; double wz[2], wy[2], wx[2];
+                const int kz = lin_terms(z, nz, iz, wz), ky = lin_terms(y, ny, iy, wy), kx = lin_terms(x_, nx, ix, wx);
+                double s = 0;
+                for (int a = 0; a < kz; a++)
+                    for (int b = 0; b < ky; b++)
+                        for (int c = 0; c < kx; c++) {
+                            const double w = (wz[a] * wy[b]) * wx[c];
+                            const double t = w * e[((int64_t)iz[a] * NY + iy[b]) * NX + ix[c]];
+                            s += t;
+                        }
+                x[i] += s;
+            }
+}
+
+/*
+ * Restriction b_c = P^T r with the P above: coarse I of a coarsened dimension
+ * gathers the fine cells 2I-1, 2I, 2I+1, 2I+2 with weights 1/4, 3/4, 3/4, 1/4
+ * (those inside the grid), a dimension of extent 1 its single cell with
+ * weight 1.  Terms in ascending (z, y, x) order of the fine cell, each the
+ * rounded product w * r with w = (wz * wy) * wx, summed left to right from 0.
+ */
+static int lin_gather(int I, int n, int idx[4], double w[4])
+{
+    if (n == 1) { idx[0] = 0; w[0] = 1.0; return 1; }
+    int k = 0;
+    for (int d = -1; d <= 2; d++) {
+        const int i = 2 * I + d;
+        if (i < 0 || i >= n) continue;
+        idx[k] = i; w[k] = (d == -1 || d == 2) ? 0.25 : 0.75; k++;
+    }
+    return k;
+}
+
+void oracle_mg_restrict_linear(int nx, int ny, int nz, const double *r, double *bc)
+{
+    const int NX = nx > 1 ? nx / 2 : 1, NY = ny > 1 ? ny / 2 : 1, NZ = nz > 1 ? nz / 2 : 1;
+    int64_t I = 0;
+    for (int Z = 0; Z < NZ; Z++)
+        for (int Y = 0; Y < NY; Y++)
+            for (int X = 0; X < NX; X++, I++) {
+                int iz[4], iy[4], ix[4]; double wz[4], wy[4], wx[4];
+                const int kz = lin_gather(Z, nz, iz, wz), ky = lin_gather(Y, ny, iy, wy), kx = lin_gather(X, nx, ix, wx);
+                double s = 0;
+                for (int a = 0; a < kz; a++)
+                    for (int b = 0; b < ky; b++)
+                        for (int c = 0; c < kx; c++) {
+                            const double w = (wz[a] * wy[b]) * wx[c];
+                            const double t = w * r[((int64_t)iz[a] * ny + iy[b]) * nx + ix[c]];
+                            s += t;
+                        }
+                bc[I] = s;
+            }
+}
+
 /* x = omega * (dinv * b)   (Jacobi sweep from a zero guess) */
 void oracle_mg_jacobi_first(int64_t n, double omega, const double *dinv, const double *b, double *x)
 {
@@ -197,7 +287,8 @@ mg_hierarchy *oracle_mg_setup(int nx, int ny, int nz, int levels,
             L->owns_matrix = 0;
         } else {
             const mg_level *F = &H->lv[l - 1];
-            if ((F->nx > 1 && F->nx % 2) || (F->ny > 1 && F->ny % 2) || (F->nz > 1 && F->nz % 2)) { /* odd extent */
+            if ((F->nx > 1 && F->nx % 2) || (F->ny > 1 && F->ny % 2) || (F->nz > 1 && F->nz % 2) ||     /* odd extent */
+                (F->nx == 1 && F->ny == 1 && F->nz == 1)) {                                            /* a single cell: nothing left to coarsen */
                 H->levels = l; break;
             }
             L->nx = F->nx > 1 ? F->nx / 2 : 1; L->ny = F->ny > 1 ? F->ny / 2 : 1; L->nz = F->nz > 1 ? F->nz / 2 : 1;
@@ -233,6 +324,7 @@ void oracle_mg_free(mg_hierarchy *H)
     free(H->lv); free(H);
 }
 
+void oracle_mg_set_interpolation(mg_hierarchy *H, int mode) { H->interp = (mode == 1) ? 1 : 0; }
 int oracle_mg_levels(const mg_hierarchy *H) { return H->levels; }
 int64_t oracle_mg_level_rows(const mg_hierarchy *H, int l) { return H->lv[l].n; }
 int64_t oracle_mg_level_nnz(const mg_hierarchy *H, int l) { return H->lv[l].nnz; }
@@ -266,9 +358,11 @@ static void vcycle(mg_hierarchy *H, int l)
     mg_level *C = &H->lv[l + 1];
     smooth(H, L, H->nu, 1);
     oracle_mg_residual(L->elements, L->columnIndeces, L->rowOffsets, L->n, L->b, L->x, L->r);
-    oracle_mg_restrict(L->nx, L->ny, L->nz, L->r, C->b);
+    if (H->interp == 1) oracle_mg_restrict_linear(L->nx, L->ny, L->nz, L->r, C->b);
+    else oracle_mg_restrict(L->nx, L->ny, L->nz, L->r, C->b);
     vcycle(H, l + 1);
-    oracle_mg_prolong_add(L->nx, L->ny, L->nz, L->x, C->x);
+    if (H->interp == 1) oracle_mg_prolong_add_linear(L->nx, L->ny, L->nz, L->x, C->x);
+    else oracle_mg_prolong_add(L->nx, L->ny, L->nz, L->x, C->x);
     smooth(H, L, H->nu, 0);
 }
 

@@ -64,6 +64,9 @@ def lib():
         L.oracle_mg_galerkin.restype = C.c_int
         L.oracle_mg_restrict.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp]
         L.oracle_mg_prolong_add.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp]
+        L.oracle_mg_restrict_linear.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp]
+        L.oracle_mg_prolong_add_linear.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp]
+        L.oracle_mg_set_interpolation.argtypes = [C.c_void_p, C.c_int]
         L.oracle_mg_jacobi_first.argtypes = [C.c_int64, C.c_double, _dp, _dp, _dp]
         L.oracle_mg_jacobi.argtypes = [_dp, _ip, _ip, C.c_int64, C.c_double, _dp, _dp, _dp, _dp]
         L.oracle_mg_residual.argtypes = [_dp, _ip, _ip, C.c_int64, _dp, _dp, _dp]
@@ -194,7 +197,7 @@ def mgcgmain_csr(count, max_nonzero=160):
 class Multigrid:
     """V(nu,nu) weighted-Jacobi geometric multigrid preconditioner (mg_oracle.c)."""
 
-    def __init__(self, system, levels=3, omega=None, nu=1, nu_coarse=4, sigma=0.5):
+    def __init__(self, system, levels=3, omega=None, nu=1, nu_coarse=4, sigma=0.5, interpolation=0):
         nx, ny, nz = system.grid
         if omega is None:
             omega = 6.0 / 7.0 if nz > 1 else 4.0 / 5.0
@@ -203,6 +206,8 @@ class Multigrid:
         self.h = lib().oracle_mg_setup(nx, ny, nz, levels, self._e, self._c, self._r, omega, nu, nu_coarse, sigma)
         self.levels = lib().oracle_mg_levels(self.h)
         self.omega, self.nu, self.nu_coarse, self.sigma = omega, nu, nu_coarse, sigma
+        self.interpolation = int(interpolation)          # 0: piecewise constant, 1: cell-centred linear
+        lib().oracle_mg_set_interpolation(self.h, self.interpolation)
 
     def __del__(self):
         try:

@@ -11,8 +11,9 @@ from tests.gpu_util import assert_trace_close
 pytestmark = pytest.mark.gpu
 
 
-def _mg(system, levels=3, nu=1, nuc=4, sigma=0.5, tol=1e-8, max_it=500, rule=_lib.RULE_CSHARP):
-    cg = ConjugateGradientMgGpu(system.Count, 7, 0, max_it, tol, system.grid, levels=levels, nu=nu, nuCoarse=nuc, sigma=sigma, rule=rule).load(system)
+def _mg(system, levels=3, nu=1, nuc=4, sigma=0.5, tol=1e-8, max_it=500, rule=_lib.RULE_CSHARP, interpolation=0):
+    cg = ConjugateGradientMgGpu(system.Count, 7, 0, max_it, tol, system.grid, levels=levels, nu=nu, nuCoarse=nuc, sigma=sigma, rule=rule,
+                                interpolation=interpolation).load(system)
     cg.Initialize()
     return cg
 
@@ -84,3 +85,38 @@ def test_mg_variable_coefficients(oracle):
     cg.Read()
     assert cg.Iteration == ref["iteration"]
     assert np.abs(cg.x - ref["x"]).max() <= 1e-9 * np.abs(ref["x"]).max()
+
+
+@pytest.mark.parametrize("dims", [(16, 16, 16), (8, 12, 4), (24, 16, 1), (4, 2, 2), (6, 1, 10)])
+def test_linear_transfer_vcycle_bit_exact_vs_oracle(oracle, dims):
+    """MgSetInterpolation(mg, 1): cell-centred linear P and R = P^T, the coarse operators unchanged."""
+    s = problems.poisson(*dims)
+    for (levels, nu, nuc) in [(3, 1, 4), (2, 2, 3), (4, 1, 2)]:
+        M = oracle.Multigrid(s, levels=levels, nu=nu, nu_coarse=nuc, interpolation=1)
+        cg = _mg(s, levels=levels, nu=nu, nuc=nuc, interpolation=1)
+        assert cg.levels == M.levels
+        r = np.random.default_rng(11).standard_normal(s.Count)
+        assert np.array_equal(cg.Apply(r), M.apply(r)), f"{dims} L{levels} nu{nu} nuc{nuc}"
+        cg.Dispose()
+
+
+def test_linear_transfer_cuts_iterations_and_stays_symmetric(oracle):
+    s = problems.poisson(32, 32, 32)
+    cg = _mg(s, levels=4, interpolation=1)
+    rng = np.random.default_rng(9)
+    u, v = rng.standard_normal(s.Count), rng.standard_normal(s.Count)
+    a, b = float(u @ cg.Apply(v)), float(v @ cg.Apply(u))
+    assert abs(a - b) <= 1e-12 * abs(a)
+    ref = oracle.Multigrid(s, levels=4, interpolation=1).pcg(rule=oracle.RULE_CSHARP, max_iteration=500, trace=True)
+    const = oracle.Multigrid(s, levels=4).pcg(rule=oracle.RULE_CSHARP, max_iteration=500)
+    cg.Solve(trace=True)
+    cg.Read()
+    assert cg.Iteration == ref["iteration"] < const["iteration"]
+    assert_trace_close(cg.trace, ref["trace"])
+    assert np.linalg.norm(s.b - s.to_scipy() @ cg.x) < 2e-8
+    # switching back restores the piecewise-constant cycle
+    assert _lib.lib().MgSetInterpolation(cg.mg, 0) == 0
+    assert np.array_equal(cg.Apply(u), oracle.Multigrid(s, levels=4).apply(u))
+    assert _lib.lib().MgSetInterpolation(cg.mg, 7) == -1
+    _lib.lib().MgcgClearLastError()
+    cg.Dispose()

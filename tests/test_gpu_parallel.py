@@ -224,8 +224,9 @@ def test_native_multirank_loop_over_loopback(oracle, monkeypatch, world, which, 
     assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
 
 
-@pytest.mark.parametrize("world,dims,levels", [(2, (8, 8, 16), 3), (4, (16, 8, 16), 2), (2, (12, 12, 8), 3)])
-def test_distributed_multigrid_over_loopback(oracle, monkeypatch, world, dims, levels):
+@pytest.mark.parametrize("world,dims,levels,interpolation", [(2, (8, 8, 16), 3, 0), (4, (16, 8, 16), 2, 0), (2, (12, 12, 8), 3, 0),
+                                                            (2, (8, 8, 16), 3, 1), (4, (16, 8, 16), 2, 1), (3, (8, 4, 24), 3, 1)])
+def test_distributed_multigrid_over_loopback(oracle, monkeypatch, world, dims, levels, interpolation):
     """Row-partitioned MGCG (config 4 in miniature): slab-local Galerkin set-up, per-level halo planes, V-cycle
     bit-identical to the single-domain oracle, PCG within the dot-product tolerance."""
     from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu
@@ -236,13 +237,14 @@ def test_distributed_multigrid_over_loopback(oracle, monkeypatch, world, dims, l
     s = problems.poisson(*dims)
     rng = np.random.default_rng(3)
     s.b[:] = rng.standard_normal(s.Count)
-    M = oracle.Multigrid(s, levels=levels)
+    M = oracle.Multigrid(s, levels=levels, interpolation=interpolation)
     ref = M.pcg(rule=oracle.RULE_CSHARP, max_iteration=400, trace=True)
     rvec = rng.standard_normal(s.Count)
     zref = M.apply(rvec)
 
     def make_rank(rank, comm):
-        cg = ConjugateGradientMgRankGpu(s.Count, 7, 0, 400, 1e-8, s.grid, rank=rank, world=world, comm=comm, device=rank, levels=levels).load(s)
+        cg = ConjugateGradientMgRankGpu(s.Count, 7, 0, 400, 1e-8, s.grid, rank=rank, world=world, comm=comm, device=rank, levels=levels,
+                                        interpolation=interpolation).load(s)
         cg.Initialize()
         cg.Setup()
         assert cg.levels == M.levels

@@ -96,3 +96,75 @@ def test_pcg_iteration_counts_and_fixture(oracle):
 def test_levels_clip_to_the_grid(oracle):
     assert oracle.Multigrid(problems.poisson(12, 12, 12), levels=6).levels == 3     # 12 -> 6 -> 3 (odd: stop)
     assert oracle.Multigrid(problems.poisson(16, 16, 1), levels=3).level_dims(2) == (4, 4, 1)
+    assert oracle.Multigrid(problems.poisson(4, 2, 2), levels=5).levels == 3        # (4,2,2) -> (2,1,1) -> (1,1,1): a single cell ends it
+
+
+# ---------------------------------------------------------------- cell-centred linear transfer (interpolation = 1)
+def linear_1d(n):
+    """child i: 3/4 of parent i//2, 1/4 of the parent's neighbour on the child's side (nothing outside the grid)"""
+    if n == 1:
+        return sp.identity(1, format="csr")
+    m = n // 2
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        I = i // 2
+        J = I - 1 if i % 2 == 0 else I + 1
+        rows.append(i); cols.append(I); vals.append(0.75)
+        if 0 <= J < m:
+            rows.append(i); cols.append(J); vals.append(0.25)
+    return sp.csr_matrix((vals, (rows, cols)), shape=(n, m))
+
+
+def linear_prolongation(nx, ny, nz):
+    return sp.kron(sp.kron(linear_1d(nz), linear_1d(ny)), linear_1d(nx)).tocsr()
+
+
+@pytest.mark.parametrize("dims", [(8, 8, 8), (12, 8, 4), (16, 12, 1), (2, 2, 2), (4, 1, 6)])
+def test_linear_transfer_matches_scipy(oracle, dims):
+    P = linear_prolongation(*dims)
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal(P.shape[0])
+    bc = np.empty(P.shape[1])
+    oracle.lib().oracle_mg_restrict_linear(*dims, v, bc)
+    np.testing.assert_allclose(bc, P.T @ v, rtol=1e-13, atol=1e-14)
+    ec = rng.standard_normal(P.shape[1])
+    xx = v.copy()
+    oracle.lib().oracle_mg_prolong_add_linear(*dims, xx, ec)
+    np.testing.assert_allclose(xx, v + P @ ec, rtol=1e-13, atol=1e-14)
+    # interior rows of P sum to one: constants are interpolated exactly away from the boundary
+    if min(d for d in dims if d > 1) >= 8:
+        assert np.asarray(P.sum(axis=1)).ravel().max() == 1.0
+
+
+def test_linear_vcycle_equals_the_matrix_formula_and_is_spd(oracle):
+    dims = (8, 8, 8)
+    s = problems.poisson(*dims)
+    A, P0, P = s.to_scipy(), prolongation(*dims), linear_prolongation(*dims)
+    omega, nuc = 6.0 / 7.0, 3
+    M = oracle.Multigrid(s, levels=2, nu=1, nu_coarse=nuc, omega=omega, sigma=0.5, interpolation=1)
+    Ac = 0.5 * (P0.T @ A @ P0)                            # the coarse operator does not change with the transfer
+    Dinv, Dcinv = sp.diags(1.0 / A.diagonal()), sp.diags(1.0 / Ac.diagonal())
+    r = np.random.default_rng(1).standard_normal(s.Count)
+    x = omega * (Dinv @ r)
+    bc = P.T @ (r - A @ x)
+    ec = omega * (Dcinv @ bc)
+    for _ in range(nuc - 1):
+        ec = ec + omega * (Dcinv @ (bc - Ac @ ec))
+    x = x + P @ ec
+    x = x + omega * (Dinv @ (r - A @ x))
+    np.testing.assert_allclose(M.apply(r), x, rtol=1e-12, atol=1e-14)
+    M3 = oracle.Multigrid(s, levels=3, interpolation=1)
+    Minv = np.column_stack([M3.apply(np.eye(s.Count)[:, j]) for j in range(s.Count)])
+    assert np.abs(Minv - Minv.T).max() < 1e-13
+    assert np.linalg.eigvalsh(0.5 * (Minv + Minv.T)).min() > 0
+
+
+def test_linear_transfer_needs_fewer_iterations(oracle):
+    counts = {}
+    for n in (16, 32):
+        sn = problems.poisson(n, n, n)
+        const = oracle.Multigrid(sn, levels=4).pcg(rule=oracle.RULE_CSHARP, max_iteration=500)
+        lin = oracle.Multigrid(sn, levels=4, interpolation=1).pcg(rule=oracle.RULE_CSHARP, max_iteration=500)
+        assert np.abs(lin["x"] - const["x"]).max() < 1e-7
+        counts[n] = (const["iteration"], lin["iteration"])
+    assert counts[32][1] < counts[32][0] and counts[32][1] <= counts[16][1] + 2     # nearly grid independent
