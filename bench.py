@@ -188,12 +188,13 @@ def mgcg_extra(L, n: int):
     vb, shell = vcycle_bytes(n, levels, nu, nuc)
     out = {"config": f"MGCG, V({nu},{nu}) cycle, {levels} levels, weighted Jacobi (omega = 6/7), {nuc} coarse sweeps, 7-pt Poisson {n}^3, b = 1, x0 = 0, stop at ||r|| <= 1e-8 ||b||",
            "algorithmic_bytes_per_iteration": vb + shell, "vcycle_algorithmic_bytes": vb}
-    # third row: the same solver with the hierarchy taken down to 4^3 and V(2,2) -- what a caller who is free to choose
-    # the cycle would run (profiles/r2/mgcg_levels_sweep_512_csr.log); its bytes are its own
-    deep = (8, 2, 8) if n == 512 else None
-    rows = [("csr", 0, (levels, nu, nuc)), ("row_pattern", 1, (levels, nu, nuc))] + ([("csr_8_levels_v22", 0, deep)] if deep else [])
-    for key, mode, (lv_, nu_, nuc_) in rows:
-        mg = ConjugateGradientMgGpu(N, 7, 0, 5000, tol, (n, n, n), levels=lv_, nu=nu_, nuCoarse=nuc_, rule=_lib.RULE_CSHARP)
+    # third row: what a caller who is free to choose the cycle would run -- the hierarchy taken down to 4^3 and the cell-centred
+    # linear transfer (MgSetInterpolation; profiles/r2/mgcg_levels_sweep_512_csr*.log); its bytes are its own (the transfers
+    # move the same HBM bytes, their extra operands come from cache)
+    deep = (8, 1, 4) if n == 512 else None
+    rows = [("csr", 0, (levels, nu, nuc), 0), ("row_pattern", 1, (levels, nu, nuc), 0)] + ([("csr_8_levels_linear_transfer", 0, deep, 1)] if deep else [])
+    for key, mode, (lv_, nu_, nuc_), interp in rows:
+        mg = ConjugateGradientMgGpu(N, 7, 0, 5000, tol, (n, n, n), levels=lv_, nu=nu_, nuCoarse=nuc_, rule=_lib.RULE_CSHARP, interpolation=interp)
         vb_, shell_ = vcycle_bytes(n, lv_, nu_, nuc_)
         try:
             L.MgcgSetMatrixCompression(mg.cusparse, mode)
@@ -213,7 +214,7 @@ def mgcg_extra(L, n: int):
                         "achieved_gbps": ((vb_ + shell_) / (ms * 1e-3) / 1e9) if mode == 0 else None,
                         "frac_of_peak": ((vb_ + shell_) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if mode == 0 else None}
             if key != "csr" and mode == 0:
-                out[key]["config"] = f"V({nu_},{nu_}), {lv_} levels, {nuc_} coarse sweeps"
+                out[key]["config"] = f"V({nu_},{nu_}), {lv_} levels, {nuc_} coarse sweeps" + (", cell-centred linear transfer" if interp else "")
                 out[key]["algorithmic_bytes_per_iteration"] = vb_ + shell_
         finally:
             mg.Dispose()
