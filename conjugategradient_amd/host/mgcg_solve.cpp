@@ -1,7 +1,7 @@
 // mgcg_solve -- command-line driver over the C ABI (SURVEY.md section 5 "config / flags": the reference fixes its
 // problem in compile-time constants of each Main; here they are flags).  Builds a 5/7-point Poisson system in HBM,
 // runs CG or MGCG on device 0 and prints one JSON line.
-//   mgcg_solve [--nx N] [--ny N] [--nz N] [--mgcg] [--levels L] [--nu K] [--nu-coarse K] [--omega W] [--tol T] [--rel-tol T]
+//   mgcg_solve [--nx N] [--ny N] [--nz N] [--mgcg] [--levels L] [--nu K] [--nu-coarse K] [--omega W] [--linear-transfer] [--tol T] [--rel-tol T]
 //              [--min-it I] [--max-it I] [--rule native|csharp|simple|viennacl|handmadecl] [--compression 0|1|2] [--b V] [--x0 V]
 #include <chrono>
 #include <cmath>
@@ -28,7 +28,7 @@ int main(int argc, char** argv)
 {
     int nx = 64, ny = 64, nz = 64, levels = 3, nu = 1, nuCoarse = 4, minIt = 0, maxIt = -1, compression = 1;
     double omega = 0, tol = 1e-8, relTol = 0, bValue = 1.0, x0Value = 0.0;
-    bool mgcg = false;
+    bool mgcg = false, linearTransfer = false;
     std::string rule = "csharp";
     try {
         for (int i = 1; i < argc; ++i) {
@@ -37,6 +37,7 @@ int main(int argc, char** argv)
             if (a == "--nx") nx = std::atoi(val()); else if (a == "--ny") ny = std::atoi(val()); else if (a == "--nz") nz = std::atoi(val());
             else if (a == "--n") { nx = ny = nz = std::atoi(val()); }
             else if (a == "--mgcg") mgcg = true;
+            else if (a == "--linear-transfer") linearTransfer = true;
             else if (a == "--levels") levels = std::atoi(val()); else if (a == "--nu") nu = std::atoi(val()); else if (a == "--nu-coarse") nuCoarse = std::atoi(val());
             else if (a == "--omega") omega = std::atof(val()); else if (a == "--tol") tol = std::atof(val()); else if (a == "--rel-tol") relTol = std::atof(val());
             else if (a == "--min-it") minIt = std::atoi(val()); else if (a == "--max-it") maxIt = std::atoi(val());
@@ -69,6 +70,7 @@ int main(int argc, char** argv)
             MgcgDeviceSynchronize();
             setupS = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (!mg) { Check("MgSetup"); throw MgcgError("MgSetup failed"); }
+            if (linearTransfer && MgSetInterpolation(mg, 1) != 0) { Check("MgSetInterpolation"); throw MgcgError("MgSetInterpolation failed"); }
         }
         int iteration = 0; double residual = 0;
         const auto t0 = std::chrono::steady_clock::now();               // Solve() only, like MgcgMain.cs:121-126

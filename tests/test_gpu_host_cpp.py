@@ -73,5 +73,9 @@ def test_command_line_driver(oracle):
     rec = run("--n", "16", "--mgcg", "--levels", "3", "--compression", "1")
     assert rec["levels"] == 3 and rec["iteration"] == mref["iteration"]
     assert abs(rec["sum_x"] - mref["x"].sum()) <= 1e-9 * np.abs(mref["x"]).sum()
+    lref = oracle.Multigrid(s, levels=3, interpolation=1).pcg(rule=oracle.RULE_CSHARP, max_iteration=400)
+    rec = run("--n", "16", "--mgcg", "--levels", "3", "--linear-transfer", "--compression", "0")
+    assert rec["iteration"] == lref["iteration"] < mref["iteration"]
+    assert abs(rec["sum_x"] - lref["x"].sum()) <= 1e-9 * np.abs(lref["x"]).sum()
     bad = subprocess.run([exe, "--rule", "nonsense"], capture_output=True, text=True)
     assert bad.returncode == 1 and "unknown --rule" in bad.stderr

@@ -167,3 +167,20 @@ def test_bench_vcycle_bytes_formula():
     assert (v, s) == (fine + coarse, shell)
     v, s = bench.vcycle_bytes(512, 3, 1, 4)
     assert v == 42127196160 and v + s == 65730641924
+
+
+def test_device_workers_under_thread_sanitizer(tmp_path):
+    """host/Mgcg.hpp DeviceWorkers (the long-lived per-device threads behind the C++ twin's Parallel.For): race-free hand-over
+    of phases and results, exceptions surface once."""
+    import os
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "workers"
+    src = os.path.join(ROOT, "tests", "host_workers_check.cpp")
+    inc = os.path.join(ROOT, "conjugategradient_amd", "host")
+    build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", "-I" + inc, src, "-o", str(exe)], capture_output=True, text=True)
+    if build.returncode != 0:                                   # no libtsan on this host: the plain build still checks the logic
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-I" + inc, src, "-o", str(exe)])
+    for n, phases in ((8, 4000), (1, 100), (3, 2000)):
+        out = subprocess.run([str(exe), str(n), str(phases)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and "ok 2" in out.stdout and "WARNING: ThreadSanitizer" not in out.stderr, out.stdout + out.stderr
