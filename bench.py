@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--grid", type=int, default=512, help="n for the n^3 7-point Poisson grid (BASELINE config: 512)")
     ap.add_argument("--solver", choices=["cg", "mgcg"], default="cg")
+    ap.add_argument("--mg-levels", type=int, default=3, help="--solver mgcg: hierarchy depth (BASELINE config 3/4: 3)")
+    ap.add_argument("--mg-nu", type=int, default=1, help="--solver mgcg: pre/post Jacobi sweeps")
+    ap.add_argument("--mg-nu-coarse", type=int, default=4, help="--solver mgcg: sweeps on the coarsest level")
+    ap.add_argument("--mg-interpolation", type=int, default=0, choices=[0, 1], help="--solver mgcg: 0 piecewise-constant transfer (default), 1 cell-centred linear")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=4, help="CG iterations of the CPU oracle sample")
     ap.add_argument("--no-compression", action="store_true", help="(default) plain CSR inside the loop")
@@ -315,7 +319,7 @@ def main():
 
         # fixed-length runs: rule NATIVE with an infinite tolerance stops exactly at index minIteration
         cg = ConjugateGradientMgRankGpu(N, 7, 0, 10**9, 1e300, (n, n, n), rank=rank, world=world, device=local_rank,
-                                        rule=_lib.RULE_NATIVE, levels=3, nu=1, nuCoarse=4)
+                                        rule=_lib.RULE_NATIVE, levels=a.mg_levels, nu=a.mg_nu, nuCoarse=a.mg_nu_coarse, interpolation=a.mg_interpolation)
     else:
         cg = ConjugateGradientRankGpu(N, 7, 0, 10**9, 1e-8, rank=rank, world=world, device=local_rank)
     if a.compression is None:
@@ -455,6 +459,8 @@ def main():
         achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
         nnz_total = 7 * N - 6 * n * n
         iter_bytes = 12 * nnz_total + 4 * (N + 1) + 16 * N + 72 * N
+        if a.solver == "mgcg":                              # V-cycle + shell (SURVEY.md 8d per-pass formulas)
+            iter_bytes = sum(vcycle_bytes(n, a.mg_levels, a.mg_nu, a.mg_nu_coarse))
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", "spmv_traffic.json")
         if os.path.exists(pmc_file) and world == 1:
@@ -466,7 +472,7 @@ def main():
                 traffic = None
         out = {
             "metric": (f"CG iterations/sec (7-pt Poisson {n}^3); SpMV achieved HBM GB/s in roofline" if a.solver == "cg"
-                       else f"MGCG iterations/sec (3-level V(1,1) Jacobi, 7-pt Poisson {n}^3)"),
+                       else f"MGCG iterations/sec ({a.mg_levels}-level V({a.mg_nu},{a.mg_nu}) Jacobi{', linear transfer' if a.mg_interpolation else ''}, 7-pt Poisson {n}^3)"),
             "value": a.steps / dt,
             "unit": "iterations/s",
             "n_gpus": world,

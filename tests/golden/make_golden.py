@@ -63,3 +63,10 @@ if __name__ == "__main__":
                         dinv0=M.level_dinv(0), dinv2=M.level_dinv(2), pcg_iteration=res["iteration"], pcg_residual=res["residual"],
                         pcg_trace=res["trace"], pcg_x=res["x"], x_direct=direct(s))
     print("mg_poisson7_16 pcg iteration", res["iteration"], res["residual"], np.abs(res["x"] - direct(s)).max())
+    # the same with the cell-centred linear transfer (MgSetInterpolation(mg, 1)); coarse operators are those above
+    ML = O.Multigrid(s, levels=3, nu=1, nu_coarse=4, sigma=0.5, interpolation=1)
+    zl = ML.apply(r)
+    resl = ML.pcg(rule=O.RULE_CSHARP, allowable_residual=1e-8, max_iteration=500, trace=True)
+    np.savez_compressed(os.path.join(OUT, "mg_poisson7_16_linear.npz"), r=r, z=zl, pcg_iteration=resl["iteration"], pcg_residual=resl["residual"],
+                        pcg_trace=resl["trace"], pcg_x=resl["x"], x_direct=direct(s))
+    print("mg_poisson7_16_linear pcg iteration", resl["iteration"], resl["residual"], np.abs(resl["x"] - direct(s)).max())

@@ -120,3 +120,16 @@ def test_linear_transfer_cuts_iterations_and_stays_symmetric(oracle):
     assert _lib.lib().MgSetInterpolation(cg.mg, 7) == -1
     _lib.lib().MgcgClearLastError()
     cg.Dispose()
+
+
+def test_linear_transfer_fixture_16cubed():
+    g = golden("mg_poisson7_16_linear")
+    cg = _mg(problems.poisson(16, 16, 16), interpolation=1)
+    assert np.array_equal(cg.Apply(g["r"]), g["z"])
+    cg.Solve(trace=True)
+    cg.Read()
+    assert cg.Iteration == int(g["pcg_iteration"])
+    assert_trace_close(cg.trace, g["pcg_trace"])
+    assert np.abs(cg.x - g["pcg_x"]).max() <= 1e-10 * np.abs(g["pcg_x"]).max()
+    assert np.abs(cg.x - g["x_direct"]).max() <= 1e-8 * np.abs(g["x_direct"]).max()
+    cg.Dispose()

@@ -168,3 +168,13 @@ def test_linear_transfer_needs_fewer_iterations(oracle):
         assert np.abs(lin["x"] - const["x"]).max() < 1e-7
         counts[n] = (const["iteration"], lin["iteration"])
     assert counts[32][1] < counts[32][0] and counts[32][1] <= counts[16][1] + 2     # nearly grid independent
+
+
+def test_linear_transfer_fixture(oracle):
+    g = golden("mg_poisson7_16_linear")
+    s = problems.poisson(16, 16, 16)
+    M = oracle.Multigrid(s, interpolation=1)
+    res = M.pcg(rule=oracle.RULE_CSHARP, max_iteration=500, trace=True)
+    assert res["iteration"] == int(g["pcg_iteration"]) == 12
+    assert np.array_equal(res["x"], g["pcg_x"]) and np.array_equal(M.apply(g["r"]), g["z"])
+    assert np.abs(res["x"] - g["x_direct"]).max() < 1e-9
