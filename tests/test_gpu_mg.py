@@ -87,7 +87,7 @@ def test_mg_variable_coefficients(oracle):
     assert np.abs(cg.x - ref["x"]).max() <= 1e-9 * np.abs(ref["x"]).max()
 
 
-@pytest.mark.parametrize("dims", [(16, 16, 16), (8, 12, 4), (24, 16, 1), (4, 2, 2), (6, 1, 10)])
+@pytest.mark.parametrize("dims", [(16, 16, 16), (8, 12, 4), (24, 16, 1), (4, 2, 2), (6, 1, 10), (1, 8, 12), (520, 4, 2)])
 def test_linear_transfer_vcycle_bit_exact_vs_oracle(oracle, dims):
     """MgSetInterpolation(mg, 1): cell-centred linear P and R = P^T, the coarse operators unchanged."""
     s = problems.poisson(*dims)

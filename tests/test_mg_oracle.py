@@ -119,7 +119,7 @@ def linear_prolongation(nx, ny, nz):
     return sp.kron(sp.kron(linear_1d(nz), linear_1d(ny)), linear_1d(nx)).tocsr()
 
 
-@pytest.mark.parametrize("dims", [(8, 8, 8), (12, 8, 4), (16, 12, 1), (2, 2, 2), (4, 1, 6)])
+@pytest.mark.parametrize("dims", [(8, 8, 8), (12, 8, 4), (16, 12, 1), (2, 2, 2), (4, 1, 6), (1, 8, 12)])
 def test_linear_transfer_matches_scipy(oracle, dims):
     P = linear_prolongation(*dims)
     rng = np.random.default_rng(3)
