@@ -182,26 +182,41 @@ __global__ __launch_bounds__(kBlock) void prolong_linear_add_rows_kernel(int nx,
     const int ty = kBlock / tx;
     const int lx = threadIdx.x % tx, ly = threadIdx.x / tx;
     const long long rows = (long long)ny * (z1 - z0);
-    for (long long row = (long long)blockIdx.x * ty + ly; row < rows; row += (long long)gridDim.x * ty) {
-        const int yy = (int)(row % ny), zz = z0 + (int)(row / ny);
+    // workgroup b runs on XCD b % 8 (each with its own L2): XCD k sweeps the k-th eighth of the rows, so that the coarse rows a fine
+    // row shares with its neighbours are fetched into one L2 instead of eight
+    const long long band = (rows + 7) / 8;
+    const long long bandBegin = (blockIdx.x & 7) * band, bandEnd = bandBegin + band < rows ? bandBegin + band : rows;
+    for (long long row = bandBegin + (long long)(blockIdx.x >> 3) * ty + ly; row < bandEnd; row += (long long)(gridDim.x >> 3) * ty) {
+        const unsigned r32 = (unsigned)row;                       // rows < 2^31 (the vector has fewer entries than that): 32-bit division
+        const int yy = (int)(r32 % (unsigned)ny), zz = z0 + (int)(r32 / (unsigned)ny);
         int iz[2], iy[2]; double wz[2], wy[2];
         const int kz = lin_terms(zz, nz, iz, wz), ky = lin_terms(yy, ny, iy, wy);
         d2mg* xr = (d2mg*)(x + row * nx);
+        if (kz == 1) { iz[1] = iz[0]; wz[1] = 0.0; }                 // absent terms: a valid address, and (below) +0.0 instead of their product
+        if (ky == 1) { iy[1] = iy[0]; wy[1] = 0.0; }
         for (int X = lx; X < NX; X += tx) {
             const bool hasL = X > 0, hasR = X + 1 < NX;
+            const int XL = hasL ? X - 1 : X, XR = hasR ? X + 1 : X;
+            // all twelve coarse operands are loaded before the first is used (four dependent round trips otherwise); a term that does
+            // not exist contributes +0.0, which leaves a sum that started at +0.0 bit for bit as it was
+            double eC[4], eL[4], eR[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double* er = eFull + ((long long)iz[t >> 1] * NY + iy[t & 1]) * NX;
+                eC[t] = er[X]; eL[t] = er[XL]; eR[t] = er[XR];
+            }
             double sumL = 0.0, sumR = 0.0;
-            for (int a = 0; a < kz; ++a)
-                for (int b = 0; b < ky; ++b) {
-                    const double wzy = wz[a] * wy[b];
-                    const double* er = eFull + ((long long)iz[a] * NY + iy[b]) * NX;
-                    const double eC = er[X];
-                    const double eL = hasL ? er[X - 1] : 0.0, eR = hasR ? er[X + 1] : 0.0;
-                    const double w3 = wzy * 0.75, w1 = wzy * 0.25;
-                    const double tC = w3 * eC;
-                    sumL += tC; sumR += tC;
-                    if (hasL) { const double t = w1 * eL; sumL += t; }
-                    if (hasR) { const double t = w1 * eR; sumR += t; }
-                }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool term = (t >> 1) < kz && (t & 1) < ky;
+                const double wzy = wz[t >> 1] * wy[t & 1];
+                const double w3 = wzy * 0.75, w1 = wzy * 0.25;
+                const double pC = w3 * eC[t], pL = w1 * eL[t], pR = w1 * eR[t];
+                const double tC = term ? pC : 0.0;
+                sumL += tC; sumR += tC;
+                sumL += (term && hasL) ? pL : 0.0;
+                sumR += (term && hasR) ? pR : 0.0;
+            }
             d2mg v = xr[X];
             v.x = v.x + sumL; v.y = v.y + sumR;
             xr[X] = v;
@@ -214,7 +229,7 @@ void launch_prolong_linear_add(hipStream_t s, int nx, int ny, int nz, int z0, in
     if (nx >= 2 && (nx & 1) == 0 && (((uintptr_t)x) & 15) == 0) {
         const int tx = rows_tx(nx / 2), ty = kBlock / tx;
         const long long rows = (long long)ny * (z1 - z0);
-        long long g = (rows + ty - 1) / ty; if (g > kMaxGrid) g = kMaxGrid; if (g < 1) g = 1;
+        long long g = ((rows + 7) / 8 + ty - 1) / ty * 8; if (g > kMaxGrid) g = kMaxGrid; if (g < 8) g = 8;      // a multiple of 8: whole XCD rounds
         hipLaunchKernelGGL(prolong_linear_add_rows_kernel, dim3((int)g), dim3(kBlock), 0, s, nx, ny, nz, z0, z1, tx, x, eFull, done);
         return;
     }
@@ -274,24 +289,41 @@ __global__ __launch_bounds__(kBlock) void restrict_linear_rows_kernel(int nx, in
         first = lo < 0 ? 0 : lo; count = (hi >= n ? n - 1 : hi) - first + 1; quarterFirst = lo < 0 ? 0 : 1;
     };
     auto weight = [](int k, int q) { if (q < 0) return 1.0; const int rel = k + (1 - q); return (rel == 0 || rel == 3) ? 0.25 : 0.75; };
-    for (long long row = (long long)blockIdx.x * ty + ly; row < rows; row += (long long)gridDim.x * ty) {
-        const int Y = (int)(row % NY), Z = Z0 + (int)(row / NY);
+    // XCD k sweeps the k-th eighth of the coarse rows (see the prolongation): the fine rows two coarse rows share stay in one L2
+    const long long band = (rows + 7) / 8;
+    const long long bandBegin = (blockIdx.x & 7) * band, bandEnd = bandBegin + band < rows ? bandBegin + band : rows;
+    for (long long row = bandBegin + (long long)(blockIdx.x >> 3) * ty + ly; row < bandEnd; row += (long long)(gridDim.x >> 3) * ty) {
+        const unsigned r32 = (unsigned)row;
+        const int Y = (int)(r32 % (unsigned)NY), Z = Z0 + (int)(r32 / (unsigned)NY);
         int fz, nzT, qz, fy, nyT, qy;
         span(Z, nz, fz, nzT, qz); span(Y, ny, fy, nyT, qy);
         for (int X = lx; X < NX; X += tx) {
             const bool hasL = X > 0, hasR = 2 * X + 2 < nx;
+            // the eight (z, y) rows of two z terms are loaded before the first is used; a term that does not exist reads a valid
+            // address and contributes +0.0 (bitwise neutral for a sum that started at +0.0)
+            const int oL = hasL ? -1 : 0, oR = hasR ? 2 : 0;
             double sum = 0.0;
-            for (int a = 0; a < nzT; ++a) {
-                const double wza = weight(a, qz);
-                for (int b = 0; b < nyT; ++b) {
-                    const double wzy = wza * weight(b, qy);
-                    const double* rr = rFull + ((long long)(fz + a) * ny + (fy + b)) * nx + 2 * X;
-                    const d2mg mid = *(const d2mg*)rr;
+#pragma unroll
+            for (int a0 = 0; a0 < 4; a0 += 2) {
+                d2mg mid[8]; double left[8], right[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int a = a0 + (t >> 2), b = t & 3;
+                    const int za = a < nzT ? a : 0, yb = b < nyT ? b : 0;
+                    const double* rr = rFull + ((long long)(fz + za) * ny + (fy + yb)) * nx + 2 * X;
+                    mid[t] = *(const d2mg*)rr; left[t] = rr[oL]; right[t] = rr[oR];
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int a = a0 + (t >> 2), b = t & 3;
+                    const bool term = a < nzT && b < nyT;
+                    const double wzy = weight(a, qz) * weight(b, qy);
                     const double w3 = wzy * 0.75, w1 = wzy * 0.25;
-                    if (hasL) { const double t = w1 * rr[-1]; sum += t; }
-                    { const double t = w3 * mid.x; sum += t; }
-                    { const double t = w3 * mid.y; sum += t; }
-                    if (hasR) { const double t = w1 * rr[2]; sum += t; }
+                    const double pl = w1 * left[t], p0 = w3 * mid[t].x, p1 = w3 * mid[t].y, pr = w1 * right[t];
+                    sum += (term && hasL) ? pl : 0.0;
+                    sum += term ? p0 : 0.0;
+                    sum += term ? p1 : 0.0;
+                    sum += (term && hasR) ? pr : 0.0;
                 }
             }
             bc[row * NX + X] = sum;
@@ -303,7 +335,7 @@ void launch_restrict_linear(hipStream_t s, int nx, int ny, int nz, int z0, int z
     if (nx >= 2 && (nx & 1) == 0 && (((uintptr_t)rFull) & 15) == 0) {
         const int tx = rows_tx(nx / 2), ty = kBlock / tx;
         const long long rows = (long long)(ny > 1 ? ny / 2 : 1) * ((z1 - z0) / (nz > 1 ? 2 : 1));
-        long long g = (rows + ty - 1) / ty; if (g > kMaxGrid) g = kMaxGrid; if (g < 1) g = 1;
+        long long g = ((rows + 7) / 8 + ty - 1) / ty * 8; if (g > kMaxGrid) g = kMaxGrid; if (g < 8) g = 8;
         hipLaunchKernelGGL(restrict_linear_rows_kernel, dim3((int)g), dim3(kBlock), 0, s, nx, ny, nz, z0, z1, tx, rFull, bc, done);
         return;
     }
