@@ -38,9 +38,13 @@ int main(int argc, char** argv)
     const size_t slack = 256 * MiB;
     const size_t total = szE + szC + szR + 2 * (szV + slack) + gran;
     void* base = nullptr;
-    const int how = argc > 3 ? atoi(argv[3]) : 0;      // 0: hipMemCreate + hipMemMap, 1: one hipMalloc, 2: VMM with 2 MiB granularity and 1 GiB aligned reserve
+    const int how = argc > 3 ? atoi(argv[3]) : 0;
+    if (how == 4 || how == 5) { CK(hipMalloc(&base, 4096)); }
+    else      // 0: hipMemCreate + hipMemMap, 1: one hipMalloc, 2: VMM with 2 MiB granularity and 1 GiB aligned reserve
     if (how == 1) {
         CK(hipMalloc(&base, total));
+    } else if (how == 3) {
+        CK(hipExtMallocWithFlags(&base, total, hipDeviceMallocContiguous));       // physically contiguous VRAM
     } else {
         if (how == 2) gran = 2 * MiB;
         const size_t tot2 = (total + gran - 1) / gran * gran;
@@ -58,6 +62,15 @@ int main(int argc, char** argv)
     int* r = (int*)p; p += szR;
     char* yRegion = p; p += szV + slack;
     char* xRegion = p;
+    if (how == 4 || how == 5) {                        // one allocation per array: 4 physically contiguous, 5 default (the library's way)
+        const unsigned fl = how == 4 ? hipDeviceMallocContiguous : hipDeviceMallocDefault;
+        void* q = nullptr;
+        CK(hipExtMallocWithFlags(&q, szE, fl)); e = (double*)q;
+        CK(hipExtMallocWithFlags(&q, szC, fl)); c = (int*)q;
+        CK(hipExtMallocWithFlags(&q, szR, fl)); r = (int*)q;
+        CK(hipExtMallocWithFlags(&q, szV + slack, fl)); yRegion = (char*)q;
+        CK(hipExtMallocWithFlags(&q, szV + slack, fl)); xRegion = (char*)q;
+    }
     printf("granularity %zu KiB, arena %.2f GiB at %p: e +0, c +%zu MiB, r +%zu MiB, y +%zu MiB, x +%zu MiB\n", gran >> 10, total / 1073741824.0, base,
            (size_t)((char*)c - (char*)base) / MiB, (size_t)((char*)r - (char*)base) / MiB, (size_t)(yRegion - (char*)base) / MiB, (size_t)(xRegion - (char*)base) / MiB);
     CK(hipMemcpy(e, ToRawPtr_Double(ve), 8 * (size_t)nnz, hipMemcpyDeviceToDevice));
