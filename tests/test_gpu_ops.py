@@ -1,5 +1,6 @@
 """HIP kernels vs the CPU oracle, through the C ABI (raw-device-pointer ops of Mgcg.cu:10-54)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -124,7 +125,7 @@ def test_csrmv_rowtile_slow_blocks_and_ragged_ends(h, oracle):
         assert np.array_equal(got, ref), (M.shape, M.nnz)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MGCG_FUZZ_SEEDS", "12"))))     # MGCG_FUZZ_SEEDS=400 for a long soak
 def test_csrmv_rowtile_random_shapes(h, oracle, seed):
     """Randomised shapes for the row-tile kernel: sizes around the tile and block boundaries, densities that mix the fast path
     (rows <= 7 / 8, spans <= 512) with slow blocks, empty rows, unsorted columns, nnz of every residue mod 4; CsrMV and the
