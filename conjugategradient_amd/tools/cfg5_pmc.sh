@@ -1,12 +1,12 @@
 #!/bin/bash
-# BASELINE config 5 (random SPD, 10 M rows) evidence: per-kernel stats and PMC passes of tools/cfg5_run.py --no-solve
+# BASELINE config 5 (random SPD, 10 M rows) evidence: per-kernel stats and PMC passes of tests/perf/cfg5_run.py --no-solve
 # (run on the GPU box from the repo root):  bash conjugategradient_amd/tools/cfg5_pmc.sh OUTDIR [rows]
 set -u
 OUT=$1; ROWS=${2:-10000000}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 export PYTHONPATH=$GRAFT_REPO_ROOT
-RUN="python3 $GRAFT_REPO_ROOT/conjugategradient_amd/tools/cfg5_run.py --no-solve --reps 5 --rows $ROWS"
+RUN="python3 $GRAFT_REPO_ROOT/tests/perf/cfg5_run.py --no-solve --reps 5 --rows $ROWS"
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/stats" -- $RUN) > "$OUT/stats.log" 2>&1
 echo "stats rc=$?"
 pass() { local name=$1; shift

@@ -2,6 +2,7 @@
 """BASELINE.json config 5 at full size (random SPD, N = 10 M, ~30 nnz/row, irregular): SpMV of every kernel family against
 the CPU oracle's product, timing, and the whole solve against a manufactured solution.  Prints one JSON line.
 Host generation needs ~25 GB of RAM and a few minutes; --rows scales it down."""
+# Lives under tests/ (not in the package) because it checks the GPU products against the CPU oracle: the oracle is test infrastructure.
 import argparse
 import json
 import os

@@ -3,6 +3,7 @@
 MIN_ITERATION = 200): the C++ twin host/MgcgMain (single device and the host-driven multi-device phases) next to the CPU
 oracle on the same system.  The reference prints "ticks per iteration" for CPU / 1 GPU / N GPUs (MgcgMain.cs:165-167); this
 prints the same three figures as one JSON line."""
+# Lives under tests/ (not in the package) because it times the CPU oracle next to the GPU driver: the oracle is test infrastructure.
 import json
 import os
 import subprocess
