@@ -70,6 +70,10 @@ struct CgScalars {
     int done;         // set by the finalisation kernel; every later kernel exits at once
     int status;
     int pad;          // "x pending": set by the finalisation kernel for update_xp, cleared when no iteration ran
+    // Copy of {rr, rr0, alpha, iteration, done} taken by update_r for the x/p update that also finalises the iteration
+    // (single rank, no preconditioner): that kernel's workgroups read these while its first workgroup rewrites the live fields
+    double fRr, fRr0, fAlpha;
+    int fIteration, fDone;
 };
 
 static_assert(offsetof(CgScalars, rzNew) == offsetof(CgScalars, rrNew) + sizeof(double), "{rrNew, rzNew} are all-reduced as one pair");
@@ -290,8 +294,13 @@ void launch_update_p(hipStream_t s, const CgScalars* sc, double* p, const double
 // pApPartials != nullptr: p.Ap is still in nPAp per-workgroup partial sums; every workgroup adds them up itself (same fixed
 // order everywhere) instead of a separate reduction launch.  partials (output) must not overlap pApPartials.
 int  launch_update_r(hipStream_t s, CgScalars* sc, double* r, const double* Ap, long long n, double* partials, double* partialsInf,
-                     const double* pApPartials = nullptr, int nPAp = 0);
+                     const double* pApPartials = nullptr, int nPAp = 0, bool freeze = false);
 void launch_update_xp(hipStream_t s, const CgScalars* sc, double* x, double* p, const double* z, long long n);
+// x/p update that first does what finalize_kernel does (every workgroup reduces the r.r partial sums itself and takes the same stop
+// decision; workgroup 0 publishes it): one launch fewer per iteration.  Needs update_r launched with freeze = true.
+struct FinalizeArgs;
+void launch_update_xp_final(hipStream_t s, const FinalizeArgs& f, const double* partials, const double* partialsInf, int nPartials,
+                            double* x, double* p, const double* z, long long n);
 
 struct FinalizeArgs {
     CgScalars* sc;

@@ -291,12 +291,12 @@ int launch_update_xr(hipStream_t s, const CgScalars* sc, double* x, double* r, c
 template <bool V2, bool INF>
 __global__ __launch_bounds__(kBlock) void update_r_kernel(CgScalars* __restrict__ sc, double* __restrict__ r, const double* __restrict__ Ap, long long n,
                                                           double* __restrict__ partials, double* __restrict__ partialsInf,
-                                                          const double* __restrict__ pApPartials, int nPAp)
+                                                          const double* __restrict__ pApPartials, int nPAp, int freeze)
 {
     __shared__ double s_red[4];
     __shared__ double s_red2[4];
     __shared__ double s_pAp;
-    if (sc->done != 0) return;
+    if (sc->done != 0) { if (freeze && blockIdx.x == 0 && threadIdx.x == 0) sc->fDone = 1; return; }   // tells the folded x/p update that no iteration ran
     double pAp;
     if (pApPartials != nullptr) {                                     // single-rank loop: no separate reduction launch
         const double t = reduce_partials_block(pApPartials, nPAp, s_red, 0);
@@ -308,7 +308,10 @@ __global__ __launch_bounds__(kBlock) void update_r_kernel(CgScalars* __restrict_
         pAp = sc->pAp;
     }
     const double alpha = sc->rr / pAp;
-    if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;      // for update_xp of this iteration
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc->alpha = alpha;                                            // for update_xp of this iteration
+        if (freeze) { sc->fRr = sc->rr; sc->fRr0 = sc->rr0; sc->fAlpha = alpha; sc->fIteration = sc->iteration; sc->fDone = 0; }
+    }
     const double malpha = -alpha;
     double acc = 0.0, mx = 0.0;
     auto one = [&](long long i) {
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(kBlock) void update_r_kernel(CgScalars* __restrict_
     }
 }
 int launch_update_r(hipStream_t s, CgScalars* sc, double* r, const double* Ap, long long n, double* partials, double* partialsInf,
-                    const double* pApPartials, int nPAp)
+                    const double* pApPartials, int nPAp, bool freeze)
 {
     const bool v2 = al16(r) && al16(Ap);
     int grid = grid_for(n, v2 ? 4 : 2);
@@ -353,7 +356,7 @@ int launch_update_r(hipStream_t s, CgScalars* sc, double* r, const double* Ap, l
     const int want = rcap > 0 ? rcap : 2 * (d ? d->numCu : kNumCu);
     if (grid > want) grid = want;
     const bool inf = partialsInf != nullptr;
-#define GO(V, I) hipLaunchKernelGGL((update_r_kernel<V, I>), dim3(grid), dim3(kBlock), 0, s, sc, r, Ap, n, partials, partialsInf, pApPartials, nPAp)
+#define GO(V, I) hipLaunchKernelGGL((update_r_kernel<V, I>), dim3(grid), dim3(kBlock), 0, s, sc, r, Ap, n, partials, partialsInf, pApPartials, nPAp, freeze ? 1 : 0)
     if (v2) { if (inf) GO(true, true); else GO(true, false); }
     else { if (inf) GO(false, true); else GO(false, false); }
 #undef GO
@@ -403,6 +406,102 @@ void launch_update_xp(hipStream_t s, const CgScalars* sc, double* x, double* p, 
     else hipLaunchKernelGGL(update_xp_kernel<false>, dim3(grid_for(n, 1)), dim3(kBlock), 0, s, sc, x, p, z, n);
 }
 
+// The stop decision of one iteration (the five rules of SURVEY.md 3.5): residual to show, stop or not, status.
+struct StopDecision { double res, shown; bool stop; int status; };
+__device__ __forceinline__ StopDecision decide_stop(const FinalizeArgs& f, double rrNew, double inf, double rr0, int it)
+{
+    StopDecision d;
+    d.res = sqrt(rrNew);
+    if (f.rule == MGCG_RULE_HANDMADECL) d.res = inf;
+    d.shown = d.res;
+    bool converged;
+    switch (f.rule) {
+    case MGCG_RULE_NATIVE:   converged = (f.minIt <= it) && (d.res < f.tol); break;
+    case MGCG_RULE_SIMPLE:   converged = (f.minIt < it) && (d.res < f.tol); break;
+    case MGCG_RULE_VIENNACL: d.shown = sqrt(rrNew / rr0); converged = (f.minIt < it) && (rrNew / rr0 < f.tol * f.tol); break;
+    default:                 converged = (it >= f.minIt) && (it <= f.maxIt) && (d.res < f.tol); break;  // ConjugateGradient.cs:56-79
+    }
+    d.status = MGCG_OK;
+    d.stop = converged;
+    if (!d.stop && it >= f.minIt && it > f.maxIt) { d.stop = true; d.status = MGCG_MAXIT_EXCEEDED; }
+    if (!d.stop && !(d.res == d.res && fabs(d.res) <= 1.79e308)) { d.stop = true; d.status = MGCG_NONFINITE; }
+    return d;
+}
+
+// The x/p update with the iteration's finalisation folded in (single rank, no preconditioner: z = r).  Every workgroup reduces the
+// r.r (and max|r|) partial sums of update_r in the order finalize_kernel uses and takes the same decision from the values update_r
+// froze (fRr, fRr0, fAlpha, fIteration, fDone); workgroup 0 alone rewrites the live scalars, the host mirror and the trace, which
+// nothing in this kernel reads.  The arithmetic of x and p is update_xp_kernel's.
+template <bool V2>
+__global__ __launch_bounds__(kBlock) void update_xp_final_kernel(FinalizeArgs f, const double* __restrict__ partials, const double* __restrict__ partialsInf,
+                                                                 int nPartials, double* __restrict__ x, double* __restrict__ p, const double* __restrict__ z, long long n)
+{
+    __shared__ double s_red[4];
+    __shared__ double s_red2[4];
+    __shared__ double s_beta;
+    __shared__ int s_stop;
+    CgScalars* sc = f.sc;
+    if (sc->fDone != 0) return;                                       // the loop had stopped before this iteration: nothing ran, nothing is pending
+    const double rrNew = reduce_partials_block(partials, nPartials, s_red, 0);
+    double inf = 0.0;
+    if (partialsInf != nullptr) inf = reduce_partials_block(partialsInf, nPartials, s_red2, 1);
+    const double alpha = sc->fAlpha;
+    if (threadIdx.x == 0) {
+        const int it = sc->fIteration;
+        const StopDecision d = decide_stop(f, rrNew, inf, sc->fRr0, it);
+        const double beta = rrNew / sc->fRr;
+        s_stop = d.stop ? 1 : 0; s_beta = beta;
+        if (blockIdx.x == 0) {                                        // publish (what finalize_kernel writes)
+            if (f.trace != nullptr && it < f.traceCap) f.trace[it] = d.shown;
+            sc->rrNew = rrNew; sc->residual = d.res; sc->nrmInf = inf; sc->pad = 0;
+            if (d.stop) {
+                sc->done = 1; sc->status = d.status;
+                f.mirror->residual = d.res; f.mirror->iteration = it; f.mirror->status = d.status;
+                __threadfence_system();
+                f.mirror->done = 1;
+            } else {
+                sc->beta = beta; sc->rr = rrNew; sc->iteration = it + 1;
+                f.mirror->residual = d.res; f.mirror->iteration = it + 1;
+            }
+        }
+    }
+    __syncthreads();
+    const double beta = s_beta;
+    if (s_stop) {                                                     // the iteration that stops the loop: x only
+        grid_stride<V2>(n,
+            [&](long long i) { d2 pv = *(const d2*)(p + i); d2 xv = *(d2*)(x + i); double t0 = alpha * pv.x; double t1 = alpha * pv.y; xv.x = xv.x + t0; xv.y = xv.y + t1; *(d2*)(x + i) = xv; },
+            [&](long long i) { double t = alpha * p[i]; x[i] = x[i] + t; });
+        return;
+    }
+    auto one = [&](long long i) { const double pv = p[i]; double t = alpha * pv; x[i] = x[i] + t; double u = beta * pv; p[i] = z[i] + u; };
+    if constexpr (V2) {
+        d2* x2 = (d2*)x; d2* p2 = (d2*)p; const d2* z2 = (const d2*)z;
+        auto fin = [&](d2& xv, d2& pv, const d2& zv) {
+            double t0 = alpha * pv.x; double t1 = alpha * pv.y; xv.x = xv.x + t0; xv.y = xv.y + t1;
+            double u0 = beta * pv.x; double u1 = beta * pv.y; pv.x = zv.x + u0; pv.y = zv.y + u1;
+        };
+        chunk_pairs(n >> 1, [&](long long i, bool two) {
+            const long long j = two ? i + kBlock : i;
+            d2 pv0 = __builtin_nontemporal_load(p2 + i), xv0 = __builtin_nontemporal_load(x2 + i), zv0 = __builtin_nontemporal_load(z2 + i);
+            d2 pv1 = __builtin_nontemporal_load(p2 + j), xv1 = __builtin_nontemporal_load(x2 + j), zv1 = __builtin_nontemporal_load(z2 + j);
+            fin(xv0, pv0, zv0);
+            __builtin_nontemporal_store(xv0, x2 + i); __builtin_nontemporal_store(pv0, p2 + i);
+            if (two) { fin(xv1, pv1, zv1); __builtin_nontemporal_store(xv1, x2 + j); __builtin_nontemporal_store(pv1, p2 + j); }
+        });
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) one(n - 1);
+    } else {
+        grid_stride<false>(n, [&](long long) {}, one);
+    }
+}
+void launch_update_xp_final(hipStream_t s, const FinalizeArgs& f, const double* partials, const double* partialsInf, int nPartials,
+                            double* x, double* p, const double* z, long long n)
+{
+    if (n <= 0) return;
+    const bool v2 = al16(x) && al16(p) && al16(z);
+    if (v2) hipLaunchKernelGGL(update_xp_final_kernel<true>, dim3(grid_for(n, 2)), dim3(kBlock), 0, s, f, partials, partialsInf, nPartials, x, p, z, n);
+    else hipLaunchKernelGGL(update_xp_final_kernel<false>, dim3(grid_for(n, 1)), dim3(kBlock), 0, s, f, partials, partialsInf, nPartials, x, p, z, n);
+}
+
 // p = z + beta*p   (ConjugateGradientCpu.cs:94 with z = r; the preconditioned loop passes z = M^-1 r)
 template <bool V2>
 __global__ __launch_bounds__(kBlock) void update_p_kernel(const CgScalars* __restrict__ sc, double* __restrict__ p, const double* __restrict__ z, long long n)
@@ -432,6 +531,7 @@ __global__ __launch_bounds__(kBlock) void init_scalars_kernel(const double* __re
         if (!reduceFirst) rr = sc->rr;
         sc->rr = rr; sc->rr0 = rr; sc->pAp = 0; sc->rrNew = 0; sc->rzNew = 0; sc->residual = 0; sc->nrmInf = 0;
         sc->beta = 0; sc->alpha = 0; sc->iteration = 0; sc->done = 0; sc->status = 0; sc->pad = 0;
+        sc->fRr = rr; sc->fRr0 = rr; sc->fAlpha = 0; sc->fIteration = 0; sc->fDone = 0;
         (void)rule;
         mirror->residual = 0; mirror->iteration = 0; mirror->status = 0; mirror->done = 0;
     }
@@ -441,7 +541,7 @@ void launch_init_scalars(hipStream_t s, const double* partials, int n, bool redu
     hipLaunchKernelGGL(init_scalars_kernel, dim3(1), dim3(kBlock), 0, s, partials, n, reduceFirst ? 1 : 0, sc, mirror, rule);
 }
 
-// Residual, stop test (the five rules of SURVEY.md 3.5), beta and the rr hand-over.
+// Residual, stop test, beta and the rr hand-over.
 __global__ __launch_bounds__(kBlock) void finalize_kernel(const double* __restrict__ partials, const double* __restrict__ partialsInf, int n,
                                                           int reduceFirst, FinalizeArgs f)
 {
@@ -457,20 +557,10 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const double* __restri
     if (threadIdx.x != 0) return;
     if (!reduceFirst) { rrNew = sc->rrNew; inf = sc->nrmInf; }
     const int it = sc->iteration;
-    double res = sqrt(rrNew);
-    if (f.rule == MGCG_RULE_HANDMADECL) res = inf;
-    double shown = res;
-    bool converged;
-    switch (f.rule) {
-    case MGCG_RULE_NATIVE:   converged = (f.minIt <= it) && (res < f.tol); break;
-    case MGCG_RULE_SIMPLE:   converged = (f.minIt < it) && (res < f.tol); break;
-    case MGCG_RULE_VIENNACL: shown = sqrt(rrNew / sc->rr0); converged = (f.minIt < it) && (rrNew / sc->rr0 < f.tol * f.tol); break;
-    default:                 converged = (it >= f.minIt) && (it <= f.maxIt) && (res < f.tol); break;  // ConjugateGradient.cs:56-79
-    }
-    int status = MGCG_OK;
-    bool stop = converged;
-    if (!stop && it >= f.minIt && it > f.maxIt) { stop = true; status = MGCG_MAXIT_EXCEEDED; }
-    if (!stop && !(res == res && fabs(res) <= 1.79e308)) { stop = true; status = MGCG_NONFINITE; }
+    const StopDecision d = decide_stop(f, rrNew, inf, sc->rr0, it);
+    const double res = d.res, shown = d.shown;
+    const bool stop = d.stop;
+    const int status = d.status;
     if (f.trace != nullptr && it < f.traceCap) f.trace[it] = shown;
     sc->rrNew = rrNew; sc->residual = res; sc->nrmInf = inf;
     sc->pad = 1;                                 // this iteration's x += alpha p is still to be done (update_xp)

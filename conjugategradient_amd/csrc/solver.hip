@@ -323,6 +323,9 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
     }
     double* pInf = R.wantInf ? R.ws->partials + kMaxPartials : nullptr;
     double* rrPartials = R.ws->partials;
+    // one rank, no preconditioner: the x/p update finalises the iteration itself (one launch fewer; MGCG_NO_FOLDED_FINALIZE for A/B)
+    const bool noFold = getenv("MGCG_NO_FOLDED_FINALIZE") != nullptr;          // (read per call: tools flip it inside one process)
+    const bool fold = R.nranks == 1 && !R.mg && R.nLocal > 0 && !noFold;
     if (R.nranks > 1) {
         launch_reduce_to(s, R.ws->partials, n, &sc->pAp, done);
         if (!comm_allreduce_sum(R.comm, &sc->pAp, 1, s)) return false;               // (:499)
@@ -331,12 +334,16 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
         // one rank: the workgroups of the r update add the p.Ap partial sums themselves (one launch fewer per iteration);
         // their own r.r partial sums go to the third region of the buffer
         rrPartials = R.ws->partials + 2 * kMaxPartials;
-        n = launch_update_r(s, sc, R.r, R.Ap, R.nLocal, rrPartials, pInf, R.ws->partials, n);
+        n = launch_update_r(s, sc, R.r, R.Ap, R.nLocal, rrPartials, pInf, R.ws->partials, n, fold);
     }
     FinalizeArgs f{};
     f.sc = sc; f.mirror = R.ws->mirror; f.trace = R.ws->trace; f.traceCap = R.ws->traceCap;
     f.tol = R.tol; f.minIt = R.minIt; f.maxIt = R.maxIt; f.rule = R.rule; f.preconditioned = R.mg ? 1 : 0;
     if (!withStopTest) { f.tol = -1.0; f.minIt = 0; f.maxIt = 0x7fffffff; f.rule = MGCG_RULE_NATIVE; }   // never converges
+    if (fold) {
+        launch_update_xp_final(s, f, rrPartials, pInf, n, R.x, pLoc, R.r, R.nLocal);     // residual, stop test, beta (:251-266) ; x += a p (:246) ; p = r + beta p (:265)
+        return MGCG_HIP(hipGetLastError());
+    }
     if (R.nranks > 1 && R.mg) {
         // Preconditioned, several ranks: r.r (stop test) and r.z (beta) travel in ONE all-reduce of two doubles behind the
         // V-cycle ("[r.z, r.r] batched"); the stop decision of an iteration is taken one V-cycle later,
