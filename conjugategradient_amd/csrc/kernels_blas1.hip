@@ -442,9 +442,11 @@ __global__ __launch_bounds__(kBlock) void update_xp_final_kernel(FinalizeArgs f,
     __shared__ int s_stop;
     CgScalars* sc = f.sc;
     if (sc->fDone != 0) return;                                       // the loop had stopped before this iteration: nothing ran, nothing is pending
-    const double rrNew = reduce_partials_block(partials, nPartials, s_red, 0);
+    // nPartials == 0: several ranks -- r.r has been reduced and all-reduced into sc->rrNew before this launch (workgroup 0 writes the
+    // same bits back below)
+    const double rrNew = nPartials > 0 ? reduce_partials_block(partials, nPartials, s_red, 0) : sc->rrNew;
     double inf = 0.0;
-    if (partialsInf != nullptr) inf = reduce_partials_block(partialsInf, nPartials, s_red2, 1);
+    if (partialsInf != nullptr && nPartials > 0) inf = reduce_partials_block(partialsInf, nPartials, s_red2, 1);
     const double alpha = sc->fAlpha;
     if (threadIdx.x == 0) {
         const int it = sc->fIteration;

@@ -326,10 +326,11 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
     // one rank, no preconditioner: the x/p update finalises the iteration itself (one launch fewer; MGCG_NO_FOLDED_FINALIZE for A/B)
     const bool noFold = getenv("MGCG_NO_FOLDED_FINALIZE") != nullptr;          // (read per call: tools flip it inside one process)
     const bool fold = R.nranks == 1 && !R.mg && R.nLocal > 0 && !noFold;
+    const bool foldRanks = R.nranks > 1 && !R.mg && R.nLocal > 0 && !noFold;         // several ranks: the same fold behind the all-reduce of r.r
     if (R.nranks > 1) {
         launch_reduce_to(s, R.ws->partials, n, &sc->pAp, done);
         if (!comm_allreduce_sum(R.comm, &sc->pAp, 1, s)) return false;               // (:499)
-        n = launch_update_r(s, sc, R.r, R.Ap, R.nLocal, rrPartials, pInf);           // r -= a Ap ; r.r  (:247-248); x += a p rides with the p update below
+        n = launch_update_r(s, sc, R.r, R.Ap, R.nLocal, rrPartials, pInf, nullptr, 0, foldRanks);   // r -= a Ap ; r.r  (:247-248); x += a p rides with the p update below
     } else {
         // one rank: the workgroups of the r update add the p.Ap partial sums themselves (one launch fewer per iteration);
         // their own r.r partial sums go to the third region of the buffer
@@ -362,6 +363,10 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
     if (R.nranks > 1) {
         launch_reduce_to(s, rrPartials, n, &sc->rrNew, done);
         if (!comm_allreduce_sum(R.comm, &sc->rrNew, 1, s)) return false;             // (:525)
+        if (foldRanks) {
+            launch_update_xp_final(s, f, nullptr, nullptr, 0, R.x, pLoc, R.r, R.nLocal);     // stop test, beta, x += a p, p = r + beta p in one launch
+            return MGCG_HIP(hipGetLastError());
+        }
         launch_finalize(s, rrPartials, pInf, n, false, f);
     } else {
         launch_finalize(s, rrPartials, pInf, n, true, f);                            // residual, stop test, beta  (:251-266)
