@@ -239,7 +239,7 @@ struct SpmvConfig { int kernel = 0; int rowsPerBlock = 64; int flags = 0; int gr
 int launch_spmv(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg);
 // Row-tile kernel for short rows on plain CSR (kernels_rowtile.hip); periodRows = distance of the far band in rows (0: unknown),
 // gridReq = wavefronts (0: 8 per CU).  Needs 16-byte aligned elements / columnIndeces and elementsCount >= 8.
-int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int periodRows, int gridReq, int maxRow = 0);
+int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int periodRows, int gridReq, int maxRow = 0, bool ntWindow = false);
 // Distance (in rows) of the farthest band of the matrix, read off one row in the middle of the slice, and the longest row (one pass
 // over the row offsets; both remembered per handle -- stale values can only cost speed: any period gives the same results, and rows
 // longer than the remembered maximum take the kernel's slow path); the caller's hint (MgcgSetSpmvPeriod) wins for the period.

@@ -66,7 +66,7 @@ __device__ __forceinline__ RowsEpi tile_epi_prefetch(const SpmvArgs& a, int row)
 
 // NG = gathers issued per row in the fast path: 8, or 7 when no row of the matrix is longer (a 7-point stencil: one LDS read
 // pair, one gather and one product fewer per row, 1-2.5 % -- profiles/r2/spmv_lab_lab15_micro.log, spmv_lab_lab17_records.log).
-template <int EPI, int NG>
+template <int EPI, int NG, bool NT = false>
 __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, TileMap tm, int nTiles)
 {
     __shared__ __attribute__((aligned(16))) int s_colAll[kTCap * kTW];
@@ -115,10 +115,14 @@ __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, Tile
         const int tb = s & ~3;
         int k0 = tb + 4 * tid, k1 = k0 + 256;
         k0 = k0 < kMax4 ? k0 : kMax4; k1 = k1 < kMax4 ? k1 : kMax4;
-        c0 = *(const i4*)(a.columnIndeces + k0); c1 = *(const i4*)(a.columnIndeces + k1);
+        if constexpr (NT) { c0 = __builtin_nontemporal_load((const i4*)(a.columnIndeces + k0)); c1 = __builtin_nontemporal_load((const i4*)(a.columnIndeces + k1)); }
+        else { c0 = *(const i4*)(a.columnIndeces + k0); c1 = *(const i4*)(a.columnIndeces + k1); }
         int j0 = tb + 2 * tid, j1 = j0 + 128, j2 = j0 + 256, j3 = j0 + 384;
         j0 = j0 < kMax2 ? j0 : kMax2; j1 = j1 < kMax2 ? j1 : kMax2; j2 = j2 < kMax2 ? j2 : kMax2; j3 = j3 < kMax2 ? j3 : kMax2;
-        v0 = *(const d2*)(a.elements + j0); v1 = *(const d2*)(a.elements + j1); v2 = *(const d2*)(a.elements + j2); v3 = *(const d2*)(a.elements + j3);
+        if constexpr (NT) {
+            v0 = __builtin_nontemporal_load((const d2*)(a.elements + j0)); v1 = __builtin_nontemporal_load((const d2*)(a.elements + j1));
+            v2 = __builtin_nontemporal_load((const d2*)(a.elements + j2)); v3 = __builtin_nontemporal_load((const d2*)(a.elements + j3));
+        } else { v0 = *(const d2*)(a.elements + j0); v1 = *(const d2*)(a.elements + j1); v2 = *(const d2*)(a.elements + j2); v3 = *(const d2*)(a.elements + j3); }
     };
 
     // prologue in the loop's own issue order: ro(0); raw(0); ro(1)
@@ -233,7 +237,7 @@ TileMap make_tile_map(long long rows, int periodRows, int nWG, int tileRows)
 }
 
 template <int EPI>
-static int launch_rowtile_epi(hipStream_t s, const SpmvArgs& a, int periodRows, int gridReq, int maxRow)
+static int launch_rowtile_epi(hipStream_t s, const SpmvArgs& a, int periodRows, int gridReq, int maxRow, bool ntWindow)
 {
     const int nTiles = a.rowCount / kTRows;                       // full tiles; the kernel's workgroup 0 takes the rows behind them
     DeviceState* d = device_state();
@@ -244,22 +248,34 @@ static int launch_rowtile_epi(hipStream_t s, const SpmvArgs& a, int periodRows, 
     if (nWG < 1) nWG = 1;
     static const bool noSweep = getenv("MGCG_NO_ZSWEEP") != nullptr;
     const TileMap tm = make_tile_map(a.rowCount, noSweep ? 0 : periodRows, nWG, kTRows);
-    if (maxRow > 0 && maxRow <= 7) hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 7>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
+    // Matrix streams with the non-temporal hint when the vectors of the system are small enough to live in the 256 MB Infinity Cache
+    // between the kernels of an iteration (the slab of one rank of an 8-GPU run, the coarse levels of a hierarchy): the matrix, read once
+    // per product, then does not push them out.  CG iteration, alternating inside one process (tools/nt_ab.py): -1 % at 8.4 M rows, -3.5 % at 16.8 M,
+    // -1.5 % at 33.5 M, +0.2 % at 42 M, +1.5 % at 134 M (there the hint only costs) and +10 % at 2 M (there the matrix itself would have stayed in the cache).  Only the plain CG loop asks for it (SpmvConfig::flags & 8): inside the V-cycle
+    // the same hint made the slab's MGCG iteration 1-3 % slower.  MGCG_ROWTILE_NT=0/1 overrides.
+    const char* ntEnv = getenv("MGCG_ROWTILE_NT");
+    const bool nt = ntEnv ? atoi(ntEnv) != 0 : (ntWindow && a.rowCount >= 8000000 && a.rowCount <= 36000000);
+    const bool seven = maxRow > 0 && maxRow <= 7;
+    if (nt) {
+        if (seven) hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 7, true>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
+        else hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 8, true>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
+    }
+    else if (seven) hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 7>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
     else hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 8>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
     return nWG * kTW;
 }
 
 // Requires 16-byte aligned elements and columnIndeces and elementsCount >= 8 (checked by the caller).
-int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int periodRows, int gridReq, int maxRow)
+int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int periodRows, int gridReq, int maxRow, bool ntWindow)
 {
     if (a.rowCount <= 0) return 0;
     switch (epilogue) {
-    case EPI_AXPBY:        return a.beta != 0.0 ? launch_rowtile_epi<EPI_AXPBY_BETA>(s, a, periodRows, gridReq, maxRow) : launch_rowtile_epi<EPI_AXPBY>(s, a, periodRows, gridReq, maxRow);
-    case EPI_DOT:          return launch_rowtile_epi<EPI_DOT>(s, a, periodRows, gridReq, maxRow);
-    case EPI_RESIDUAL:     return launch_rowtile_epi<EPI_RESIDUAL>(s, a, periodRows, gridReq, maxRow);
-    case EPI_RESIDUAL_DOT: return launch_rowtile_epi<EPI_RESIDUAL_DOT>(s, a, periodRows, gridReq, maxRow);
-    case EPI_JACOBI:       return launch_rowtile_epi<EPI_JACOBI>(s, a, periodRows, gridReq, maxRow);
-    case EPI_JACOBI_DOT:   return launch_rowtile_epi<EPI_JACOBI_DOT>(s, a, periodRows, gridReq, maxRow);
+    case EPI_AXPBY:        return a.beta != 0.0 ? launch_rowtile_epi<EPI_AXPBY_BETA>(s, a, periodRows, gridReq, maxRow, ntWindow) : launch_rowtile_epi<EPI_AXPBY>(s, a, periodRows, gridReq, maxRow, ntWindow);
+    case EPI_DOT:          return launch_rowtile_epi<EPI_DOT>(s, a, periodRows, gridReq, maxRow, ntWindow);
+    case EPI_RESIDUAL:     return launch_rowtile_epi<EPI_RESIDUAL>(s, a, periodRows, gridReq, maxRow, ntWindow);
+    case EPI_RESIDUAL_DOT: return launch_rowtile_epi<EPI_RESIDUAL_DOT>(s, a, periodRows, gridReq, maxRow, ntWindow);
+    case EPI_JACOBI:       return launch_rowtile_epi<EPI_JACOBI>(s, a, periodRows, gridReq, maxRow, ntWindow);
+    case EPI_JACOBI_DOT:   return launch_rowtile_epi<EPI_JACOBI_DOT>(s, a, periodRows, gridReq, maxRow, ntWindow);
     }
     return 0;
 }

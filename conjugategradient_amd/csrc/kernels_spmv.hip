@@ -513,7 +513,7 @@ static int launch_spmv_epi(hipStream_t s, const SpmvArgs& a, const SpmvConfig& c
     }
     if (kernel == 10) {     // row-tile kernel (four wavefronts per tile of 256 rows); 16-byte aligned arrays
         const bool ok = (((uintptr_t)a.elements & 15) == 0) && (((uintptr_t)a.columnIndeces & 15) == 0) && a.elementsCount >= 8;
-        if (ok) return launch_spmv_rowtile(s, EPI == EPI_AXPBY_BETA ? (int)EPI_AXPBY : (int)EPI, a, cfg.periodRows, cfg.gridBlocks, cfg.maxRow);
+        if (ok) return launch_spmv_rowtile(s, EPI == EPI_AXPBY_BETA ? (int)EPI_AXPBY : (int)EPI, a, cfg.periodRows, cfg.gridBlocks, cfg.maxRow, (cfg.flags & 8) != 0);
         kernel = 9;
     }
     if (kernel == 9) {      // row-block kernel, "stage raw, multiply by row" form; same alignment needs as the stream kernel's wide path

@@ -265,6 +265,7 @@ static bool cg_enqueue_init(CgRun& R)
     hipStream_t s = R.ws->stream;
     if (R.cusparse) R.dcsr = dcsr_lookup(R.cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset, R.count);
     if (R.cusparse && R.elementsCount >= 8) R.cfg.periodRows = spmv_period(R.cusparse, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.cfg.maxRow);
+    if (!R.mg) R.cfg.flags |= 8;                 // plain CG loop: the row-tile kernel may read the matrix with the non-temporal hint (kernels_rowtile.hip)
     CgScalars* sc = R.ws->scalars;
     double* pLoc = R.p + R.offset;
     if (R.rule == MGCG_RULE_SIMPLE) launch_fill(s, R.x, 0.0, R.nLocal);             // SimpleConjugateGradient.cu:53
@@ -552,6 +553,7 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     if (R.nranks > 1) { R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, R.columnIndeces, R.elementsCount); ok = R.halo != nullptr && cg_plan_overlap(R); }
     R.dcsr = dcsr_lookup(cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset, R.count);
     if (R.elementsCount >= 8) R.cfg.periodRows = spmv_period(cusparse, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.cfg.maxRow);
+    R.cfg.flags |= 8;
     if (ok && restart) ok = cg_enqueue_init(R);
     else if (ok) hipLaunchKernelGGL(clear_done_kernel, dim3(1), dim3(1), 0, R.ws->stream, R.ws->scalars);
     for (int k = 0; ok && k < steps; ++k) ok = cg_enqueue_iteration(R, false);
