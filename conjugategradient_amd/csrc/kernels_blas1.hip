@@ -57,6 +57,17 @@ static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // Element-wise grid-stride driver.  V2: f2(i) handles elements i, i+1 with 16-byte accesses and the
 // odd tail goes to f1 on one thread; otherwise f1(i) per element.
+// Streaming hint of the CG vector passes (non-temporal loads and stores).  Measured per size, alternating inside one process
+// (tools/vec_nt_ab.py, profiles/r2/vec_nt_ab.log): with the hint the CG iteration is 2-11 % faster from 4 M rows up (11 % at the 16.8 M rows
+// of one rank's slab of an 8-GPU run, 2 % at 134 M) and 2.5 % slower at 2 M rows and below, where every vector stays in the caches anyway.
+template <bool NTV, typename T> __device__ __forceinline__ T ldv(const T* p) { if constexpr (NTV) return __builtin_nontemporal_load(p); else return *p; }
+template <bool NTV, typename T> __device__ __forceinline__ void stv(const T& v, T* p) { if constexpr (NTV) __builtin_nontemporal_store(v, p); else *p = v; }
+static bool vec_nt(long long n)
+{
+    const char* e = getenv("MGCG_VEC_NT");
+    return e ? atoi(e) != 0 : n > 3000000;
+}
+
 template <bool V2, typename F2, typename F1>
 __device__ __forceinline__ void grid_stride(long long n, F2 f2, F1 f1)
 {
@@ -288,7 +299,7 @@ int launch_update_xr(hipStream_t s, const CgScalars* sc, double* x, double* r, c
 // reference's phase functions: r first (its norm decides the stop test), then x and p together, so that p is read
 // once for both x += alpha p and p = z + beta p  (64N bytes per iteration instead of 72N).
 // alpha = rr / pAp ; r = r + (-alpha)*Ap ; partial r.r [, partial max|r|]
-template <bool V2, bool INF>
+template <bool V2, bool INF, bool NTV>
 __global__ __launch_bounds__(kBlock) void update_r_kernel(CgScalars* __restrict__ sc, double* __restrict__ r, const double* __restrict__ Ap, long long n,
                                                           double* __restrict__ partials, double* __restrict__ partialsInf,
                                                           const double* __restrict__ pApPartials, int nPAp, int freeze)
@@ -329,9 +340,9 @@ __global__ __launch_bounds__(kBlock) void update_r_kernel(CgScalars* __restrict_
         chunk_pairs(n >> 1, [&](long long i, bool two) {
             const long long j = two ? i + kBlock : i;
             // streaming hints as in update_xp (measured there: 5.2 -> 6.3 TB/s): Ap is not read again, r not before 2 GB of other traffic
-            d2 av0 = __builtin_nontemporal_load(a2 + i), rv0 = __builtin_nontemporal_load(r2 + i), av1 = __builtin_nontemporal_load(a2 + j), rv1 = __builtin_nontemporal_load(r2 + j);
-            fin(rv0, av0); __builtin_nontemporal_store(rv0, r2 + i);
-            if (two) { fin(rv1, av1); __builtin_nontemporal_store(rv1, r2 + j); }
+            d2 av0 = ldv<NTV>(a2 + i), rv0 = ldv<NTV>(r2 + i), av1 = ldv<NTV>(a2 + j), rv1 = ldv<NTV>(r2 + j);
+            fin(rv0, av0); stv<NTV>(rv0, r2 + i);
+            if (two) { fin(rv1, av1); stv<NTV>(rv1, r2 + j); }
         });
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) one(n - 1);
     } else {
@@ -356,7 +367,9 @@ int launch_update_r(hipStream_t s, CgScalars* sc, double* r, const double* Ap, l
     const int want = rcap > 0 ? rcap : 2 * (d ? d->numCu : kNumCu);
     if (grid > want) grid = want;
     const bool inf = partialsInf != nullptr;
-#define GO(V, I) hipLaunchKernelGGL((update_r_kernel<V, I>), dim3(grid), dim3(kBlock), 0, s, sc, r, Ap, n, partials, partialsInf, pApPartials, nPAp, freeze ? 1 : 0)
+    const bool nt = vec_nt(n);
+#define GO(V, I) do { if (nt) hipLaunchKernelGGL((update_r_kernel<V, I, true>), dim3(grid), dim3(kBlock), 0, s, sc, r, Ap, n, partials, partialsInf, pApPartials, nPAp, freeze ? 1 : 0); \
+                      else hipLaunchKernelGGL((update_r_kernel<V, I, false>), dim3(grid), dim3(kBlock), 0, s, sc, r, Ap, n, partials, partialsInf, pApPartials, nPAp, freeze ? 1 : 0); } while (0)
     if (v2) { if (inf) GO(true, true); else GO(true, false); }
     else { if (inf) GO(false, true); else GO(false, false); }
 #undef GO
@@ -365,7 +378,7 @@ int launch_update_r(hipStream_t s, CgScalars* sc, double* r, const double* Ap, l
 
 // x = x + alpha*p (whenever the iteration ran: sc->pad is the finalisation kernel's "x pending" mark) and, unless the
 // stop test fired, p = z + beta*p.
-template <bool V2>
+template <bool V2, bool NTV>
 __global__ __launch_bounds__(kBlock) void update_xp_kernel(const CgScalars* __restrict__ sc, double* __restrict__ x, double* __restrict__ p,
                                                            const double* __restrict__ z, long long n)
 {
@@ -387,11 +400,11 @@ __global__ __launch_bounds__(kBlock) void update_xp_kernel(const CgScalars* __re
         };
         chunk_pairs(n >> 1, [&](long long i, bool two) {
             const long long j = two ? i + kBlock : i;
-            d2 pv0 = __builtin_nontemporal_load(p2 + i), xv0 = __builtin_nontemporal_load(x2 + i), zv0 = __builtin_nontemporal_load(z2 + i);
-            d2 pv1 = __builtin_nontemporal_load(p2 + j), xv1 = __builtin_nontemporal_load(x2 + j), zv1 = __builtin_nontemporal_load(z2 + j);
+            d2 pv0 = ldv<NTV>(p2 + i), xv0 = ldv<NTV>(x2 + i), zv0 = ldv<NTV>(z2 + i);
+            d2 pv1 = ldv<NTV>(p2 + j), xv1 = ldv<NTV>(x2 + j), zv1 = ldv<NTV>(z2 + j);
             fin(xv0, pv0, zv0);
-            __builtin_nontemporal_store(xv0, x2 + i); __builtin_nontemporal_store(pv0, p2 + i);
-            if (two) { fin(xv1, pv1, zv1); __builtin_nontemporal_store(xv1, x2 + j); __builtin_nontemporal_store(pv1, p2 + j); }
+            stv<NTV>(xv0, x2 + i); stv<NTV>(pv0, p2 + i);
+            if (two) { fin(xv1, pv1, zv1); stv<NTV>(xv1, x2 + j); stv<NTV>(pv1, p2 + j); }
         });
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) one(n - 1);
     } else {
@@ -402,8 +415,10 @@ void launch_update_xp(hipStream_t s, const CgScalars* sc, double* x, double* p, 
 {
     if (n <= 0) return;
     const bool v2 = al16(x) && al16(p) && al16(z);
-    if (v2) hipLaunchKernelGGL(update_xp_kernel<true>, dim3(grid_for(n, 2)), dim3(kBlock), 0, s, sc, x, p, z, n);
-    else hipLaunchKernelGGL(update_xp_kernel<false>, dim3(grid_for(n, 1)), dim3(kBlock), 0, s, sc, x, p, z, n);
+    const bool nt = vec_nt(n);
+    if (v2 && nt) hipLaunchKernelGGL((update_xp_kernel<true, true>), dim3(grid_for(n, 2)), dim3(kBlock), 0, s, sc, x, p, z, n);
+    else if (v2) hipLaunchKernelGGL((update_xp_kernel<true, false>), dim3(grid_for(n, 2)), dim3(kBlock), 0, s, sc, x, p, z, n);
+    else hipLaunchKernelGGL((update_xp_kernel<false, false>), dim3(grid_for(n, 1)), dim3(kBlock), 0, s, sc, x, p, z, n);
 }
 
 // The stop decision of one iteration (the five rules of SURVEY.md 3.5): residual to show, stop or not, status.
@@ -432,7 +447,7 @@ __device__ __forceinline__ StopDecision decide_stop(const FinalizeArgs& f, doubl
 // r.r (and max|r|) partial sums of update_r in the order finalize_kernel uses and takes the same decision from the values update_r
 // froze (fRr, fRr0, fAlpha, fIteration, fDone); workgroup 0 alone rewrites the live scalars, the host mirror and the trace, which
 // nothing in this kernel reads.  The arithmetic of x and p is update_xp_kernel's.
-template <bool V2>
+template <bool V2, bool NTV>
 __global__ __launch_bounds__(kBlock) void update_xp_final_kernel(FinalizeArgs f, const double* __restrict__ partials, const double* __restrict__ partialsInf,
                                                                  int nPartials, double* __restrict__ x, double* __restrict__ p, const double* __restrict__ z, long long n)
 {
@@ -484,11 +499,11 @@ __global__ __launch_bounds__(kBlock) void update_xp_final_kernel(FinalizeArgs f,
         };
         chunk_pairs(n >> 1, [&](long long i, bool two) {
             const long long j = two ? i + kBlock : i;
-            d2 pv0 = __builtin_nontemporal_load(p2 + i), xv0 = __builtin_nontemporal_load(x2 + i), zv0 = __builtin_nontemporal_load(z2 + i);
-            d2 pv1 = __builtin_nontemporal_load(p2 + j), xv1 = __builtin_nontemporal_load(x2 + j), zv1 = __builtin_nontemporal_load(z2 + j);
+            d2 pv0 = ldv<NTV>(p2 + i), xv0 = ldv<NTV>(x2 + i), zv0 = ldv<NTV>(z2 + i);
+            d2 pv1 = ldv<NTV>(p2 + j), xv1 = ldv<NTV>(x2 + j), zv1 = ldv<NTV>(z2 + j);
             fin(xv0, pv0, zv0);
-            __builtin_nontemporal_store(xv0, x2 + i); __builtin_nontemporal_store(pv0, p2 + i);
-            if (two) { fin(xv1, pv1, zv1); __builtin_nontemporal_store(xv1, x2 + j); __builtin_nontemporal_store(pv1, p2 + j); }
+            stv<NTV>(xv0, x2 + i); stv<NTV>(pv0, p2 + i);
+            if (two) { fin(xv1, pv1, zv1); stv<NTV>(xv1, x2 + j); stv<NTV>(pv1, p2 + j); }
         });
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) one(n - 1);
     } else {
@@ -500,8 +515,10 @@ void launch_update_xp_final(hipStream_t s, const FinalizeArgs& f, const double* 
 {
     if (n <= 0) return;
     const bool v2 = al16(x) && al16(p) && al16(z);
-    if (v2) hipLaunchKernelGGL(update_xp_final_kernel<true>, dim3(grid_for(n, 2)), dim3(kBlock), 0, s, f, partials, partialsInf, nPartials, x, p, z, n);
-    else hipLaunchKernelGGL(update_xp_final_kernel<false>, dim3(grid_for(n, 1)), dim3(kBlock), 0, s, f, partials, partialsInf, nPartials, x, p, z, n);
+    const bool nt = vec_nt(n);
+    if (v2 && nt) hipLaunchKernelGGL((update_xp_final_kernel<true, true>), dim3(grid_for(n, 2)), dim3(kBlock), 0, s, f, partials, partialsInf, nPartials, x, p, z, n);
+    else if (v2) hipLaunchKernelGGL((update_xp_final_kernel<true, false>), dim3(grid_for(n, 2)), dim3(kBlock), 0, s, f, partials, partialsInf, nPartials, x, p, z, n);
+    else hipLaunchKernelGGL((update_xp_final_kernel<false, false>), dim3(grid_for(n, 1)), dim3(kBlock), 0, s, f, partials, partialsInf, nPartials, x, p, z, n);
 }
 
 // p = z + beta*p   (ConjugateGradientCpu.cs:94 with z = r; the preconditioned loop passes z = M^-1 r)
