@@ -362,7 +362,7 @@ int launch_update_r(hipStream_t s, CgScalars* sc, double* r, const double* Ap, l
     int grid = grid_for(n, v2 ? 4 : 2);
     // two workgroups per CU measured best for this 2-reads-1-write pass (0.565 ms against 0.59-0.61 for 768 / 1024 / 2048 and 0.72 for 256
     // workgroups at 512^3; the 3-reads-2-writes x/p pass keeps 2048); MGCG_R_GRID overrides
-    static const int rcap = [] { const char* e = getenv("MGCG_R_GRID"); const int v = e ? atoi(e) : 0; return (v >= 64 && v <= kMaxGrid) ? v : 0; }();
+    const int rcap = [] { const char* e = getenv("MGCG_R_GRID"); const int v = e ? atoi(e) : 0; return (v >= 64 && v <= kMaxGrid) ? v : 0; }();   // (read per launch: tools/slab_grid_ab.py)
     DeviceState* d = device_state();
     const int want = rcap > 0 ? rcap : 2 * (d ? d->numCu : kNumCu);
     if (grid > want) grid = want;
@@ -516,8 +516,10 @@ void launch_update_xp_final(hipStream_t s, const FinalizeArgs& f, const double* 
     if (n <= 0) return;
     const bool v2 = al16(x) && al16(p) && al16(z);
     const bool nt = vec_nt(n);
-    if (v2 && nt) hipLaunchKernelGGL((update_xp_final_kernel<true, true>), dim3(grid_for(n, 2)), dim3(kBlock), 0, s, f, partials, partialsInf, nPartials, x, p, z, n);
-    else if (v2) hipLaunchKernelGGL((update_xp_final_kernel<true, false>), dim3(grid_for(n, 2)), dim3(kBlock), 0, s, f, partials, partialsInf, nPartials, x, p, z, n);
+    int g2 = grid_for(n, 2);
+    if (const char* e = getenv("MGCG_XP_GRID")) { const int v = atoi(e); if (v >= 64 && v <= 16384 && v < g2) g2 = v; }      // (A/B: tools/slab_grid_ab.py)
+    if (v2 && nt) hipLaunchKernelGGL((update_xp_final_kernel<true, true>), dim3(g2), dim3(kBlock), 0, s, f, partials, partialsInf, nPartials, x, p, z, n);
+    else if (v2) hipLaunchKernelGGL((update_xp_final_kernel<true, false>), dim3(g2), dim3(kBlock), 0, s, f, partials, partialsInf, nPartials, x, p, z, n);
     else hipLaunchKernelGGL((update_xp_final_kernel<false, false>), dim3(grid_for(n, 1)), dim3(kBlock), 0, s, f, partials, partialsInf, nPartials, x, p, z, n);
 }
 

@@ -246,7 +246,7 @@ static int launch_rowtile_epi(hipStream_t s, const SpmvArgs& a, int periodRows, 
     if (nWG * kTW > kMaxPartials) nWG = kMaxPartials / kTW;
     if (nWG > nTiles) nWG = nTiles;
     if (nWG < 1) nWG = 1;
-    static const bool noSweep = getenv("MGCG_NO_ZSWEEP") != nullptr;
+    const bool noSweep = getenv("MGCG_NO_ZSWEEP") != nullptr;       // (read per launch: A/B tools flip it inside one process)
     const TileMap tm = make_tile_map(a.rowCount, noSweep ? 0 : periodRows, nWG, kTRows);
     // Matrix streams with the non-temporal hint when the vectors of the system are small enough to live in the 256 MB Infinity Cache
     // between the kernels of an iteration (the slab of one rank of an 8-GPU run, the coarse levels of a hierarchy): the matrix, read once
