@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- CG iterations/sec and SpMV achieved HBM GB/s on the 7-point Poisson 512^3 matrix.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: either under a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...), or as the bare command above -- the process then starts its N ranks itself
+(launch_ranks: a GPU-free parent, one child per GPU, rank 0's line forwarded, the worst exit code returned).
 
 A "step" is one CG iteration of the hot path (halo exchange, SpMV fused with p.Ap, x/r update fused
 with r.r, stop-test scalars, p update) on the synthetic 7-point 512^3 system (config of BASELINE.json's
@@ -225,15 +229,88 @@ def mgcg_extra(L, n: int):
     return out
 
 
+def _free_port() -> int:
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv: list[str], script: str | None = None, grace_s: float = 30.0) -> int:
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks (one process per GPU) as children of
+    this GPU-free parent -- the N-GPU timed leg of the reference's own benchmark (Mgcg/cuBlas/Mgcg/MgcgMain.cs:143-167)
+    is one command there too.  The parent imports neither torch nor the library and makes no GPU call; every child gets
+    RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR / MASTER_PORT, as torch.distributed.run would set
+    them.  Rank 0's stdout (the ONE JSON line) is forwarded to the parent's stdout, everything else to stderr.  Returns
+    the worst exit code of the children (3: RCCL could not form and --allow-fallback was not given).  When a rank fails,
+    the others get `grace_s` seconds to leave their collectives on their own, then exactly those PIDs are terminated."""
+    import subprocess
+
+    script = script or os.environ.get("MGCG_BENCH_RANK_SCRIPT") or os.path.abspath(__file__)     # (the variable: tests/test_bench_launcher.py)
+    env0 = dict(os.environ)
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on this driver
+    env0["MASTER_ADDR"] = "127.0.0.1"
+    env0["MASTER_PORT"] = str(env0.get("MGCG_BENCH_MASTER_PORT") or _free_port())
+    env0["WORLD_SIZE"] = env0["LOCAL_WORLD_SIZE"] = str(n)
+    children = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        children.append(subprocess.Popen([sys.executable, script, *argv], env=env,
+                                         stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    import threading
+
+    lines: list[str] = []
+    reader = threading.Thread(target=lambda: lines.extend(l.decode(errors="replace") for l in children[0].stdout), daemon=True)
+    reader.start()
+    failed_at = None
+    while True:
+        codes = [c.poll() for c in children]
+        if all(c is not None for c in codes):
+            break
+        if failed_at is None and any(c not in (None, 0) for c in codes):
+            failed_at = time.monotonic()
+        if failed_at is not None and time.monotonic() - failed_at > grace_s:
+            for c in children:
+                if c.poll() is None:
+                    c.terminate()
+            deadline = time.monotonic() + 10.0
+            for c in children:
+                try:
+                    c.wait(timeout=max(0.1, deadline - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    c.kill()
+                    c.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10.0)
+    codes = [c.returncode for c in children]
+    worst = max((128 - c) if c < 0 else c for c in codes)      # killed by a signal: the shell's convention
+    json_lines = [l for l in lines if l.lstrip().startswith("{")]
+    for l in lines:
+        if l in json_lines[-1:]:
+            continue
+        sys.stderr.write(l)
+    if json_lines:
+        sys.stdout.write(json_lines[-1] if json_lines[-1].endswith("\n") else json_lines[-1] + "\n")
+        sys.stdout.flush()
+    elif worst == 0:
+        print("bench.py: the ranks exited cleanly but rank 0 printed no JSON line", file=sys.stderr)
+        worst = 1
+    return worst
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if a.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE=1")
 
     dist = None
     if a.torch_first:

@@ -1,0 +1,90 @@
+"""bench.py's self-launcher (`python bench.py --gpus N` with no launcher around it): argument, environment, output and
+exit-code plumbing, exercised with stand-in rank scripts -- no GPU, no torch in the parent.  The N-GPU timed leg it serves
+is the reference's Mgcg/cuBlas/Mgcg/MgcgMain.cs:143-167."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+
+def _script(tmp_path, body):
+    p = tmp_path / "rank.py"
+    p.write_text(textwrap.dedent(body))
+    return str(p)
+
+
+def test_ranks_get_the_launcher_environment_and_rank0_line_is_forwarded(tmp_path, capfd):
+    s = _script(tmp_path, """
+        import json, os, sys
+        r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        assert os.environ["LOCAL_RANK"] == str(r) and os.environ["LOCAL_WORLD_SIZE"] == str(w)
+        assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+        assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        print("chatter from rank", r)
+        if r == 0:
+            print(json.dumps({"metric": "m", "n_gpus": w, "argv": sys.argv[1:]}))
+    """)
+    rc = bench.launch_ranks(3, ["--gpus", "3", "--steps", "7"], script=s)
+    out, err = capfd.readouterr()
+    assert rc == 0
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1                                   # ONE JSON line on stdout, the chatter went to stderr
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 3 and rec["argv"] == ["--gpus", "3", "--steps", "7"]
+    assert err.count("chatter from rank") == 3
+
+
+def test_worst_exit_code_is_returned_and_stragglers_are_ended(tmp_path, capfd):
+    s = _script(tmp_path, """
+        import os, sys, time
+        r = int(os.environ["RANK"])
+        if r == 1:
+            sys.exit(3)                                      # "RCCL could not form"
+        if r == 2:
+            time.sleep(600)                                  # a rank left waiting in a collective
+        sys.exit(0)
+    """)
+    rc = bench.launch_ranks(3, [], script=s, grace_s=0.5)
+    capfd.readouterr()
+    assert rc == 128 + 15                                    # the straggler was terminated (SIGTERM), which outranks 3
+    s = _script(tmp_path, "import os, sys; sys.exit(3)")
+    assert bench.launch_ranks(2, [], script=s) == 3
+
+
+def test_clean_exit_without_a_line_is_an_error(tmp_path, capfd):
+    s = _script(tmp_path, "pass")
+    assert bench.launch_ranks(2, [], script=s) == 1
+    assert "no JSON line" in capfd.readouterr().err
+
+
+def test_bench_parent_stays_gpu_free(tmp_path):
+    """`python bench.py --gpus 2` as a program: the parent neither imports torch nor loads the library (checked through
+    a sitecustomize hook that refuses both in the parent only) and hands its arguments to the ranks."""
+    (tmp_path / "sitecustomize.py").write_text(textwrap.dedent("""
+        import builtins, os, sys
+        if "WORLD_SIZE" not in os.environ:
+            real = builtins.__import__
+            def guard(name, *a, **k):
+                if name.split(".")[0] in ("torch", "conjugategradient_amd"):
+                    raise ImportError("the launcher parent imported " + name)
+                return real(name, *a, **k)
+            builtins.__import__ = guard
+    """))
+    stub = _script(tmp_path, """
+        import json, os, sys
+        if os.environ["RANK"] == "0":
+            print(json.dumps({"metric": "stub", "argv": sys.argv[1:]}))
+    """)
+    env = dict(os.environ, PYTHONPATH=str(tmp_path), MGCG_BENCH_RANK_SCRIPT=stub)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["argv"] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
