@@ -14,7 +14,8 @@ import os
 
 DLL_NAME = "libMgcgGpu.so"  # MgcgGpu.cs:11 has "MgcgGpu.dll"
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, DLL_NAME)
+# MGCG_LIB_PATH: the lab build of the same sources (make -C csrc lab) for tools/spmv_sweep.py --ablate; never set by tests or bench.py
+LIB_PATH = os.environ.get("MGCG_LIB_PATH") or os.path.join(_PKG, DLL_NAME)
 
 _vp = C.c_void_p
 _i = C.c_int
@@ -64,6 +65,9 @@ SIGNATURES = {
     "MgcgGetLastError": (C.c_char_p, []),
     "MgcgClearLastError": (None, []),
     "MgcgAbiVersion": (_i, []),
+    "MgcgSetTuning": (_i, [C.c_char_p, _i]),
+    "MgcgGetTuning": (_i, [C.c_char_p, _pi]),
+    "MgcgReloadEnvironment": (None, []),
     "MgcgDeviceSynchronize": (_i, []),
     "MgcgEventCreate": (_vp, []),
     "MgcgEventRecord": (None, [_vp]),

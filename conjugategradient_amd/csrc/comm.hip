@@ -271,7 +271,7 @@ HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long 
     for (int q = 0; q < n; ++q) h->contiguousRecv += h->recvCount[q];
     // Unstructured slices: the contiguous ranges degenerate to (nearly) the whole vector.  Whether index lists pay is a
     // collective decision (every rank must take the same path): all ranks look at the same table.
-    static const bool noIndex = getenv("MGCG_NO_INDEXED_HALO") != nullptr;
+    const bool noIndex = tuning().noIndexedHalo.load(std::memory_order_relaxed) != 0;
     bool wide = false;
     for (int q = 0; q < n; ++q) {
         const long long qCnt = all[4 * q + 1], qMin = all[4 * q + 2], qMax = all[4 * q + 3];

@@ -35,6 +35,34 @@ void set_error(const char* fmt, ...);
 bool hip_ok(hipError_t e, const char* what, const char* file, int line);
 #define MGCG_HIP(call) ::mgcg::hip_ok((call), #call, __FILE__, __LINE__)
 
+// ---------------------------------------------------------------- tuning knobs
+// Every MGCG_* environment variable the library honours is read ONCE (first use) into this block of atomics; launches read
+// the atomics, never the environment (getenv racing a setenv of another thread is undefined, and ranks that read different
+// values would take different collective paths).  MgcgSetTuning(name, value) changes one knob for the in-process A/B tools,
+// MgcgReloadEnvironment() reads the environment again.  Nothing here changes results: every knob picks between bit-identical
+// schedules (include/MgcgGpu.h lists them).
+struct Tuning {
+    std::atomic<int> overlap{1};             // MGCG_OVERLAP            0 off, 1 when it pays, 2 whenever an interior exists
+    std::atomic<int> noFold{0};              // MGCG_NO_FOLD            V(1,*): store the first sweep instead of forming it per gather
+    std::atomic<int> noFoldedFinalize{0};    // MGCG_NO_FOLDED_FINALIZE separate finalisation kernel
+    std::atomic<int> checkEvery{4};          // MGCG_CHECK_EVERY        iterations the host enqueues ahead of the stop flag
+    std::atomic<int> noUniformDiagonal{0};   // MGCG_NO_UNIFORM_DIAGONAL read the D^-1 array even when it is constant
+    std::atomic<int> noZsweep{0};            // MGCG_NO_ZSWEEP          memory-order tiles
+    std::atomic<int> rowtileNt{-1};          // MGCG_ROWTILE_NT         -1 by size, 0 / 1 forced
+    std::atomic<int> vecNt{-1};              // MGCG_VEC_NT             -1 by size, 0 / 1 forced
+    std::atomic<int> vecGrid{0}, rGrid{0}, xpGrid{0};      // MGCG_VEC_GRID / MGCG_R_GRID / MGCG_XP_GRID  workgroup caps (0: default)
+    std::atomic<int> patternGroup{0}, patternWaves{16};    // MGCG_PATTERN_GROUP / MGCG_PATTERN_WAVES
+    std::atomic<int> noIndexedHalo{0};       // MGCG_NO_INDEXED_HALO
+    std::atomic<int> tileNt{0}, tileShift{0};              // MGCG_TILE_NT / MGCG_TILE_SHIFT (0: default 19)
+    std::atomic<int> verbose{0};             // MGCG_VERBOSE            errors also go to stderr
+    std::atomic<int> lazyCodeObjects{0};     // MGCG_LAZY_CODE_OBJECTS
+    std::atomic<int> virtualDevices{0};      // MGCG_VIRTUAL_DEVICES    one physical GPU shown as n devices (tests)
+    std::atomic<int> forceMultiRank{0};      // MGCG_FORCE_MULTIRANK    a one-rank communicator takes the several-ranks code path (measurement)
+    std::atomic<int> wideAllReduce{0};       // MGCG_WIDE_ALLREDUCE     several ranks: all-reduce the partial-sum arrays (no reduction launch)
+};
+Tuning& tuning();
+void tuning_reload();
+
 // ---------------------------------------------------------------- per-device state
 // One stream per device, shared by every handle created on that device, so calls made through
 // different handles stay ordered exactly as they are on the reference's default stream.
@@ -191,6 +219,12 @@ enum SpmvEpilogue {
     EPI_AXPBY_BETA = 5,  // internal: EPI_AXPBY with beta != 0 (reads y)
     EPI_JACOBI_DOT = 6   // EPI_JACOBI ; partial += b_i * y_i   (last sweep of the V-cycle: r.z of the PCG loop rides along)
 };
+// Timing ablations that produce WRONG results exist only in lab builds of the library (make lab: -DMGCG_LAB).
+#ifdef MGCG_LAB
+#define MGCG_ABLATE(a, bits) (((a).ablate & (bits)) != 0)
+#else
+#define MGCG_ABLATE(a, bits) false
+#endif
 constexpr bool epi_has_dot(int e) { return e == EPI_DOT || e == EPI_RESIDUAL_DOT || e == EPI_JACOBI_DOT; }
 
 struct SpmvArgs {
@@ -213,7 +247,7 @@ struct SpmvArgs {
     double xInner, xOuter;   //   (a first Jacobi sweep from zero folded into the residual pass of the V-cycle)
     double* partials;        // EPI_DOT / EPI_RESIDUAL_DOT / EPI_JACOBI_DOT: one double per workgroup
     const int* doneFlag;     // optional: exit at once when *doneFlag != 0
-    int ablate;              // diagnostics only (tools/spmv_sweep.py --ablate): bit0 skip the y store, bit1 gathers from L1
+    int ablate;              // lab builds only (-DMGCG_LAB, tools/spmv_sweep.py --ablate): bit0 skip the y store, bit1 gathers from L1; the product never reads it
 };
 
 // Kernel family by average row length (measured on banded and random matrices, profiles/r1/rowlen_sweep.log):

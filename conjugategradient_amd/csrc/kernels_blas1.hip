@@ -47,7 +47,8 @@ __device__ __forceinline__ double block_max(double v, double* s_red)
 
 static inline int grid_for(long long n, int perThread)
 {
-    static const int cap = [] { const char* e = getenv("MGCG_VEC_GRID"); const int v = e ? atoi(e) : 0; return (v >= 64 && v <= kMaxGrid) ? v : kMaxGrid; }();   // (A/B knob)
+    const int knob = tuning().vecGrid.load(std::memory_order_relaxed);
+    const int cap = (knob >= 64 && knob <= kMaxGrid) ? knob : kMaxGrid;
     long long blocks = (n + (long long)kBlock * perThread - 1) / ((long long)kBlock * perThread);
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
@@ -64,8 +65,8 @@ template <bool NTV, typename T> __device__ __forceinline__ T ldv(const T* p) { i
 template <bool NTV, typename T> __device__ __forceinline__ void stv(const T& v, T* p) { if constexpr (NTV) __builtin_nontemporal_store(v, p); else *p = v; }
 static bool vec_nt(long long n)
 {
-    const char* e = getenv("MGCG_VEC_NT");
-    return e ? atoi(e) != 0 : n > 3000000;
+    const int knob = tuning().vecNt.load(std::memory_order_relaxed);
+    return knob >= 0 ? knob != 0 : n > 3000000;
 }
 
 template <bool V2, typename F2, typename F1>
@@ -362,7 +363,8 @@ int launch_update_r(hipStream_t s, CgScalars* sc, double* r, const double* Ap, l
     int grid = grid_for(n, v2 ? 4 : 2);
     // two workgroups per CU measured best for this 2-reads-1-write pass (0.565 ms against 0.59-0.61 for 768 / 1024 / 2048 and 0.72 for 256
     // workgroups at 512^3; the 3-reads-2-writes x/p pass keeps 2048); MGCG_R_GRID overrides
-    const int rcap = [] { const char* e = getenv("MGCG_R_GRID"); const int v = e ? atoi(e) : 0; return (v >= 64 && v <= kMaxGrid) ? v : 0; }();   // (read per launch: tools/slab_grid_ab.py)
+    const int rknob = tuning().rGrid.load(std::memory_order_relaxed);                 // (tools/slab_grid_ab.py)
+    const int rcap = (rknob >= 64 && rknob <= kMaxGrid) ? rknob : 0;
     DeviceState* d = device_state();
     const int want = rcap > 0 ? rcap : 2 * (d ? d->numCu : kNumCu);
     if (grid > want) grid = want;
@@ -517,7 +519,7 @@ void launch_update_xp_final(hipStream_t s, const FinalizeArgs& f, const double* 
     const bool v2 = al16(x) && al16(p) && al16(z);
     const bool nt = vec_nt(n);
     int g2 = grid_for(n, 2);
-    if (const char* e = getenv("MGCG_XP_GRID")) { const int v = atoi(e); if (v >= 64 && v <= 16384 && v < g2) g2 = v; }      // (A/B: tools/slab_grid_ab.py)
+    { const int v = tuning().xpGrid.load(std::memory_order_relaxed); if (v >= 64 && v <= 16384 && v < g2) g2 = v; }      // (A/B: tools/slab_grid_ab.py)
     if (v2 && nt) hipLaunchKernelGGL((update_xp_final_kernel<true, true>), dim3(g2), dim3(kBlock), 0, s, f, partials, partialsInf, nPartials, x, p, z, n);
     else if (v2) hipLaunchKernelGGL((update_xp_final_kernel<true, false>), dim3(g2), dim3(kBlock), 0, s, f, partials, partialsInf, nPartials, x, p, z, n);
     else hipLaunchKernelGGL((update_xp_final_kernel<false, false>), dim3(grid_for(n, 1)), dim3(kBlock), 0, s, f, partials, partialsInf, nPartials, x, p, z, n);

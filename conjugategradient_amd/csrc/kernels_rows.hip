@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64) void spmv_rows_kernel(SpmvArgs a, DcsrView m, i
                     if constexpr (FMT == FMT_DCSR8) vv[j] = s_vD[s_vc[idx]]; else vv[j] = s_val[idx];
                 }
                 if (j >= cnt) col = 0;                                // masked: any valid column
-                if (a.ablate & 2) col &= 1023;
+                if (MGCG_ABLATE(a, 2)) col &= 1023;
                 xg[j] = a.x[col];
             }
             long long myRow = r0 + tid;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64) void spmv_rows_kernel(SpmvArgs a, DcsrView m, i
             const RowsEpi eo = rows_epi_prefetch<EPI>(a, myRow);
             // the next block's raw stream goes in flight behind the gathers, then the previous trip's result
             issue(nxt, t + 1 < nTrips ? rb_of(t + 1) : rb);
-            if (pendRow >= 0 && !(a.ablate & 1)) a.y[pendRow] = pendVal;
+            if (pendRow >= 0 && !MGCG_ABLATE(a, 1)) a.y[pendRow] = pendVal;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const double p = vv[j] * xg[j]; acc += (j < cnt) ? p : 0.0; }
             k += cnt;
@@ -202,12 +202,12 @@ __global__ __launch_bounds__(64) void spmv_rows_kernel(SpmvArgs a, DcsrView m, i
             }
             pendRow = -1;
             if (tid < nr) { pendVal = rows_epilogue_value<EPI>(a, acc, eo, dotacc); pendRow = r0 + tid; }
-            if ((a.ablate & 1) && acc == 1.2345e300) pendRow = 0;
+            if (MGCG_ABLATE(a, 1) && acc == 1.2345e300) pendRow = 0;
             __syncthreads();                                          // LDS is free for the next trip
             cur = nxt;
             nxt.s = s2; nxt.e = e2;
         }
-        if (pendRow >= 0 && !(a.ablate & 1)) a.y[pendRow] = pendVal;
+        if (pendRow >= 0 && !MGCG_ABLATE(a, 1)) a.y[pendRow] = pendVal;
     }
     if constexpr (epi_has_dot(EPI)) {
         double v = dotacc;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64) void spmv_pattern_kernel(SpmvArgs a, DcsrView m
                 for (int j = 0; j < CH; ++j) {
                     vv[u][j] = s_val[tb[u] + j];
                     long long col = g + s_delta[tb[u] + j];
-                    if (a.ablate & 2) col &= 1023;                 // diagnostics: gathers served from L1
+                    if (MGCG_ABLATE(a, 2)) col &= 1023;           // lab builds: gathers served from L1
                     xg[u][j] = a.x[col];
                 }
             }
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(64) void spmv_pattern_kernel(SpmvArgs a, DcsrView m
         for (int u = 0; u < RPL; ++u)
             if (live[u]) {
                 const double v = rows_epilogue_value<EPI>(a, acc[u], eo[u], dotacc);
-                if (!(a.ablate & 1) || v == 1.2345e300) a.y[row[u]] = v;       // (bit0: diagnostics, no y store)
+                if (!MGCG_ABLATE(a, 1) || v == 1.2345e300) a.y[row[u]] = v;       // (lab builds, bit0: no y store)
             }
     }
     if constexpr (epi_has_dot(EPI)) {
@@ -374,13 +374,13 @@ __global__ __launch_bounds__(64) void spmv_pattern_kernel(SpmvArgs a, DcsrView m
 
 static int pattern_group_blocks()
 {
-    static int v = [] { const char* e = getenv("MGCG_PATTERN_GROUP"); const int r = e ? atoi(e) : 0; return (r >= 0 && r <= 65536) ? r : 0; }();
-    return v;
+    const int r = tuning().patternGroup.load(std::memory_order_relaxed);
+    return (r >= 0 && r <= 65536) ? r : 0;
 }
 static int pattern_waves_per_cu()
 {
-    static int v = [] { const char* e = getenv("MGCG_PATTERN_WAVES"); const int r = e ? atoi(e) : 16; return (r >= 1 && r <= 32) ? r : 16; }();
-    return v;
+    const int r = tuning().patternWaves.load(std::memory_order_relaxed);
+    return (r >= 1 && r <= 32) ? r : 16;
 }
 
 template <int EPI>
@@ -394,7 +394,7 @@ static int launch_pattern_epi(hipStream_t s, const SpmvArgs& a, const DcsrView& 
     if (grid < 1) grid = 1;
     const size_t lds = (size_t)m.nPattern * m.patWidth * 12 + (size_t)m.nPattern * 4;
     const int group = (grid % 8 == 0 && nRowBlocks >= 64 * 8) ? pattern_group_blocks() : 0;
-    static const bool noSweep = getenv("MGCG_NO_ZSWEEP") != nullptr;
+    const bool noSweep = tuning().noZsweep.load(std::memory_order_relaxed) != 0;
     TileMap tm = make_tile_map(a.rowCount, (noSweep || group > 0 || a.rowCount % 128 != 0) ? 0 : periodRows, grid, 128);
     // slots per pass = the longest row when it is 5 or 7 (the 2-D / 3-D stencils), else 8
     if (m.patWidth == 7) hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 7>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks, group, tm);

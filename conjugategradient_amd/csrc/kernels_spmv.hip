@@ -260,7 +260,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs a, int nRow
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         int c0 = cur.col[c][h].x, c1 = cur.col[c][h].y;
-                        if (a.ablate & 2) { c0 &= 1023; c1 &= 1023; }      // diagnostic: gathers served from L1
+                        if (MGCG_ABLATE(a, 2)) { c0 &= 1023; c1 &= 1023; }      // lab builds: gathers served from L1
                         xg[c][h][0] = a.x[c0]; xg[c][h][1] = a.x[c1];
                     }
                 }
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs a, int nRow
             // (3) the next block's matrix stream goes in flight behind them (the last trip re-reads its own block)
             issue(nxt, t + 1 < nTrips ? rb_of(t + 1) : rb);
             // (4) the previous trip's result
-            if (pendRow >= 0 && !(a.ablate & 1)) a.y[(a.ablate & 8) ? (pendRow & 0xFFFF) : pendRow] = pendVal;   // bit3: diagnostic, stores stay in L2
+            if (pendRow >= 0 && !MGCG_ABLATE(a, 1)) a.y[MGCG_ABLATE(a, 8) ? (pendRow & 0xFFFF) : pendRow] = pendVal;   // (lab builds, bit3: stores stay in L2)
             // ---- products of the current block to LDS ----
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
@@ -329,12 +329,12 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs a, int nRow
             }
             pendRow = -1;
             if (tid < nr) { pendVal = spmv_epilogue_value<EPI>(a, acc, eo, dotacc); pendRow = r0 + tid; }
-            if ((a.ablate & 1) && acc == 1.2345e300) pendRow = 0;     // diagnostic (no y store): keep acc alive
+            if (MGCG_ABLATE(a, 1) && acc == 1.2345e300) pendRow = 0;     // lab builds (no y store): keep acc alive
             __syncthreads();                                          // LDS is free for the next trip
             cur = nxt;
             nxt.s = s2; nxt.e = e2;
         }
-        if (pendRow >= 0 && !(a.ablate & 1)) a.y[pendRow] = pendVal;
+        if (pendRow >= 0 && !MGCG_ABLATE(a, 1)) a.y[pendRow] = pendVal;
     }
     if constexpr (epi_has_dot(EPI)) {
         double t = wave_sum(dotacc);

@@ -210,8 +210,7 @@ __global__ __launch_bounds__(kBlock) void tiled_epilogue_kernel(SpmvArgs a)
 
 static bool tile_streams_nontemporal()
 {
-    static const bool v = [] { const char* e = getenv("MGCG_TILE_NT"); return e != nullptr && atoi(e) != 0; }();
-    return v;
+    return tuning().tileNt.load(std::memory_order_relaxed) != 0;
 }
 
 template <int EPI>
@@ -269,7 +268,7 @@ bool tiled_build(hipStream_t s, const double* elements, const int* rowOffsets, c
                  long long rows, long long nnz, long long rowBase, long long columns, DcsrMatrix* out)
 {
     int tileShift = 19;                                            // 2^19 columns = 4 MiB of x per tile (one XCD's L2)
-    if (const char* e = getenv("MGCG_TILE_SHIFT")) { const int v = atoi(e); if (v >= 8 && v <= 26) tileShift = v; }
+    { const int v = tuning().tileShift.load(std::memory_order_relaxed); if (v >= 8 && v <= 26) tileShift = v; }
     const long long tileCols = 1LL << tileShift;
     const int nTiles = (int)((columns + tileCols - 1) / tileCols);
     if (rows <= 0 || nnz <= 0 || nTiles < 4 || nTiles > 256) return true;            // x fits a few L2s, or absurdly many passes

@@ -53,7 +53,9 @@ void CsrMV(MgcgSparse* cusparse, MgcgMatDescr* matDescr, double* y,
     SpmvArgs a{};
     a.elements = elements; a.rowOffsets = rowOffsets; a.columnIndeces = columnIndeces; a.x = x; a.y = y;
     a.elementsCount = elementsCount; a.rowCount = rowCount; a.columnCount = columnCount; a.alpha = alpha; a.beta = beta;
-    if (const char* ab = getenv("MGCG_SPMV_ABLATE")) a.ablate = atoi(ab);     // timing diagnostics only (wrong results)
+#ifdef MGCG_LAB
+    if (const char* ab = getenv("MGCG_SPMV_ABLATE")) a.ablate = atoi(ab);     // lab builds only: timing ablations with WRONG results
+#endif
     const DcsrMatrix* dc = dcsr_lookup(cusparse, elements, rowOffsets, columnIndeces, rowCount, elementsCount, 0, columnCount);
     analysis_note_write(y, sizeof(double) * (size_t)rowCount);
     launch_spmv_auto(cusparse->ws.stream, EPI_AXPBY, a, cfg_for(cusparse, a, 0), dc);
@@ -68,7 +70,9 @@ double CsrMVDot(MgcgBlas* cublas, MgcgSparse* cusparse, double* y,
     if (!cublas || !cusparse || !y || !rowOffsets || !x || !w) { set_error("CsrMVDot: null argument"); return NAN; }
     if (rowCount <= 0) return 0.0;
     SpmvArgs a{};
-    if (const char* ab = getenv("MGCG_SPMV_ABLATE")) a.ablate = atoi(ab);     // timing diagnostics only
+#ifdef MGCG_LAB
+    if (const char* ab = getenv("MGCG_SPMV_ABLATE")) a.ablate = atoi(ab);
+#endif
     a.elements = elements; a.rowOffsets = rowOffsets; a.columnIndeces = columnIndeces; a.x = x; a.y = y;
     a.elementsCount = elementsCount; a.rowCount = rowCount; a.columnCount = columnCount; a.w = w; a.partials = cublas->ws.partials;
     const DcsrMatrix* dc = dcsr_lookup(cusparse, elements, rowOffsets, columnIndeces, rowCount, elementsCount, 0, columnCount);

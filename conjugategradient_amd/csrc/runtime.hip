@@ -15,8 +15,47 @@ void set_error(const char* fmt, ...)
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     t_lastError = buf;
-    if (getenv("MGCG_VERBOSE")) fprintf(stderr, "[MgcgGpu] %s\n", buf);
+    if (tuning().verbose.load(std::memory_order_relaxed)) fprintf(stderr, "[MgcgGpu] %s\n", buf);
 }
+
+// ---------------------------------------------------------------- tuning knobs (common.hpp)
+namespace {
+struct Knob { const char* env; const char* name; std::atomic<int> Tuning::*field; int unset; bool flag; };   // flag: the variable's presence means 1
+const Knob kKnobs[] = {
+    { "MGCG_OVERLAP", "overlap", &Tuning::overlap, 1, false },
+    { "MGCG_NO_FOLD", "no_fold", &Tuning::noFold, 0, true },
+    { "MGCG_NO_FOLDED_FINALIZE", "no_folded_finalize", &Tuning::noFoldedFinalize, 0, true },
+    { "MGCG_CHECK_EVERY", "check_every", &Tuning::checkEvery, 4, false },
+    { "MGCG_NO_UNIFORM_DIAGONAL", "no_uniform_diagonal", &Tuning::noUniformDiagonal, 0, true },
+    { "MGCG_NO_ZSWEEP", "no_zsweep", &Tuning::noZsweep, 0, true },
+    { "MGCG_ROWTILE_NT", "rowtile_nt", &Tuning::rowtileNt, -1, false },
+    { "MGCG_VEC_NT", "vec_nt", &Tuning::vecNt, -1, false },
+    { "MGCG_VEC_GRID", "vec_grid", &Tuning::vecGrid, 0, false },
+    { "MGCG_R_GRID", "r_grid", &Tuning::rGrid, 0, false },
+    { "MGCG_XP_GRID", "xp_grid", &Tuning::xpGrid, 0, false },
+    { "MGCG_PATTERN_GROUP", "pattern_group", &Tuning::patternGroup, 0, false },
+    { "MGCG_PATTERN_WAVES", "pattern_waves", &Tuning::patternWaves, 16, false },
+    { "MGCG_NO_INDEXED_HALO", "no_indexed_halo", &Tuning::noIndexedHalo, 0, true },
+    { "MGCG_TILE_NT", "tile_nt", &Tuning::tileNt, 0, false },
+    { "MGCG_TILE_SHIFT", "tile_shift", &Tuning::tileShift, 0, false },
+    { "MGCG_VERBOSE", "verbose", &Tuning::verbose, 0, true },
+    { "MGCG_LAZY_CODE_OBJECTS", "lazy_code_objects", &Tuning::lazyCodeObjects, 0, true },
+    { "MGCG_VIRTUAL_DEVICES", "virtual_devices", &Tuning::virtualDevices, 0, false },
+    { "MGCG_FORCE_MULTIRANK", "force_multirank", &Tuning::forceMultiRank, 0, false },
+    { "MGCG_WIDE_ALLREDUCE", "wide_allreduce", &Tuning::wideAllReduce, 0, false },
+};
+Tuning g_tuning;
+std::once_flag g_tuningOnce;
+void tuning_read_environment()
+{
+    for (const Knob& k : kKnobs) {
+        const char* e = getenv(k.env);
+        (g_tuning.*(k.field)).store(e ? (k.flag ? 1 : atoi(e)) : k.unset, std::memory_order_relaxed);
+    }
+}
+} // namespace
+Tuning& tuning() { std::call_once(g_tuningOnce, tuning_read_environment); return g_tuning; }
+void tuning_reload() { (void)tuning(); tuning_read_environment(); }
 
 bool hip_ok(hipError_t e, const char* what, const char* file, int line)
 {
@@ -37,8 +76,8 @@ static int physical_count()
 }
 static int virtual_count()
 {
-    const char* v = getenv("MGCG_VIRTUAL_DEVICES");
-    if (v && atoi(v) > 0 && physical_count() > 0) return atoi(v);
+    const int v = tuning().virtualDevices.load(std::memory_order_relaxed);
+    if (v > 0 && physical_count() > 0) return v;
     return physical_count();
 }
 
@@ -71,7 +110,7 @@ DeviceState* device_state()
         if (!MGCG_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking))) return nullptr;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, pd) == hipSuccess) d->numCu = prop.multiProcessorCount;
-        if (!getenv("MGCG_LAZY_CODE_OBJECTS")) {
+        if (!tuning().lazyCodeObjects.load(std::memory_order_relaxed)) {
             preload_kernels_spmv(); preload_kernels_rowtile(); preload_kernels_blas1(); preload_solver(); preload_ops();
             preload_kernels_rows(); preload_kernels_mg(); preload_kernels_dcsr(); preload_kernels_tiled(); preload_comm(); preload_spectrum();
         }
@@ -300,7 +339,23 @@ extern "C" {
 
 const char* MgcgGetLastError(void) { return mgcg::t_lastError.c_str(); }
 void MgcgClearLastError(void) { mgcg::t_lastError.clear(); }
-int MgcgAbiVersion(void) { return 1; }
+int MgcgAbiVersion(void) { return 2; }
+
+void MgcgReloadEnvironment(void) { mgcg::tuning_reload(); }
+int MgcgSetTuning(const char* name, int value)
+{
+    if (name) for (const mgcg::Knob& k : mgcg::kKnobs)
+        if (strcmp(name, k.name) == 0 || strcmp(name, k.env) == 0) { (mgcg::tuning().*(k.field)).store(value, std::memory_order_relaxed); return 0; }
+    mgcg::set_error("MgcgSetTuning: unknown knob '%s'", name ? name : "(null)");
+    return -1;
+}
+int MgcgGetTuning(const char* name, int* value)
+{
+    if (name && value) for (const mgcg::Knob& k : mgcg::kKnobs)
+        if (strcmp(name, k.name) == 0 || strcmp(name, k.env) == 0) { *value = (mgcg::tuning().*(k.field)).load(std::memory_order_relaxed); return 0; }
+    mgcg::set_error("MgcgGetTuning: unknown knob '%s'", name ? name : "(null)");
+    return -1;
+}
 
 int GetDeviceCount(void) { return virtual_count(); }
 

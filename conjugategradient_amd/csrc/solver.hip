@@ -66,8 +66,7 @@ static bool plan_overlap(hipStream_t s, MgcgComm* comm, int nranks, const int* r
                          long long n, long long offset, bool* active, long long* i0, long long* i1)
 {
     *active = false; *i0 = 0; *i1 = 0;
-    int mode = 1;
-    if (const char* e = getenv("MGCG_OVERLAP")) mode = atoi(e);
+    const int mode = tuning().overlap.load(std::memory_order_relaxed);
     if (nranks <= 1 || mode == 0 || (mode == 1 && n < 4096)) return true;
     int* d2 = nullptr;
     if (!MGCG_HIP(hipMalloc((void**)&d2, 2 * sizeof(int)))) return false;
@@ -150,7 +149,7 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
     // the residual pass forms x1[col] per gather and the prolongation forms x1[i] again when it adds the correction
     const bool linear = mg->interp == 1;
     const bool fold = mg->nu == 1 && mg->nranks == 1 && !linear && L.dinvUniform && L.dcsr != nullptr && L.dcsr->usable && L.dcsr->patternId != nullptr &&
-                      getenv("MGCG_NO_FOLD") == nullptr;
+                      tuning().noFold.load(std::memory_order_relaxed) == 0;
     if (fold) cur = x0;
     else if (!mg_smooth(mg, L, b, x0, x1, mg->nu, true, done, &cur)) return false;
     double* other = (cur == x0) ? x1 : x0;
@@ -223,6 +222,7 @@ struct CgRun {
     // rows [interior0, interior1) reference local columns only: they are multiplied (side stream) while the halo of p is in flight
     bool overlap = false;
     long long interior0 = 0, interior1 = 0;
+    bool noFoldedFinalize = false;         // tuning knob, resolved once per solve (every iteration of every rank takes the same path)
 };
 
 static thread_local long long t_lastOverlap[3] = { 0, 0, 0 };
@@ -325,7 +325,7 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
     double* pInf = R.wantInf ? R.ws->partials + kMaxPartials : nullptr;
     double* rrPartials = R.ws->partials;
     // one rank, no preconditioner: the x/p update finalises the iteration itself (one launch fewer; MGCG_NO_FOLDED_FINALIZE for A/B)
-    const bool noFold = getenv("MGCG_NO_FOLDED_FINALIZE") != nullptr;          // (read per call: tools flip it inside one process)
+    const bool noFold = R.noFoldedFinalize;
     const bool fold = R.nranks == 1 && !R.mg && R.nLocal > 0 && !noFold;
     const bool foldRanks = R.nranks > 1 && !R.mg && R.nLocal > 0 && !noFold;         // several ranks: the same fold behind the all-reduce of r.r
     if (R.nranks > 1) {
@@ -402,9 +402,10 @@ static int cg_solve(CgRun& R, int* iteration, double* residual, double* residual
     double* savedTrace = R.ws->trace; const int savedCap = R.ws->traceCap;
     if (!devTraceCap) { R.ws->trace = nullptr; R.ws->traceCap = 0; } else R.ws->traceCap = devTraceCap;
 
+    R.noFoldedFinalize = tuning().noFoldedFinalize.load(std::memory_order_relaxed) != 0;
     int status = MGCG_ERROR;
     int checkEvery = 4;
-    if (const char* e = getenv("MGCG_CHECK_EVERY")) { checkEvery = atoi(e); if (checkEvery < 1) checkEvery = 1; }
+    { const int v = tuning().checkEvery.load(std::memory_order_relaxed); if (v >= 1) checkEvery = v; }
     const long long hostCap = (long long)(R.maxIt > R.minIt ? R.maxIt : R.minIt) + 4;
     hipEvent_t ev[2] = { nullptr, nullptr };
     volatile int* slots = (volatile int*)&R.ws->hostScalar[2];   // two ints per double: slots[0..3]
@@ -554,6 +555,7 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     R.dcsr = dcsr_lookup(cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset, R.count);
     if (R.elementsCount >= 8) R.cfg.periodRows = spmv_period(cusparse, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.cfg.maxRow);
     R.cfg.flags |= 8;
+    R.noFoldedFinalize = tuning().noFoldedFinalize.load(std::memory_order_relaxed) != 0;
     if (ok && restart) ok = cg_enqueue_init(R);
     else if (ok) hipLaunchKernelGGL(clear_done_kernel, dim3(1), dim3(1), 0, R.ws->stream, R.ws->scalars);
     for (int k = 0; ok && k < steps; ++k) ok = cg_enqueue_iteration(R, false);
@@ -686,7 +688,7 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
             if (ok) launch_uniform_check(s, L.dinv, L.n, dmm);
             ok = ok && MGCG_HIP(hipMemcpyAsync(&differs, dmm, sizeof(int), hipMemcpyDeviceToHost, s)) &&
                  MGCG_HIP(hipMemcpyAsync(&L.dinvScalar, L.dinv, sizeof(double), hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
-            L.dinvUniform = ok && differs == 0 && getenv("MGCG_NO_UNIFORM_DIAGONAL") == nullptr;
+            L.dinvUniform = ok && differs == 0 && tuning().noUniformDiagonal.load(std::memory_order_relaxed) == 0;
         }
         if (ok) L.dcsr = dcsr_lookup(cusparse, L.elements, L.rowOffsets, L.columnIndeces, L.n, L.nnz, L.offset);
         L.cfg = mg->cfg;

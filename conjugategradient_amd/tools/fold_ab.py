@@ -22,17 +22,14 @@ def main():
         out = {0: [], 1: []}
         for rep in range(4):
             for nofold in (0, 1):
-                if nofold:
-                    os.environ["MGCG_NO_FOLDED_FINALIZE"] = "1"
-                else:
-                    os.environ.pop("MGCG_NO_FOLDED_FINALIZE", None)
+                L.MgcgSetTuning(b"no_folded_finalize", nofold)
                 cg.Steps(5, restart=False)
                 L.MgcgDeviceSynchronize()
                 t0 = time.perf_counter()
                 cg.Steps(steps, restart=False)
                 L.MgcgDeviceSynchronize()
                 out[nofold].append((time.perf_counter() - t0) / steps * 1e6)
-        os.environ.pop("MGCG_NO_FOLDED_FINALIZE", None)
+        L.MgcgSetTuning(b"no_folded_finalize", 0)
         f, s = sorted(out[0])[1], sorted(out[1])[1]
         print(f"{nx}x{ny}x{nz}: folded {f:9.2f} us per iteration | separate finalize kernel {s:9.2f} us | {100 * (s - f) / s:+.1f} %", flush=True)
         cg.Dispose()

@@ -44,10 +44,7 @@ def main():
 
     def env(name):
         def f(v):
-            if v is None:
-                os.environ.pop(name, None)
-            else:
-                os.environ[name] = str(v)
+            L.MgcgSetTuning(name.encode(), 0 if v is None else int(v))
         return f
 
     sweep(f"512x512x{planes} tile order (1 = memory order instead of the z sweep)", [None, 1], env("MGCG_NO_ZSWEEP"))

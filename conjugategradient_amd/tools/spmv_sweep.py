@@ -61,7 +61,7 @@ def main():
     times = {v[0]: [] for v in variants}
 
     def run(v):
-        os.environ["MGCG_SPMV_ABLATE"] = str(v[7]) if len(v) > 7 else "0"
+        os.environ["MGCG_SPMV_ABLATE"] = str(v[7]) if len(v) > 7 else "0"     # honoured by lab builds of the library only (make -C csrc lab)
         L.MgcgSetMatrixCompression(sparse, 2 if "dcsr" in v[0] else (1 if "pattern" in v[0] else 0))
         L.MgcgSetSpmvKernel(sparse, v[1])
         L.MgcgSetSpmvTuning(sparse, v[2], v[3], v[4])

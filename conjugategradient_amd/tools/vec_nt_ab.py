@@ -22,14 +22,14 @@ def main():
         out = {0: [], 1: []}
         for rep in range(4):
             for nofold in (0, 1):
-                os.environ["MGCG_VEC_NT"] = "1" if nofold else "0"
+                L.MgcgSetTuning(b"vec_nt", 1 if nofold else 0)
                 cg.Steps(5, restart=False)
                 L.MgcgDeviceSynchronize()
                 t0 = time.perf_counter()
                 cg.Steps(steps, restart=False)
                 L.MgcgDeviceSynchronize()
                 out[nofold].append((time.perf_counter() - t0) / steps * 1e6)
-        os.environ.pop("MGCG_VEC_NT", None)
+        L.MgcgSetTuning(b"vec_nt", -1)
         f, s = sorted(out[0])[1], sorted(out[1])[1]
         print(f"{nx}x{ny}x{nz}: plain vector accesses {f:9.2f} us per iteration | non-temporal vector accesses {s:9.2f} us | {100 * (s - f) / s:+.1f} %", flush=True)
         cg.Dispose()

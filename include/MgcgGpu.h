@@ -158,6 +158,19 @@ const char* MgcgGetLastError(void);
 void        MgcgClearLastError(void);
 /* Library ABI revision. */
 int         MgcgAbiVersion(void);
+/* Tuning knobs.  Every MGCG_* environment variable the library honours is read once, at first use; launches never read
+ * the environment.  All knobs choose between schedules that give bit-identical results:
+ *   overlap (MGCG_OVERLAP: 0 halo exchange in line, 1 hidden behind interior rows when it pays [default], 2 whenever an
+ *   interior exists), no_fold, no_folded_finalize, check_every (iterations enqueued ahead of the stop flag, default 4),
+ *   no_uniform_diagonal, no_zsweep, rowtile_nt / vec_nt (-1 by size, 0 / 1 forced), vec_grid, r_grid, xp_grid,
+ *   pattern_group, pattern_waves, no_indexed_halo, tile_nt, tile_shift, verbose, lazy_code_objects,
+ *   virtual_devices (MGCG_VIRTUAL_DEVICES: one physical GPU shown as n devices, tests only),
+ *   force_multirank (a one-rank communicator takes the several-ranks code path, measurement only), wide_allreduce.
+ * MgcgSetTuning / MgcgGetTuning take the knob's name or its environment variable; they return 0, or -1 for an unknown
+ * name (MgcgGetLastError).  MgcgReloadEnvironment reads all variables again.  Change knobs only while no solve is running. */
+int         MgcgSetTuning(const char* name, int value);
+int         MgcgGetTuning(const char* name, int* value);
+void        MgcgReloadEnvironment(void);
 /* Wait for the current device's stream.  Returns 0 on success. */
 int         MgcgDeviceSynchronize(void);
 /* Elapsed-time helpers on the current device's stream (HIP events). */

@@ -38,3 +38,33 @@ def hiplib():
 
 def golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+class _MgcgEnv:
+    """monkeypatch for the library's MGCG_* variables: the library reads its environment once (csrc/runtime.hip: tuning()),
+    so every change is followed by MgcgReloadEnvironment()."""
+
+    def __init__(self, monkeypatch):
+        self._mp = monkeypatch
+
+    @staticmethod
+    def _reload():
+        from conjugategradient_amd import _lib
+
+        _lib.lib().MgcgReloadEnvironment()
+
+    def setenv(self, name, value):
+        self._mp.setenv(name, value)
+        self._reload()
+
+    def delenv(self, name, raising=False):
+        self._mp.delenv(name, raising=raising)
+        self._reload()
+
+
+@pytest.fixture
+def mgcg_env(monkeypatch):
+    env = _MgcgEnv(monkeypatch)
+    yield env
+    monkeypatch.undo()
+    env._reload()

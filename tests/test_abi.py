@@ -87,3 +87,28 @@ def test_missing_library_is_an_error(tmp_path, monkeypatch):
             "_lib.LIB_PATH = %r; \ntry:\n _lib.lib()\nexcept _lib.MgcgError as e:\n print('raised', 'no CPU fallback' in str(e))") % (ROOT, str(tmp_path / "nope.so"))
     out = subprocess.check_output([sys.executable, "-c", code]).decode()
     assert "raised True" in out
+
+
+def test_tuning_knobs_are_read_once_and_settable(hiplib, monkeypatch):
+    """The library reads its MGCG_* variables once; knobs change through MgcgSetTuning / MgcgReloadEnvironment, never by a
+    launch looking at the environment.  No device needed."""
+    from conjugategradient_amd import _lib
+
+    L = hiplib
+    v = C.c_int(-99)
+    L.MgcgReloadEnvironment()
+    assert L.MgcgGetTuning(b"overlap", C.byref(v)) == 0 and v.value == 1          # default
+    assert L.MgcgGetTuning(b"check_every", C.byref(v)) == 0 and v.value == 4
+    monkeypatch.setenv("MGCG_OVERLAP", "2")
+    assert L.MgcgGetTuning(b"overlap", C.byref(v)) == 0 and v.value == 1          # the environment is not re-read ...
+    L.MgcgReloadEnvironment()
+    assert L.MgcgGetTuning(b"MGCG_OVERLAP", C.byref(v)) == 0 and v.value == 2     # ... until asked; the variable's name works too
+    assert L.MgcgSetTuning(b"overlap", 0) == 0
+    assert L.MgcgGetTuning(b"overlap", C.byref(v)) == 0 and v.value == 0
+    assert L.MgcgSetTuning(b"no_such_knob", 1) == -1 and "unknown knob" in _lib.last_error()
+    L.MgcgClearLastError()
+    monkeypatch.undo()
+    L.MgcgReloadEnvironment()
+    assert L.MgcgGetTuning(b"overlap", C.byref(v)) == 0 and v.value == 1
+    # the timing ablations that produce wrong results are not in the product library
+    assert b"MGCG_SPMV_ABLATE" not in open(_lib.LIB_PATH, "rb").read()

@@ -123,14 +123,14 @@ def test_compressed_solves_match_plain_bits(oracle):
 
 
 @pytest.mark.parametrize("mode", [1, 2])
-def test_compressed_multirank(oracle, monkeypatch, mode):
+def test_compressed_multirank(oracle, mgcg_env, mode):
     """Row slices with a non-zero row base (col - row uses the GLOBAL row) through the loopback transport."""
     from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu
     from tests.test_gpu_parallel import _run_ranks_in_threads
 
     world = 2
-    monkeypatch.setenv("MGCG_VIRTUAL_DEVICES", str(world))
-    monkeypatch.setenv("MGCG_OVERLAP", "2")              # compressed interior / boundary row ranges while the halo travels
+    mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    mgcg_env.setenv("MGCG_OVERLAP", "2")              # compressed interior / boundary row ranges while the halo travels
     s = problems.poisson(8, 8, 16)
     s.b[:] = np.random.default_rng(3).standard_normal(s.Count)
     ref = oracle.Multigrid(s).pcg(rule=oracle.RULE_CSHARP, max_iteration=400)
@@ -214,12 +214,12 @@ def test_too_many_distinct_rows_fall_back_to_codes_or_csr(oracle):
     h.close()
 
 
-def test_column_tiled_form_for_matrices_without_locality(oracle, monkeypatch):
+def test_column_tiled_form_for_matrices_without_locality(oracle, mgcg_env):
     """Class 4 (BASELINE config 5 in miniature; MGCG_TILE_SHIFT shrinks the tile so that a 40 000-column matrix needs 10
     tiles): sorted random rows are re-laid out by column tile, the running row sums travel through y from tile to tile
     in stored order -- bit-identical products; unsorted rows make the analysis decline."""
     L = _lib.lib()
-    monkeypatch.setenv("MGCG_TILE_SHIFT", "12")
+    mgcg_env.setenv("MGCG_TILE_SHIFT", "12")
     s = problems.random_spd(40000, mean_upper=14.0, seed=3)
     rng = np.random.default_rng(8)
     x = rng.standard_normal(s.Count)
@@ -258,15 +258,15 @@ def test_column_tiled_form_for_matrices_without_locality(oracle, monkeypatch):
     h.close()
 
 
-def test_column_tiles_on_row_slices_over_loopback(oracle, monkeypatch):
+def test_column_tiles_on_row_slices_over_loopback(oracle, mgcg_env):
     """Two ranks, unstructured matrix: every rank tiles its own row slice over the GLOBAL column range and the halo
     degenerates to an all-gather of p; same iteration count and solution as the multi-device oracle."""
     from conjugategradient_amd.parallel import ConjugateGradientRankGpu
     from tests.test_gpu_parallel import _run_ranks_in_threads
 
     world = 2
-    monkeypatch.setenv("MGCG_VIRTUAL_DEVICES", str(world))
-    monkeypatch.setenv("MGCG_TILE_SHIFT", "9")          # 512-column tiles: 12 of them, well below the mean |col - row| of both slices
+    mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    mgcg_env.setenv("MGCG_TILE_SHIFT", "9")          # 512-column tiles: 12 of them, well below the mean |col - row| of both slices
     s = problems.random_spd(6000, mean_upper=8.0, seed=17)
     s.b[:] = np.cos(np.arange(s.Count) * 0.7) * (1.0 + np.arange(s.Count) % 5)
     ref = oracle.cg_parallel(s, world, max_iteration=s.Count)
@@ -340,10 +340,10 @@ def test_raw_pointer_writes_invalidate(oracle, mode):
     h.close()
 
 
-def test_environment_selects_per_nonzero_codes(monkeypatch):
+def test_environment_selects_per_nonzero_codes(mgcg_env):
     """MGCG_COMPRESSION=2 means mode 2 (per-nonzero codes), as the setter does -- not 'anything non-zero is mode 1'."""
     L = _lib.lib()
-    monkeypatch.setenv("MGCG_COMPRESSION", "2")
+    mgcg_env.setenv("MGCG_COMPRESSION", "2")
     s = problems.poisson(12, 10, 8)
     h = Handles()
     A = DeviceCsr(s)

@@ -145,7 +145,7 @@ def test_config3_mgcg_at_full_size():
     mg.Dispose()
 
 
-def test_config4_rank_slabs_at_full_size(monkeypatch):
+def test_config4_rank_slabs_at_full_size(mgcg_env):
     """BASELINE config 4's per-rank problem at true size on ONE GPU: 512 x 512 z-slabs of 32 planes, three loopback ranks
     (the middle one has a halo plane on BOTH sides, as six of the eight ranks of the 8-GPU run have), 3-level V(1,1) MGCG.
     Properties (no oracle can run 25 M rows in seconds): the partitioned solve takes exactly as many iterations as the
@@ -173,8 +173,8 @@ def test_config4_rank_slabs_at_full_size(monkeypatch):
     mg.Dispose()
     assert res1 < tol and 20 < it1 < 400
 
-    monkeypatch.setenv("MGCG_VIRTUAL_DEVICES", str(world))
-    monkeypatch.setenv("MGCG_OVERLAP", "2")
+    mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    mgcg_env.setenv("MGCG_OVERLAP", "2")
 
     def make_rank(rank, comm):
         cg = ConjugateGradientMgRankGpu(N, 7, 0, 1000, tol, dims, rank=rank, world=world, comm=comm, device=rank, levels=3, rule=_lib.RULE_CSHARP)

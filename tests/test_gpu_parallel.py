@@ -169,16 +169,16 @@ def _run_ranks_in_threads(world, make_rank):
 
 @pytest.mark.parametrize("overlap", ["0", "2", None])
 @pytest.mark.parametrize("world,which", [(2, "banded"), (4, "banded"), (3, "poisson"), (2, "poisson32"), (2, "unstructured")])
-def test_native_multirank_loop_over_loopback(oracle, monkeypatch, world, which, overlap):
+def test_native_multirank_loop_over_loopback(oracle, mgcg_env, world, which, overlap):
     """SolveParallel with N > 1: partition, halo plan + exchange, all-reduced dot products and the per-chunk stop
     decision, against the multi-device oracle (ConjugateGradientParallelGpu.cs:424-565 restated).
     overlap: MGCG_OVERLAP -- "0" halo then SpMV on one stream, "2" interior rows multiplied while the halo travels on the
     communicator's stream whenever a slice has interior rows, None the library's own choice (on for poisson32)."""
-    monkeypatch.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
     if overlap is None:
-        monkeypatch.delenv("MGCG_OVERLAP", raising=False)
+        mgcg_env.delenv("MGCG_OVERLAP", raising=False)
     else:
-        monkeypatch.setenv("MGCG_OVERLAP", overlap)
+        mgcg_env.setenv("MGCG_OVERLAP", overlap)
     if which == "banded":
         s = problems.mgcg_main(2403, 160)
     elif which == "poisson":
@@ -226,14 +226,14 @@ def test_native_multirank_loop_over_loopback(oracle, monkeypatch, world, which, 
 
 @pytest.mark.parametrize("world,dims,levels,interpolation", [(2, (8, 8, 16), 3, 0), (4, (16, 8, 16), 2, 0), (2, (12, 12, 8), 3, 0),
                                                             (2, (8, 8, 16), 3, 1), (4, (16, 8, 16), 2, 1), (3, (8, 4, 24), 3, 1)])
-def test_distributed_multigrid_over_loopback(oracle, monkeypatch, world, dims, levels, interpolation):
+def test_distributed_multigrid_over_loopback(oracle, mgcg_env, world, dims, levels, interpolation):
     """Row-partitioned MGCG (config 4 in miniature): slab-local Galerkin set-up, per-level halo planes, V-cycle
     bit-identical to the single-domain oracle, PCG within the dot-product tolerance."""
     from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu
     from tests.gpu_util import assert_trace_close
 
-    monkeypatch.setenv("MGCG_VIRTUAL_DEVICES", str(world))
-    monkeypatch.setenv("MGCG_OVERLAP", "2")
+    mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    mgcg_env.setenv("MGCG_OVERLAP", "2")
     s = problems.poisson(*dims)
     rng = np.random.default_rng(3)
     s.b[:] = rng.standard_normal(s.Count)
@@ -268,13 +268,13 @@ def test_distributed_multigrid_over_loopback(oracle, monkeypatch, world, dims, l
 
 
 @pytest.mark.parametrize("world,mean_upper,expect_lists", [(4, 0.0, True), (5, 0.0, True), (3, 0.3, False), (2, 6.0, False)])
-def test_unstructured_halo_moves_index_lists(oracle, monkeypatch, world, mean_upper, expect_lists):
+def test_unstructured_halo_moves_index_lists(oracle, mgcg_env, world, mean_upper, expect_lists):
     """Unstructured slices (BASELINE config 5 in miniature): the reference's contiguous halo ranges [minJ, offset) and
     [offset + count, maxJ] (Mgcg.cu:83-84) come to the whole vector; the plan built from the slice's column ids moves only
     the entries that are referenced -- when that at least halves the volume (collective decision), else the ranges stay."""
     import ctypes as C
 
-    monkeypatch.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
     s = problems.random_spd(4000, mean_upper=mean_upper, seed=77)
     s.b[:] = np.cos(np.arange(s.Count) * 0.37) * (1.0 + np.arange(s.Count) % 7)
     ref = oracle.cg_parallel(s, world, max_iteration=s.Count, trace=True)

@@ -129,10 +129,10 @@ def test_repeated_solve_restarts_from_x(oracle):
 
 
 @pytest.mark.parametrize("ndev", [1, 2, 3, 4])
-def test_parallel_gpu_phases_with_virtual_devices(oracle, monkeypatch, ndev):
+def test_parallel_gpu_phases_with_virtual_devices(oracle, mgcg_env, ndev):
     """ConjugateGradientParallelGpu (Initialize / SyncP / Solve0-3 / Read) with the devices of this
     process; MGCG_VIRTUAL_DEVICES maps several device ids onto the one GPU of the test box."""
-    monkeypatch.setenv("MGCG_VIRTUAL_DEVICES", str(ndev))
+    mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(ndev))
     s = problems.mgcg_main(2002, 160)
     ref = oracle.cg_parallel(s, ndev, allowable_residual=1e-8, min_iteration=0, max_iteration=2002, trace=True)
     cg = ConjugateGradientParallelGpu(s.Count, 160, 0, 2002, 1e-8).load(s)
