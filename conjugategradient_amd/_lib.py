@@ -65,6 +65,8 @@ SIGNATURES = {
     "MgcgGetLastError": (C.c_char_p, []),
     "MgcgClearLastError": (None, []),
     "MgcgAbiVersion": (_i, []),
+    "MgcgCommInitAll": (_i, [_vp, _i]),
+    "MgcgCommTransport": (C.c_char_p, [_vp]),
     "MgcgSetTuning": (_i, [C.c_char_p, _i]),
     "MgcgGetTuning": (_i, [C.c_char_p, _pi]),
     "MgcgReloadEnvironment": (None, []),

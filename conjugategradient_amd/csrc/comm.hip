@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <condition_variable>
+#include <memory>
 
 namespace mgcg {
 
@@ -89,6 +90,8 @@ struct MgcgLoopback {
 struct MgcgComm {
     mgcg::NcclComm comm = nullptr;   // RCCL transport
     MgcgLoopback* loop = nullptr;    // loopback transport
+    std::shared_ptr<MgcgLoopback> ownedLoop;   // MgcgCommInitAll on virtual devices: the group lives as long as any of its communicators
+    int device = -1;                 // (virtual) device the communicator was made on
     int nranks = 1, rank = 0;
     hipStream_t stream = nullptr;
     double* scratch = nullptr;       // device, 8 doubles
@@ -100,6 +103,15 @@ struct MgcgComm {
 };
 
 namespace mgcg {
+
+// Several ranks -- or ONE rank with a real RCCL communicator and the force_multirank knob set (MGCG_FORCE_MULTIRANK = entries of an
+// artificial halo): the several-ranks code path (reduction launches, ncclAllReduce on the stream, fork / join, interior and boundary
+// row ranges, a self send/recv of that many entries) then runs on a one-GPU box, where its device-side cost can be timed.
+bool comm_multi(const MgcgComm* c)
+{
+    if (!c) return false;
+    return c->nranks > 1 || (c->comm != nullptr && tuning().forceMultiRank.load(std::memory_order_relaxed) > 0);
+}
 
 bool comm_allreduce_sum(MgcgComm* c, double* devPtr, int count, hipStream_t s)
 {
@@ -146,13 +158,19 @@ struct HaloPlan {
     int* sendIdx = nullptr; int* recvIdx = nullptr;
     double* sendBuf = nullptr; double* recvBuf = nullptr;
     long long sendTotal = 0, recvTotal = 0, contiguousRecv = 0;
+    // force_multirank on a one-rank communicator: selfCount entries of p travel rank 0 -> rank 0 into selfBuf (results are not used)
+    long long selfBegin = 0, selfCount = 0;
+    double* selfBuf = nullptr;
 };
 
-__global__ __launch_bounds__(kBlock) void halo_mark_kernel(const int* __restrict__ columnIndeces, long long nnz, long long ownBegin, long long ownEnd, unsigned char* __restrict__ flags)
+// flags has `count` bytes followed by one aligned int: set when a column id lies outside [0, count) (nothing is written for it)
+__global__ __launch_bounds__(kBlock) void halo_mark_kernel(const int* __restrict__ columnIndeces, long long nnz, long long ownBegin, long long ownEnd, long long count,
+                                                           unsigned char* __restrict__ flags, int* __restrict__ outOfRange)
 {
     const long long stride = (long long)gridDim.x * kBlock;
     for (long long k = (long long)blockIdx.x * kBlock + threadIdx.x; k < nnz; k += stride) {
         const int col = columnIndeces[k];
+        if ((unsigned long long)(long long)col >= (unsigned long long)count) { *outOfRange = 1; continue; }
         if (col < ownBegin || col >= ownEnd) flags[col] = 1;       // (benign race: every writer stores the same byte)
     }
 }
@@ -225,6 +243,13 @@ HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long 
                            const int* columnIndeces, long long nnz)
 {
     HaloPlan* h = new HaloPlan();
+    if (c && c->nranks == 1 && comm_multi(c) && countLocal > 0) {
+        long long w = tuning().forceMultiRank.load(std::memory_order_relaxed);
+        if (w > countLocal) w = countLocal;
+        h->selfBegin = offset; h->selfCount = w;
+        if (!MGCG_HIP(hipMalloc((void**)&h->selfBuf, sizeof(double) * (size_t)w))) { delete h; return nullptr; }
+        return h;
+    }
     if (!c || c->nranks == 1) return h;
     const int n = c->nranks;
     h->nranks = n;
@@ -284,18 +309,28 @@ HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long 
 }
 
 // Replace the contiguous ranges by index lists if (collectively) that at least halves the entries moved.
+// Every rank walks through the same sequence of collectives whatever happens locally: a local failure is carried in `ok`, folded into
+// the all-reduce that takes the decision (and into a second one behind the device allocations), and all ranks leave together --
+// a rank that returned early would leave its peers blocked inside the next exchange.
 static bool halo_plan_index(MgcgComm* c, HaloPlan* h, const std::vector<long long>& all, long long count, long long offset, long long countLocal,
                             const int* columnIndeces, long long nnz)
 {
     const int n = c->nranks;
-    // 1. which columns outside my rows does my slice reference?
+    bool ok = true;
+    // 1. which columns outside my rows does my slice reference?  (a column id outside [0, count) is an error, not a write)
     std::vector<unsigned char> flags((size_t)count, 0);
-    unsigned char* dFlags = nullptr;
-    bool ok = MGCG_HIP(hipMalloc((void**)&dFlags, (size_t)count)) && MGCG_HIP(hipMemsetAsync(dFlags, 0, (size_t)count, c->stream));
-    if (ok && nnz > 0) hipLaunchKernelGGL(halo_mark_kernel, dim3(halo_grid(nnz)), dim3(kBlock), 0, c->stream, columnIndeces, nnz, offset, offset + countLocal, dFlags);
-    ok = ok && MGCG_HIP(hipMemcpyAsync(flags.data(), dFlags, (size_t)count, hipMemcpyDeviceToHost, c->stream)) && MGCG_HIP(hipStreamSynchronize(c->stream));
-    if (dFlags) (void)hipFree(dFlags);
-    if (!ok) return false;
+    {
+        const size_t flagAt = ((size_t)count + 7) & ~(size_t)7;
+        unsigned char* dFlags = nullptr;
+        int bad = 0;
+        ok = MGCG_HIP(hipMalloc((void**)&dFlags, flagAt + 8)) && MGCG_HIP(hipMemsetAsync(dFlags, 0, flagAt + 8, c->stream));
+        if (ok && nnz > 0) hipLaunchKernelGGL(halo_mark_kernel, dim3(halo_grid(nnz)), dim3(kBlock), 0, c->stream, columnIndeces, nnz, offset, offset + countLocal, count, dFlags, (int*)(dFlags + flagAt));
+        ok = ok && MGCG_HIP(hipMemcpyAsync(flags.data(), dFlags, (size_t)count, hipMemcpyDeviceToHost, c->stream)) &&
+             MGCG_HIP(hipMemcpyAsync(&bad, dFlags + flagAt, sizeof(int), hipMemcpyDeviceToHost, c->stream)) && MGCG_HIP(hipStreamSynchronize(c->stream));
+        if (dFlags) (void)hipFree(dFlags);
+        if (ok && bad) { set_error("indexed halo: a column index of the slice lies outside [0, %lld)", count); ok = false; }
+        if (!ok) flags.assign((size_t)count, 0);                  // take part in the exchanges below with empty lists
+    }
     // 2. per owner, the sorted list of what I need
     std::vector<std::vector<double>> need((size_t)n), give((size_t)n), cnt((size_t)n, std::vector<double>(1, 0.0)), cntIn((size_t)n, std::vector<double>(1, 0.0));
     for (int q = 0; q < n; ++q) {
@@ -306,29 +341,32 @@ static bool halo_plan_index(MgcgComm* c, HaloPlan* h, const std::vector<long lon
     }
     cnt[(size_t)c->rank].clear(); cntIn[(size_t)c->rank].clear();
     // 3. tell every owner how many and which (two rounds over the transport)
-    if (!exchange_host(c, cnt, cntIn)) return false;
-    for (int q = 0; q < n; ++q) if (q != c->rank) give[(size_t)q].resize((size_t)cntIn[(size_t)q][0]);
-    if (!exchange_host(c, need, give)) return false;
-    // 4. collective decision: total entries moved with lists vs with ranges
-    double mine[2] = { 0.0, (double)h->contiguousRecv };
+    ok = exchange_host(c, cnt, cntIn) && ok;
+    for (int q = 0; q < n; ++q) if (q != c->rank) give[(size_t)q].resize((size_t)(cntIn[(size_t)q][0] > 0 ? cntIn[(size_t)q][0] : 0));
+    ok = exchange_host(c, need, give) && ok;
+    for (int q = 0; q < n && ok; ++q)
+        for (double v : give[(size_t)q]) {
+            const long long j = (long long)v;
+            if (j < offset || j >= offset + countLocal) { set_error("indexed halo: rank %d asked rank %d for entry %lld it does not own", q, c->rank, j); ok = false; break; }
+        }
+    // 4. collective decision: total entries moved with lists vs with ranges -- and whether any rank failed so far
+    double mine[3] = { 0.0, (double)h->contiguousRecv, ok ? 0.0 : 1.0 };
     for (int q = 0; q < n; ++q) mine[0] += (double)need[(size_t)q].size();
-    double* dTot = nullptr;
-    ok = MGCG_HIP(hipMalloc((void**)&dTot, 2 * sizeof(double))) && MGCG_HIP(hipMemcpyAsync(dTot, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
-    ok = ok && comm_allreduce_sum(c, dTot, 2, c->stream);
-    ok = ok && MGCG_HIP(hipMemcpyAsync(mine, dTot, sizeof(mine), hipMemcpyDeviceToHost, c->stream)) && MGCG_HIP(hipStreamSynchronize(c->stream));
-    if (dTot) (void)hipFree(dTot);
-    if (!ok) return false;
+    auto agree = [&](double* v, int k) {                         // sum over ranks through the communicator's own scratch (allocated with it)
+        bool g = MGCG_HIP(hipMemcpyAsync(c->scratch, v, sizeof(double) * (size_t)k, hipMemcpyHostToDevice, c->stream)) && MGCG_HIP(hipStreamSynchronize(c->stream));
+        g = comm_allreduce_sum(c, c->scratch, k, c->stream) && g;
+        g = g && MGCG_HIP(hipMemcpyAsync(v, c->scratch, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost, c->stream)) && MGCG_HIP(hipStreamSynchronize(c->stream));
+        return g;
+    };
+    if (!agree(mine, 3)) return false;
+    if (!(mine[2] == 0.0)) { if (ok) set_error("indexed halo: another rank failed to build its lists"); return false; }
     if (!(mine[0] * 2.0 <= mine[1])) return true;                 // lists do not halve the volume: keep the ranges
     // 5. device lists and staging buffers
     h->sendAt.assign((size_t)n + 1, 0); h->recvAt.assign((size_t)n + 1, 0);
     std::vector<int> sIdx, rIdx;
     for (int q = 0; q < n; ++q) {
         h->sendAt[(size_t)q] = (long long)sIdx.size(); h->recvAt[(size_t)q] = (long long)rIdx.size();
-        for (double v : give[(size_t)q]) {
-            const long long j = (long long)v;
-            if (j < offset || j >= offset + countLocal) { set_error("indexed halo: rank %d asked rank %d for entry %lld it does not own", q, c->rank, j); return false; }
-            sIdx.push_back((int)j);
-        }
+        for (double v : give[(size_t)q]) sIdx.push_back((int)(long long)v);
         for (double v : need[(size_t)q]) rIdx.push_back((int)(long long)v);
     }
     h->sendAt[(size_t)n] = (long long)sIdx.size(); h->recvAt[(size_t)n] = (long long)rIdx.size();
@@ -337,8 +375,10 @@ static bool halo_plan_index(MgcgComm* c, HaloPlan* h, const std::vector<long lon
          MGCG_HIP(hipMalloc((void**)&h->sendBuf, sizeof(double) * (sIdx.size() + 1))) && MGCG_HIP(hipMalloc((void**)&h->recvBuf, sizeof(double) * (rIdx.size() + 1)));
     if (ok && !sIdx.empty()) ok = MGCG_HIP(hipMemcpyAsync(h->sendIdx, sIdx.data(), sizeof(int) * sIdx.size(), hipMemcpyHostToDevice, c->stream));
     if (ok && !rIdx.empty()) ok = MGCG_HIP(hipMemcpyAsync(h->recvIdx, rIdx.data(), sizeof(int) * rIdx.size(), hipMemcpyHostToDevice, c->stream));
-    ok = ok && MGCG_HIP(hipStreamSynchronize(c->stream));
-    if (!ok) return false;
+    ok = MGCG_HIP(hipStreamSynchronize(c->stream)) && ok;
+    double failed[1] = { ok ? 0.0 : 1.0 };
+    if (!agree(failed, 1)) return false;
+    if (!(failed[0] == 0.0)) { if (ok) set_error("indexed halo: another rank could not allocate its lists"); return false; }
     for (int q = 0; q < n; ++q) { h->sendBegin[q] = h->sendAt[(size_t)q]; h->sendCount[q] = h->sendAt[(size_t)q + 1] - h->sendAt[(size_t)q]; h->recvBegin[q] = h->recvAt[(size_t)q]; h->recvCount[q] = h->recvAt[(size_t)q + 1] - h->recvAt[(size_t)q]; }
     h->indexed = true;                                            // from here on send/recv Begin/Count address sendBuf / recvBuf
     return true;
@@ -351,6 +391,7 @@ void halo_plan_destroy(HaloPlan* h)
     if (h->recvIdx) (void)hipFree(h->recvIdx);
     if (h->sendBuf) (void)hipFree(h->sendBuf);
     if (h->recvBuf) (void)hipFree(h->recvBuf);
+    if (h->selfBuf) (void)hipFree(h->selfBuf);
     delete h;
 }
 void halo_last(long long out[3]) { out[0] = t_lastHalo[0]; out[1] = t_lastHalo[1]; out[2] = t_lastHalo[2]; }
@@ -359,6 +400,14 @@ static bool halo_exchange_ranges(MgcgComm* c, HaloPlan* h, const double* src, do
 
 bool halo_exchange(MgcgComm* c, HaloPlan* h, double* p, hipStream_t s)
 {
+    if (c && h && h->selfCount > 0 && c->comm != nullptr) {      // one rank made to take the several-ranks path: a grouped send/recv to itself
+        Rccl* r = rccl();
+        if (!r) return false;
+        bool ok = nccl_ok(r->GroupStart(), "ncclGroupStart");
+        ok = ok && nccl_ok(r->Send(p + h->selfBegin, (size_t)h->selfCount, NCCL_DOUBLE, 0, c->comm, s), "ncclSend");
+        ok = ok && nccl_ok(r->Recv(h->selfBuf, (size_t)h->selfCount, NCCL_DOUBLE, 0, c->comm, s), "ncclRecv");
+        return nccl_ok(r->GroupEnd(), "ncclGroupEnd") && ok;
+    }
     if (!c || c->nranks == 1 || !h) return true;
     t_lastHalo[0] = h->indexed ? 1 : 0; t_lastHalo[1] = h->indexed ? h->recvTotal : h->contiguousRecv; t_lastHalo[2] = h->contiguousRecv;
     if (!h->indexed) return halo_exchange_ranges(c, h, p, p, s);
@@ -427,7 +476,7 @@ static bool halo_exchange_ranges(MgcgComm* c, HaloPlan* h, const double* src, do
 // rows on the main stream, and join() makes the main stream wait for the side stream.
 bool halo_overlap_available(MgcgComm* c)
 {
-    if (!c || c->nranks == 1) return false;
+    if (!comm_multi(c)) return false;
     if (c->haloStream) return true;
     if (!MGCG_HIP(hipStreamCreateWithFlags(&c->haloStream, hipStreamNonBlocking))) { c->haloStream = nullptr; return false; }
     if (!MGCG_HIP(hipEventCreateWithFlags(&c->evReady, hipEventDisableTiming)) || !MGCG_HIP(hipEventCreateWithFlags(&c->evHalo, hipEventDisableTiming))) {
@@ -487,6 +536,61 @@ MgcgComm* MgcgCommInitRank(const void* id128, int nranks, int rank)
     }
     c->stream = d->stream;
     return c;
+}
+
+int MgcgCommInitAll(MgcgComm* comms[], int ndev)
+{
+    if (!comms || ndev < 1 || ndev > kMaxDevices) { set_error("MgcgCommInitAll: bad argument"); return -1; }
+    for (int d = 0; d < ndev; ++d) comms[d] = nullptr;            // (the caller's array has ndev entries: that is the contract)
+    int phys = 0;
+    if (hipGetDeviceCount(&phys) != hipSuccess || phys <= 0) { set_error("no HIP device available (hipGetDeviceCount = %d): the HIP path cannot run", phys); return -1; }
+    if (ndev > GetDeviceCount()) { set_error("MgcgCommInitAll: %d communicators asked for, %d device(s)", ndev, GetDeviceCount()); return -1; }
+    const int saved = current_device();
+    bool ok = true;
+    std::shared_ptr<MgcgLoopback> group;
+    if (ndev > 1 && ndev <= phys) {
+        // one physical device per rank: RCCL.  All ncclCommInitRank calls of the process are made by this thread inside one group,
+        // before any of the ranks creates its stream or allocates (as MgcgCommInitRank does for one rank per process).
+        Rccl* r = rccl();
+        if (!r) return -1;
+        NcclUniqueId id;
+        ok = nccl_ok(r->GetUniqueId(&id), "ncclGetUniqueId") && nccl_ok(r->GroupStart(), "ncclGroupStart");
+        if (!ok) return -1;
+        for (int d = 0; d < ndev && ok; ++d) {
+            SetDevice(d);
+            ok = select_device_only();
+            if (!ok) break;
+            comms[d] = new MgcgComm();
+            comms[d]->nranks = ndev; comms[d]->rank = d; comms[d]->device = d;
+            ok = nccl_ok(r->CommInitRank(&comms[d]->comm, ndev, id, d), "ncclCommInitRank");
+        }
+        ok = nccl_ok(r->GroupEnd(), "ncclGroupEnd") && ok;
+    } else if (ndev > 1) {
+        // fewer physical devices than ranks (MGCG_VIRTUAL_DEVICES, tests): the in-process loopback group, owned by its communicators
+        group.reset(MgcgLoopbackCreate(ndev), [](MgcgLoopback* g) { MgcgLoopbackDestroy(g); });
+        ok = group != nullptr;
+        for (int d = 0; d < ndev && ok; ++d) { comms[d] = new MgcgComm(); comms[d]->nranks = ndev; comms[d]->rank = d; comms[d]->device = d; comms[d]->loop = group.get(); comms[d]->ownedLoop = group; }
+    } else {
+        comms[0] = new MgcgComm(); comms[0]->device = saved;
+    }
+    for (int d = 0; d < ndev && ok; ++d) {
+        if (ndev > 1) SetDevice(d);
+        DeviceState* st = device_state();
+        ok = st != nullptr && MGCG_HIP(hipMalloc((void**)&comms[d]->scratch, 8 * sizeof(double)));
+        if (ok) comms[d]->stream = st->stream;
+    }
+    if (ndev > 1) SetDevice(saved);
+    if (!ok) { for (int d = 0; d < ndev; ++d) { if (comms[d]) { if (ndev > 1) SetDevice(d); MgcgCommDestroy(comms[d]); comms[d] = nullptr; } } if (ndev > 1) SetDevice(saved); return -1; }
+    return 0;
+}
+
+const char* MgcgCommTransport(const MgcgComm* c)
+{
+    if (!c) return "none";
+    if (c->loop) return "loopback";
+    if (c->cbAllReduce) return "callbacks";
+    if (c->comm) return "rccl";
+    return "single";
 }
 
 MgcgLoopback* MgcgLoopbackCreate(int nranks)

@@ -263,7 +263,10 @@ inline int spmv_auto_kernel(double avgRow)
 }
 
 // Order in which a lane = row kernel walks its tiles of `tileRows` rows (kernels_rowtile.hip explains the modes).
-struct TileMap { int mode; int tilesPerPlane; int nPlanes; int per; };
+// gapAt / gapSkip: tiles [gapAt, gapAt + gapSkip) are left out (the enumeration runs over the remaining tiles): the two boundary row
+// ranges of a rank's slice in ONE launch while the interior rows between them are multiplied on another stream.
+struct TileMap { int mode; int tilesPerPlane; int nPlanes; int per; int gapAt; int gapSkip; };
+constexpr int kRowTileRows = 256;    // rows per tile of the row-tile SpMV kernel (kernels_rowtile.hip)
 TileMap make_tile_map(long long rows, int periodRows, int nWG, int tileRows);
 
 struct SpmvConfig { int kernel = 0; int rowsPerBlock = 64; int flags = 0; int gridBlocks = 0; int periodRows = 0; int tileRows = 0; int tilePlanes = 0;
@@ -273,7 +276,8 @@ struct SpmvConfig { int kernel = 0; int rowsPerBlock = 64; int flags = 0; int gr
 int launch_spmv(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg);
 // Row-tile kernel for short rows on plain CSR (kernels_rowtile.hip); periodRows = distance of the far band in rows (0: unknown),
 // gridReq = wavefronts (0: 8 per CU).  Needs 16-byte aligned elements / columnIndeces and elementsCount >= 8.
-int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int periodRows, int gridReq, int maxRow = 0, bool ntWindow = false);
+int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int periodRows, int gridReq, int maxRow = 0, bool ntWindow = false,
+                        int gapAtTile = 0, int gapSkipTiles = 0);
 // Distance (in rows) of the farthest band of the matrix, read off one row in the middle of the slice, and the longest row (one pass
 // over the row offsets; both remembered per handle -- stale values can only cost speed: any period gives the same results, and rows
 // longer than the remembered maximum take the kernel's slow path); the caller's hint (MgcgSetSpmvPeriod) wins for the period.
@@ -304,6 +308,11 @@ int launch_spmv_auto(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvC
 // dot epilogues go to `partials`, at most maxGrid of them.
 int launch_spmv_range(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg, const DcsrMatrix* dc,
                       long long r0, long long r1, double* partials, int maxGrid);
+
+// Rows [0, i0) and [i1, rowCount) -- the boundary rows either side of an interior range -- in ONE launch when the row-tile kernel serves
+// the matrix and both cuts fall on its tile boundaries, else in two; partials as launch_spmv_range.
+int launch_spmv_two_ranges(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg, const DcsrMatrix* dc,
+                           long long i0, long long i1, double* partials, int maxGrid);
 
 // ---------------------------------------------------------------- BLAS-1 and fused CG updates
 void launch_axpy(hipStream_t s, double* y, const double* x, long long n, double alpha);
@@ -374,6 +383,7 @@ void launch_halo_rows(hipStream_t s, const int* rowOffsets, const int* columnInd
 // ---------------------------------------------------------------- RCCL (dlopen'ed)
 struct CommImpl;
 bool comm_allreduce_sum(MgcgComm* c, double* devPtr, int count, hipStream_t s);
+bool comm_multi(const MgcgComm* c);   // several ranks, or one rank forced onto the several-ranks path (force_multirank knob)
 struct HaloPlan;  // per-peer contiguous send/recv ranges of p
 // columnIndeces / nnz (device; may be null): when the slice is unstructured (the contiguous ranges come to a quarter of the vector or
 // more) the plan is rebuilt from the column ids actually referenced -- per-peer index lists, packed and unpacked around the exchange.

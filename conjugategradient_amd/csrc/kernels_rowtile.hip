@@ -33,6 +33,7 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTW = 4;              // wavefronts per workgroup
 constexpr int kTRows = 64 * kTW;    // rows per tile
+static_assert(kTRows == kRowTileRows, "common.hpp names the tile height for the callers that cut row ranges");
 constexpr int kTCap = 512;          // nonzeros a wavefront stages per trip
 
 // Order in which the tiles are walked ("z sweep" when the plane stride of a stencil matrix is known).
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, Tile
     double dot = 0.0;
     auto finish = [&]() {
         // rows behind the last full tile: workgroup 0, one row per thread, straight from global memory
-        const int tailRow = nTiles * kTRows + (int)threadIdx.x;
+        const int tailRow = (nTiles + tm.gapSkip) * kTRows + (int)threadIdx.x;
         if (wg == 0 && tailRow <= lastRow) {
             double acc = 0.0;
             for (int k = a.rowOffsets[tailRow]; k < a.rowOffsets[tailRow + 1]; ++k) { const double p = a.elements[k] * a.x[a.columnIndeces[k]]; acc += p; }
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, Tile
     if (nTrips <= 0) { finish(); return; }                         // (workgroup-uniform)
     auto tile_of = [&](int t) -> int {
         t = t < nTrips ? t : nTrips - 1;                           // past the end: the last tile again (loads only, results unused)
-        return tile_map_tile(tm, t, wg, nWG);
+        const int tile = tile_map_tile(tm, t, wg, nWG);
+        return tile >= tm.gapAt ? tile + tm.gapSkip : tile;        // (gapSkip = 0 unless two row ranges share the launch)
     };
 
     // ---- per-trip pieces
@@ -237,9 +239,9 @@ TileMap make_tile_map(long long rows, int periodRows, int nWG, int tileRows)
 }
 
 template <int EPI>
-static int launch_rowtile_epi(hipStream_t s, const SpmvArgs& a, int periodRows, int gridReq, int maxRow, bool ntWindow)
+static int launch_rowtile_epi(hipStream_t s, const SpmvArgs& a, int periodRows, int gridReq, int maxRow, bool ntWindow, int gapAt, int gapSkip)
 {
-    const int nTiles = a.rowCount / kTRows;                       // full tiles; the kernel's workgroup 0 takes the rows behind them
+    const int nTiles = a.rowCount / kTRows - gapSkip;             // full tiles to do; the kernel's workgroup 0 takes the rows behind the last one
     DeviceState* d = device_state();
     const int numCu = d ? d->numCu : kNumCu;
     int nWG = gridReq > 0 ? gridReq / kTW : 2 * numCu;            // 8 wavefronts per CU
@@ -247,7 +249,8 @@ static int launch_rowtile_epi(hipStream_t s, const SpmvArgs& a, int periodRows, 
     if (nWG > nTiles) nWG = nTiles;
     if (nWG < 1) nWG = 1;
     const bool noSweep = tuning().noZsweep.load(std::memory_order_relaxed) != 0;
-    const TileMap tm = make_tile_map(a.rowCount, noSweep ? 0 : periodRows, nWG, kTRows);
+    TileMap tm = make_tile_map(a.rowCount, (noSweep || gapSkip > 0) ? 0 : periodRows, nWG, kTRows);
+    tm.gapAt = gapAt; tm.gapSkip = gapSkip;
     // Matrix streams with the non-temporal hint when the vectors of the system are small enough to live in the 256 MB Infinity Cache
     // between the kernels of an iteration (the slab of one rank of an 8-GPU run, the coarse levels of a hierarchy): the matrix, read once
     // per product, then does not push them out.  CG iteration, alternating inside one process (tools/nt_ab.py): -1 % at 8.4 M rows, -3.5 % at 16.8 M,
@@ -266,16 +269,17 @@ static int launch_rowtile_epi(hipStream_t s, const SpmvArgs& a, int periodRows, 
 }
 
 // Requires 16-byte aligned elements and columnIndeces and elementsCount >= 8 (checked by the caller).
-int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int periodRows, int gridReq, int maxRow, bool ntWindow)
+int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int periodRows, int gridReq, int maxRow, bool ntWindow, int gapAt, int gapSkip)
 {
     if (a.rowCount <= 0) return 0;
+    if (gapSkip <= 0) { gapAt = 0; gapSkip = 0; }
     switch (epilogue) {
-    case EPI_AXPBY:        return a.beta != 0.0 ? launch_rowtile_epi<EPI_AXPBY_BETA>(s, a, periodRows, gridReq, maxRow, ntWindow) : launch_rowtile_epi<EPI_AXPBY>(s, a, periodRows, gridReq, maxRow, ntWindow);
-    case EPI_DOT:          return launch_rowtile_epi<EPI_DOT>(s, a, periodRows, gridReq, maxRow, ntWindow);
-    case EPI_RESIDUAL:     return launch_rowtile_epi<EPI_RESIDUAL>(s, a, periodRows, gridReq, maxRow, ntWindow);
-    case EPI_RESIDUAL_DOT: return launch_rowtile_epi<EPI_RESIDUAL_DOT>(s, a, periodRows, gridReq, maxRow, ntWindow);
-    case EPI_JACOBI:       return launch_rowtile_epi<EPI_JACOBI>(s, a, periodRows, gridReq, maxRow, ntWindow);
-    case EPI_JACOBI_DOT:   return launch_rowtile_epi<EPI_JACOBI_DOT>(s, a, periodRows, gridReq, maxRow, ntWindow);
+    case EPI_AXPBY:        return a.beta != 0.0 ? launch_rowtile_epi<EPI_AXPBY_BETA>(s, a, periodRows, gridReq, maxRow, ntWindow, gapAt, gapSkip) : launch_rowtile_epi<EPI_AXPBY>(s, a, periodRows, gridReq, maxRow, ntWindow, gapAt, gapSkip);
+    case EPI_DOT:          return launch_rowtile_epi<EPI_DOT>(s, a, periodRows, gridReq, maxRow, ntWindow, gapAt, gapSkip);
+    case EPI_RESIDUAL:     return launch_rowtile_epi<EPI_RESIDUAL>(s, a, periodRows, gridReq, maxRow, ntWindow, gapAt, gapSkip);
+    case EPI_RESIDUAL_DOT: return launch_rowtile_epi<EPI_RESIDUAL_DOT>(s, a, periodRows, gridReq, maxRow, ntWindow, gapAt, gapSkip);
+    case EPI_JACOBI:       return launch_rowtile_epi<EPI_JACOBI>(s, a, periodRows, gridReq, maxRow, ntWindow, gapAt, gapSkip);
+    case EPI_JACOBI_DOT:   return launch_rowtile_epi<EPI_JACOBI_DOT>(s, a, periodRows, gridReq, maxRow, ntWindow, gapAt, gapSkip);
     }
     return 0;
 }

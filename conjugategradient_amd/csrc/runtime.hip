@@ -289,6 +289,33 @@ int launch_spmv_range(hipStream_t s, int epilogue, const SpmvArgs& whole, const 
     return launch_spmv(s, epilogue, a, c);
 }
 
+int launch_spmv_two_ranges(hipStream_t s, int epilogue, const SpmvArgs& whole, const SpmvConfig& cfg, const DcsrMatrix* dc,
+                           long long i0, long long i1, double* partials, int maxGrid)
+{
+    const long long n = whole.rowCount;
+    if (i0 < 0) i0 = 0;
+    if (i1 > n) i1 = n;
+    if (i0 >= i1) return launch_spmv_range(s, epilogue, whole, cfg, dc, 0, n, partials, maxGrid);
+    const bool compressed = dc != nullptr && dc->usable && whole.elementsCount >= 8;
+    int kernel = cfg.kernel;
+    if (kernel == 0) kernel = spmv_auto_kernel(n > 0 ? (double)whole.elementsCount / (double)n : 0.0);
+    const bool aligned = (((uintptr_t)whole.elements & 15) == 0) && (((uintptr_t)whole.columnIndeces & 15) == 0) && whole.elementsCount >= 8;
+    if (!compressed && kernel == 10 && aligned && i0 % kRowTileRows == 0 && i1 % kRowTileRows == 0 && (i0 > 0 || i1 < n)) {
+        SpmvArgs a = whole;
+        a.partials = partials;
+        int grid = cfg.gridBlocks;
+        if (maxGrid > 0) {
+            const int numCu = device_state() ? device_state()->numCu : kNumCu;
+            const int g = cfg.gridBlocks > 0 ? cfg.gridBlocks : 8 * numCu;
+            grid = g < maxGrid ? g : maxGrid;
+        }
+        return launch_spmv_rowtile(s, epilogue, a, 0, grid, cfg.maxRow, (cfg.flags & 8) != 0, (int)(i0 / kRowTileRows), (int)((i1 - i0) / kRowTileRows));
+    }
+    int k = launch_spmv_range(s, epilogue, whole, cfg, dc, 0, i0, partials, maxGrid > 0 ? maxGrid / 2 : 0);
+    k += launch_spmv_range(s, epilogue, whole, cfg, dc, i1, n, partials ? partials + k : nullptr, maxGrid > 0 ? maxGrid / 2 : 0);
+    return k;
+}
+
 } // namespace mgcg
 
 using namespace mgcg;

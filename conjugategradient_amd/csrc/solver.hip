@@ -47,6 +47,7 @@ struct MgcgMg {
     hipStream_t stream = nullptr;
     MgcgComm* comm = nullptr;              // not owned
     int nranks = 1;
+    bool multi = false;                    // several ranks (or one rank forced onto that path, comm_multi): full-length iterates, halo exchanges, all-reduces
     // r.z of the PCG loop rides on the V-cycle's last sweep (single rank): partial sums go here, fusedDotCount of them
     double* fuseDotPartials = nullptr;
     int fusedDotCount = 0;
@@ -62,12 +63,20 @@ static SpmvConfig cfg_of(const MgcgSparse* h)
 
 // Can the halo of a row slice hide behind its interior rows?  (several ranks, most rows reference local columns only).
 // MGCG_OVERLAP: 0 off, 1 (default) when it pays, 2 whenever an interior exists (tests).
-static bool plan_overlap(hipStream_t s, MgcgComm* comm, int nranks, const int* rowOffsets, const int* columnIndeces,
+static bool plan_overlap(hipStream_t s, MgcgComm* comm, bool multi, const int* rowOffsets, const int* columnIndeces,
                          long long n, long long offset, bool* active, long long* i0, long long* i1)
 {
     *active = false; *i0 = 0; *i1 = 0;
     const int mode = tuning().overlap.load(std::memory_order_relaxed);
-    if (nranks <= 1 || mode == 0 || (mode == 1 && n < 4096)) return true;
+    if (!multi || mode == 0 || (mode == 1 && n < 4096)) return true;
+    if (MgcgCommSize(comm) == 1) {
+        // one rank forced onto the several-ranks path (measurement): an artificial split -- the first and last force_multirank rows
+        // (rounded to SpMV tiles) play the boundary
+        long long w = tuning().forceMultiRank.load(std::memory_order_relaxed);
+        w = (w + 255) & ~255LL;
+        if (n >= 4 * w && w > 0 && halo_overlap_available(comm)) { *active = true; *i0 = w; *i1 = n - w; }
+        return true;
+    }
     int* d2 = nullptr;
     if (!MGCG_HIP(hipMalloc((void**)&d2, 2 * sizeof(int)))) return false;
     int h2[2] = { 0, (int)n };
@@ -83,7 +92,7 @@ static bool plan_overlap(hipStream_t s, MgcgComm* comm, int nranks, const int* r
 
 static bool mg_halo(MgcgMg* mg, MgLevel& L, double* xfull)
 {
-    if (mg->nranks == 1) return true;
+    if (!mg->multi) return true;
     return halo_exchange(mg->comm, L.halo, xfull, mg->stream);
 }
 
@@ -100,8 +109,7 @@ static bool mg_spmv(MgcgMg* mg, MgLevel& L, int epilogue, const SpmvArgs& a, dou
     if (!side) return false;
     launch_spmv_range(side, epilogue, a, L.cfg, L.dcsr, L.interior0, L.interior1, nullptr, 0);
     if (!mg_halo(mg, L, xfull)) return false;
-    launch_spmv_range(s, epilogue, a, L.cfg, L.dcsr, 0, L.interior0, nullptr, 0);
-    launch_spmv_range(s, epilogue, a, L.cfg, L.dcsr, L.interior1, L.n, nullptr, 0);
+    launch_spmv_two_ranges(s, epilogue, a, L.cfg, L.dcsr, L.interior0, L.interior1, nullptr, 0);     // the boundary rows either side of the interior
     return halo_overlap_join(mg->comm, s);
 }
 
@@ -112,7 +120,7 @@ static bool mg_jacobi(MgcgMg* mg, MgLevel& L, const double* b, double* xin, doub
     a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = xin; a.y = xout + L.offset;
     a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal;
     a.w = xin + L.offset; a.b = b; a.dinv = L.dinv; a.dinvUniform = L.dinvUniform ? 1 : 0; a.dinvScalar = L.dinvScalar; a.omega = mg->omega; a.doneFlag = done;
-    if (withDot && mg->nranks == 1 && mg->fuseDotPartials != nullptr) {          // + partial sums of b . xout
+    if (withDot && !mg->multi && mg->fuseDotPartials != nullptr) {          // + partial sums of b . xout
         a.partials = mg->fuseDotPartials;
         mg->fusedDotCount = launch_spmv_auto(mg->stream, EPI_JACOBI_DOT, a, L.cfg, L.dcsr);
         return true;
@@ -148,7 +156,7 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
     // V(1,*) on one rank with a uniform diagonal and the row-pattern form: the first sweep x1 = omega (d0 b) is not stored;
     // the residual pass forms x1[col] per gather and the prolongation forms x1[i] again when it adds the correction
     const bool linear = mg->interp == 1;
-    const bool fold = mg->nu == 1 && mg->nranks == 1 && !linear && L.dinvUniform && L.dcsr != nullptr && L.dcsr->usable && L.dcsr->patternId != nullptr &&
+    const bool fold = mg->nu == 1 && !mg->multi && !linear && L.dinvUniform && L.dcsr != nullptr && L.dcsr->usable && L.dcsr->patternId != nullptr &&
                       tuning().noFold.load(std::memory_order_relaxed) == 0;
     if (fold) cur = x0;
     else if (!mg_smooth(mg, L, b, x0, x1, mg->nu, true, done, &cur)) return false;
@@ -156,7 +164,7 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
     SpmvArgs a{};
     // linear transfer on several ranks: the restriction reads one plane of r from each z-neighbour, so r goes to the spare
     // full-length iterate buffer (dead until the post-smoothing writes it) and that plane is exchanged
-    const bool rFullLength = linear && mg->nranks > 1;
+    const bool rFullLength = linear && mg->multi;
     a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = fold ? b : cur; a.y = rFullLength ? other + L.offset : L.r;
     a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal; a.b = b; a.doneFlag = done;
     if (fold) { a.xScaled = 1; a.xInner = L.dinvScalar; a.xOuter = mg->omega; }
@@ -170,7 +178,7 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
     double* e = nullptr;
     if (!mg_vcycle(mg, l + 1, C.b, C.xa, C.xb, done, &e)) return false;
     if (linear) {
-        if (mg->nranks > 1 && !halo_exchange(mg->comm, C.transferHalo, e, mg->stream)) return false;
+        if (mg->multi && !halo_exchange(mg->comm, C.transferHalo, e, mg->stream)) return false;
         launch_prolong_linear_add(mg->stream, L.nx, L.ny, L.nz, L.z0, L.z1, cur + L.offset, e, done);               // x += P e
     }
     else if (fold) launch_prolong_scaled(mg->stream, L.nx, L.ny, L.z1 - L.z0, cur + L.offset, b, L.dinvScalar, mg->omega, e + C.offset, done);
@@ -188,7 +196,7 @@ static bool mg_apply(MgcgMg* mg, const double* r, double* z, const int* done, do
     struct Reset { MgcgMg* m; int* n; ~Reset() { if (n) *n = m->fusedDotCount; m->fuseDotPartials = nullptr; } } reset{ mg, nDot };
     MgLevel& L0 = mg->lv[0];
     double* res = nullptr;
-    if (mg->nranks == 1) {
+    if (!mg->multi) {
         // swaps on level 0: (nu-1) pre + nu post, or (nuCoarse-1) when there is a single level
         const int swaps = (mg->levels == 1) ? (mg->nuCoarse - 1) : (2 * mg->nu - 1);
         double* start = (swaps % 2 == 0) ? z : L0.xa;
@@ -214,6 +222,7 @@ struct CgRun {
     double *x = nullptr, *b = nullptr, *Ap = nullptr, *p = nullptr, *r = nullptr, *z = nullptr;  // p is FULL length (count), the rest local
     long long count = 0, nLocal = 0, offset = 0;
     int nranks = 1;
+    bool multi = false;                    // comm_multi(comm)
     double tol = 0; int minIt = 0, maxIt = 0, rule = 0;
     bool wantInf = false;
     SpmvProfile* prof = nullptr;
@@ -230,7 +239,7 @@ static thread_local long long t_lastOverlap[3] = { 0, 0, 0 };
 static bool cg_plan_overlap(CgRun& R)
 {
     t_lastOverlap[0] = 0;
-    if (!plan_overlap(R.ws->stream, R.comm, R.nranks, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.overlap, &R.interior0, &R.interior1)) return false;
+    if (!plan_overlap(R.ws->stream, R.comm, R.multi, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.overlap, &R.interior0, &R.interior1)) return false;
     if (R.overlap) { t_lastOverlap[0] = 1; t_lastOverlap[1] = R.interior0; t_lastOverlap[2] = R.interior1; }
     return true;
 }
@@ -278,13 +287,13 @@ static bool cg_enqueue_init(CgRun& R)
     int n;
     if (R.mg) {
         int nz = 0;
-        if (!mg_apply(R.mg, R.r, R.z, nullptr, R.nranks == 1 ? R.ws->partials : nullptr, &nz)) return false;   // z = M^-1 r (+ r.z)
+        if (!mg_apply(R.mg, R.r, R.z, nullptr, !R.multi ? R.ws->partials : nullptr, &nz)) return false;   // z = M^-1 r (+ r.z)
         launch_copy(s, pLoc, R.z, R.nLocal);                                         // p = z
         n = nz > 0 ? nz : launch_dot_partials(s, R.r, R.z, R.nLocal, R.ws->partials);   // rz = r.z
     } else {
         n = launch_copy_dot(s, pLoc, R.r, R.nLocal, R.ws->partials, nullptr);        // p = r ; rr = r.r  (Mgcg.cu:227-228)
     }
-    if (R.nranks > 1) {
+    if (R.multi) {
         launch_reduce_to(s, R.ws->partials, n, &sc->rr, nullptr);
         if (!comm_allreduce_sum(R.comm, &sc->rr, 1, s)) return false;                // resultsDot.Sum()  (:463)
         launch_init_scalars(s, R.ws->partials, n, false, sc, R.ws->mirror, R.rule);
@@ -312,8 +321,7 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
         if (!side) return false;
         n = launch_spmv_range(side, EPI_DOT, a, R.cfg, R.dcsr, R.interior0, R.interior1, R.ws->partials, kMaxPartials / 2);
         if (!halo_exchange(R.comm, R.halo, R.p, s)) return false;
-        n += launch_spmv_range(s, EPI_DOT, a, R.cfg, R.dcsr, 0, R.interior0, R.ws->partials + n, kMaxPartials / 4);
-        n += launch_spmv_range(s, EPI_DOT, a, R.cfg, R.dcsr, R.interior1, R.nLocal, R.ws->partials + n, kMaxPartials / 4);
+        n += launch_spmv_two_ranges(s, EPI_DOT, a, R.cfg, R.dcsr, R.interior0, R.interior1, R.ws->partials + n, kMaxPartials / 2);   // boundary rows: one launch when the cuts fall on tiles
         if (!halo_overlap_join(R.comm, s)) return false;
         prof_mark(R, false);
     } else {
@@ -326,9 +334,9 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
     double* rrPartials = R.ws->partials;
     // one rank, no preconditioner: the x/p update finalises the iteration itself (one launch fewer; MGCG_NO_FOLDED_FINALIZE for A/B)
     const bool noFold = R.noFoldedFinalize;
-    const bool fold = R.nranks == 1 && !R.mg && R.nLocal > 0 && !noFold;
-    const bool foldRanks = R.nranks > 1 && !R.mg && R.nLocal > 0 && !noFold;         // several ranks: the same fold behind the all-reduce of r.r
-    if (R.nranks > 1) {
+    const bool fold = !R.multi && !R.mg && R.nLocal > 0 && !noFold;
+    const bool foldRanks = R.multi && !R.mg && R.nLocal > 0 && !noFold;         // several ranks: the same fold behind the all-reduce of r.r
+    if (R.multi) {
         launch_reduce_to(s, R.ws->partials, n, &sc->pAp, done);
         if (!comm_allreduce_sum(R.comm, &sc->pAp, 1, s)) return false;               // (:499)
         n = launch_update_r(s, sc, R.r, R.Ap, R.nLocal, rrPartials, pInf, nullptr, 0, foldRanks);   // r -= a Ap ; r.r  (:247-248); x += a p rides with the p update below
@@ -346,7 +354,7 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
         launch_update_xp_final(s, f, rrPartials, pInf, n, R.x, pLoc, R.r, R.nLocal);     // residual, stop test, beta (:251-266) ; x += a p (:246) ; p = r + beta p (:265)
         return MGCG_HIP(hipGetLastError());
     }
-    if (R.nranks > 1 && R.mg) {
+    if (R.multi && R.mg) {
         // Preconditioned, several ranks: r.r (stop test) and r.z (beta) travel in ONE all-reduce of two doubles behind the
         // V-cycle ("[r.z, r.r] batched"); the stop decision of an iteration is taken one V-cycle later,
         // which costs one wasted V-cycle at the very end and saves a collective per iteration.
@@ -361,7 +369,7 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
         launch_update_xp(s, sc, R.x, pLoc, R.z, R.nLocal);                           // x += a p (:246) ; p = z + beta p
         return MGCG_HIP(hipGetLastError());
     }
-    if (R.nranks > 1) {
+    if (R.multi) {
         launch_reduce_to(s, rrPartials, n, &sc->rrNew, done);
         if (!comm_allreduce_sum(R.comm, &sc->rrNew, 1, s)) return false;             // (:525)
         if (foldRanks) {
@@ -374,9 +382,9 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
     }
     if (R.mg) {
         int nz = 0;
-        if (!mg_apply(R.mg, R.r, R.z, done, R.nranks == 1 ? R.ws->partials : nullptr, &nz)) return false;   // z = M^-1 r (+ r.z on the last sweep)
+        if (!mg_apply(R.mg, R.r, R.z, done, !R.multi ? R.ws->partials : nullptr, &nz)) return false;   // z = M^-1 r (+ r.z on the last sweep)
         n = nz > 0 ? nz : launch_dot_partials(s, R.r, R.z, R.nLocal, R.ws->partials);
-        if (R.nranks > 1) {
+        if (R.multi) {
             launch_reduce_to(s, R.ws->partials, n, &sc->rzNew, done);
             if (!comm_allreduce_sum(R.comm, &sc->rzNew, 1, s)) return false;
             launch_finalize_precond(s, R.ws->partials, n, false, sc);
@@ -518,12 +526,12 @@ int SolveParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMa
                        elementsCountForDevice, countForDevice, count)) return MGCG_ERROR;
     if (offsetForDevice < 0 || (long long)offsetForDevice + countForDevice > count) { set_error("SolveParallel: bad partition"); return MGCG_ERROR; }
     CgRun R;
-    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse; R.comm = comm; R.nranks = MgcgCommSize(comm);
+    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse; R.comm = comm; R.nranks = MgcgCommSize(comm); R.multi = comm_multi(comm);
     R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCountForDevice;
     R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data;
     R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice;
     R.tol = allowableResidual; R.minIt = minIteration; R.maxIt = maxIteration; R.rule = rule;
-    if (R.nranks > 1) {
+    if (R.multi) {
         R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, R.columnIndeces, R.elementsCount);
         if (!R.halo) return MGCG_ERROR;
         if (!cg_plan_overlap(R)) { halo_plan_destroy(R.halo); return MGCG_ERROR; }
@@ -544,14 +552,14 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     if (!check_vectors("CgSteps", elementsVector, rowOffsetsVector, columnIndecesVector, xVector, bVector, ApVector, pVector, rVector,
                        elementsCountForDevice, countForDevice, count)) return NAN;
     CgRun R;
-    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse; R.comm = comm; R.nranks = MgcgCommSize(comm);
+    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse; R.comm = comm; R.nranks = MgcgCommSize(comm); R.multi = comm_multi(comm);
     R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCountForDevice;
     R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data;
     R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice; R.rule = MGCG_RULE_NATIVE;
     double* savedTrace = R.ws->trace; const int savedCap = R.ws->traceCap;
     R.ws->trace = nullptr; R.ws->traceCap = 0;
     bool ok = true;
-    if (R.nranks > 1) { R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, R.columnIndeces, R.elementsCount); ok = R.halo != nullptr && cg_plan_overlap(R); }
+    if (R.multi) { R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, R.columnIndeces, R.elementsCount); ok = R.halo != nullptr && cg_plan_overlap(R); }
     R.dcsr = dcsr_lookup(cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset, R.count);
     if (R.elementsCount >= 8) R.cfg.periodRows = spmv_period(cusparse, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.cfg.maxRow);
     R.cfg.flags |= 8;
@@ -624,7 +632,8 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     MgcgMg* mg = new MgcgMg();
     mg->omega = omega; mg->nu = nu; mg->nuCoarse = nuCoarse; mg->sigma = sigma; mg->stream = s; mg->cfg = cfg_of(cusparse);
     mg->cfg.kernel = 0;   // every level picks its kernel from its own nnz/row
-    mg->comm = comm; mg->nranks = nranks;
+    mg->comm = comm; mg->nranks = nranks; mg->multi = comm_multi(comm);
+    const bool multi = mg->multi;
     int* dErr = nullptr;
     int* dmm = nullptr;
     bool ok = MGCG_HIP(hipMalloc((void**)&dErr, sizeof(int))) && MGCG_HIP(hipMemsetAsync(dErr, 0, sizeof(int), s)) && MGCG_HIP(hipMalloc((void**)&dmm, 2 * sizeof(int)));
@@ -676,9 +685,9 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
         ok = ok && MGCG_HIP(hipMalloc((void**)&L.dinv, sizeof(double) * (size_t)L.n));
         ok = ok && MGCG_HIP(hipMalloc((void**)&L.xa, sizeof(double) * (size_t)L.nGlobal));
         ok = ok && MGCG_HIP(hipMalloc((void**)&L.r, sizeof(double) * (size_t)L.n));
-        if (l > 0 || nranks > 1) ok = ok && MGCG_HIP(hipMalloc((void**)&L.xb, sizeof(double) * (size_t)L.nGlobal));
+        if (l > 0 || multi) ok = ok && MGCG_HIP(hipMalloc((void**)&L.xb, sizeof(double) * (size_t)L.nGlobal));
         if (l > 0) ok = ok && MGCG_HIP(hipMalloc((void**)&L.b, sizeof(double) * (size_t)L.n));
-        if (ok && nranks > 1) {   // halo entries that no neighbour owns (outside the global range) are never read; the rest must start defined
+        if (ok && multi) {   // halo entries that no neighbour owns (outside the global range) are never read; the rest must start defined
             ok = ok && MGCG_HIP(hipMemsetAsync(L.xa, 0, sizeof(double) * (size_t)L.nGlobal, s)) && MGCG_HIP(hipMemsetAsync(L.xb, 0, sizeof(double) * (size_t)L.nGlobal, s));
         }
         if (ok) launch_extract_dinv(s, L.elements, L.rowOffsets, L.columnIndeces, L.n, L.offset, L.dinv);
@@ -694,7 +703,7 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
         L.cfg = mg->cfg;
         if (ok && L.nnz >= 8) (void)spmv_period(cusparse, L.rowOffsets, L.columnIndeces, L.n, L.offset, &L.cfg.maxRow);   // longest row of the level (7 on every Galerkin level of a 7-point operator)
         L.cfg.periodRows = (L.nz > 1) ? L.nx * L.ny : 0;       // far band of a 3-D stencil = one grid plane (used only if the caller switched the banded schedule on)
-        if (ok && nranks > 1) {
+        if (ok && multi) {
             int init[2] = { 0x7fffffff, (int)0x80000000 }, out[2] = { 0, -1 };
             ok = ok && MGCG_HIP(hipMemcpyAsync(dmm, init, sizeof(init), hipMemcpyHostToDevice, s));
             if (ok && L.nnz > 0) launch_minmax_int(s, L.columnIndeces, L.nnz, dmm);
@@ -702,7 +711,7 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
             ok = ok && MGCG_HIP(hipStreamSynchronize(s));
             L.minJ = out[0]; L.maxJ = out[1];
             if (ok) { L.halo = halo_plan_create(comm, L.nGlobal, L.offset, L.n, L.minJ, L.maxJ); ok = L.halo != nullptr; }
-            ok = ok && plan_overlap(s, comm, nranks, L.rowOffsets, L.columnIndeces, L.n, L.offset, &L.overlap, &L.interior0, &L.interior1);
+            ok = ok && plan_overlap(s, comm, mg->multi, L.rowOffsets, L.columnIndeces, L.n, L.offset, &L.overlap, &L.interior0, &L.interior1);
         }
         mg->lv.push_back(L);
         mg->levels = (int)mg->lv.size();
@@ -748,7 +757,7 @@ int MgSetInterpolation(MgcgMg* mg, int mode)
 {
     if (!mg || (mode != 0 && mode != 1)) { set_error("MgSetInterpolation: mode must be 0 (piecewise constant) or 1 (cell-centred linear)"); return -1; }
     if (!device_state()) return -1;
-    if (mode == 1 && mg->nranks > 1) {
+    if (mode == 1 && mg->multi) {
         // collective: every rank builds, level by level, the plan that brings one grid plane from each z-neighbour
         for (MgLevel& L : mg->lv) {
             if (L.transferHalo) continue;
@@ -807,15 +816,15 @@ int SolveMgParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, Mgcg
     if (zVector->size < countForDevice || mg->lv[0].n != countForDevice || mg->lv[0].nGlobal != count || mg->lv[0].offset != offsetForDevice) {
         set_error("SolveMg: z vector or hierarchy does not match the problem"); return MGCG_ERROR;
     }
-    if (mg->nranks != MgcgCommSize(comm)) { set_error("SolveMg: the hierarchy was built for %d rank(s)", mg->nranks); return MGCG_ERROR; }
+    if (mg->nranks != MgcgCommSize(comm) || mg->multi != comm_multi(comm)) { set_error("SolveMg: the hierarchy was built for %d rank(s)%s", mg->nranks, mg->multi ? " on the several-ranks path" : ""); return MGCG_ERROR; }
     if (rule == MGCG_RULE_HANDMADECL || rule == MGCG_RULE_VIENNACL) { set_error("SolveMg supports the 2-norm absolute rules only"); return MGCG_ERROR; }
     CgRun R;
-    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse; R.mg = mg; R.comm = comm; R.nranks = MgcgCommSize(comm);
+    R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse; R.mg = mg; R.comm = comm; R.nranks = MgcgCommSize(comm); R.multi = comm_multi(comm);
     R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCountForDevice;
     R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data; R.z = zVector->data;
     R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice;
     R.tol = allowableResidual; R.minIt = minIteration; R.maxIt = maxIteration; R.rule = rule;
-    if (R.nranks > 1) {
+    if (R.multi) {
         R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, R.columnIndeces, R.elementsCount);
         if (!R.halo) return MGCG_ERROR;
         if (!cg_plan_overlap(R)) { halo_plan_destroy(R.halo); return MGCG_ERROR; }

@@ -6,7 +6,8 @@
 //   ConjugateGradient        ConjugateGradient.cs:6-84        (IsConverged :56-79)
 //   ConjugateGradientGpu     ConjugateGradientGpu.cs:10-90
 //   ConjugateGradientSingleGpu   ConjugateGradientSingleGpu.cs:9-179
-//   ConjugateGradientParallelGpu ConjugateGradientParallelGpu.cs:11-595  (host-driven phases, host-staged halo)
+//   ConjugateGradientParallelGpu ConjugateGradientParallelGpu.cs:11-595  (Solve() = the native multi-device loop, SolveParallel over
+//                                RCCL, one host thread per device; the reference's host-driven phases stay behind UsePhases)
 //   SparseMatrix             SparseMatrix.cs:8-101
 //   VectorDouble / VectorInt VectorDouble.cs:8-113 / VectorInt.cs:8-106
 // The CPU solver of the reference (ConjugateGradientCpu.cs) is NOT here: its restatement is the test
@@ -215,10 +216,18 @@ public:
     void Read() override { vectorX.CopyTo(x.data(), Count()); }
 };
 
-// Every device of this process, one host thread per device per phase (the reference's Parallel.For),
-// host-staged halo (SyncP) and host sums of the per-device dot products in device order.
+// Every device of this process, one host thread per device (the reference's Parallel.For).  Solve() hands each device's thread
+// the WHOLE loop (SolveParallel: halo of p by grouped ncclSend/ncclRecv, the three sums of :463,499,525 by ncclAllReduce, all on
+// the device's stream -- no host round trip inside an iteration); the communicators of all devices are formed in the
+// constructor (MgcgCommInitAll).  UsePhases = true brings back the reference's own structure (:424-565): five Parallel.For
+// per iteration over Solve0..3, host-staged halo (SyncP) and host sums of the per-device dot products in device order.
 class ConjugateGradientParallelGpu : public ConjugateGradientGpu {
+public:
+    bool UsePhases = false;
+    std::string LastPath = "none";       // "native loop (SolveParallel over <transport>)" or "host-driven phases (Solve0..3)"
+private:
     int deviceCount;
+    std::vector<MgcgComm*> comms;
     std::vector<int> offsetsForDevice, minJ, maxJ;
     std::vector<MgcgBlas*> cublas; std::vector<MgcgSparse*> cusparse; std::vector<MgcgMatDescr*> matDescr;
     std::vector<VectorDouble*> vectorElements, vectorX, vectorB, vectorAp, vectorP, vectorR;
@@ -249,6 +258,8 @@ public:
     {
         if (deviceCount < 1) throw MgcgError("no GPU");
         const size_t n = (size_t)deviceCount;
+        comms.assign(n, nullptr);
+        if (MgcgCommInitAll(comms.data(), deviceCount) != 0) { Check("MgcgCommInitAll"); throw MgcgError("MgcgCommInitAll failed"); }   // before any handle or vector exists
         offsetsForDevice.assign(n + 1, 0);
         for (int i = 1; i < deviceCount; i++) offsetsForDevice[(size_t)i] = offsetsForDevice[(size_t)i - 1] + (int)std::floor((double)Count() / deviceCount);
         offsetsForDevice[n] = Count();
@@ -270,6 +281,7 @@ public:
             delete vectorElements[i]; delete vectorColumnIndeces[i]; delete vectorRowOffsets[i];
             delete vectorX[i]; delete vectorB[i]; delete vectorAp[i]; delete vectorP[i]; delete vectorR[i];
             DestroyBlas(cublas[i]); DestroySparse(cusparse[i]); DestroyMatDescr(matDescr[i]);
+            MgcgCommDestroy(comms[i]);
         }
     }
     int DeviceCount() const { return deviceCount; }
@@ -283,6 +295,26 @@ public:
         });
     }
     void Solve() override
+    {
+        if (UsePhases) { LastPath = "host-driven phases (Solve0..3)"; SolvePhases(); return; }
+        LastPath = std::string("native loop (SolveParallel over ") + MgcgCommTransport(comms[0]) + ")";
+        std::vector<int> iteration((size_t)deviceCount, 0), status((size_t)deviceCount, MGCG_ERROR);
+        std::vector<double> residual((size_t)deviceCount, 0.0);
+        ParallelFor([&](int d) { const size_t i = (size_t)d;
+            status[i] = SolveParallel(comms[i], cublas[i], cusparse[i], matDescr[i], vectorElements[i]->Ptr, vectorRowOffsets[i]->Ptr, vectorColumnIndeces[i]->Ptr,
+                                      vectorX[i]->Ptr, vectorB[i]->Ptr, vectorAp[i]->Ptr, vectorP[i]->Ptr, vectorR[i]->Ptr,
+                                      Count(), CountForDevice(d), offsetsForDevice[i], ElementCount(d), minJ[i], maxJ[i],
+                                      AllowableResidual, MinIteration, MaxIteration, MGCG_RULE_CSHARP, &iteration[i], &residual[i], nullptr, 0);
+            if (status[i] == MGCG_MAXIT_EXCEEDED) MgcgClearLastError();               // reported below as the reference does (ConjugateGradient.cs:70-74)
+        });
+        Iteration = iteration[0]; Residual = residual[0];                             // every rank holds the same all-reduced values
+        for (int d = 0; d < deviceCount; d++) {
+            if (status[(size_t)d] == MGCG_MAXIT_EXCEEDED) throw ApplicationException("the pressure equation did not converge");
+            if (status[(size_t)d] != MGCG_OK) throw MgcgError("SolveParallel failed on device " + std::to_string(d));
+        }
+    }
+    // the reference's own structure, phase by phase (:424-565)
+    void SolvePhases()
     {
         SyncP();
         ParallelFor([&](int d) { const size_t i = (size_t)d;

@@ -5,12 +5,17 @@
 // compared with each other here and tests/test_gpu_host_cpp.py compares the printed solution
 // checksum with the CPU oracle.
 //
-//   MgcgMain [COUNT] [MIN_ITERATION]        (defaults: 34567*6 and 200, the reference's constants)
+//   MgcgMain [COUNT] [MIN_ITERATION] [phases]      (defaults: 34567*6 and 200, the reference's constants)
+// The multi-device solver runs twice: on the reference's host-driven phases (Solve0..3, P2Host / P2Device) and on the native
+// loop (SolveParallel on every device's own thread, collectives on the device streams); which path produced the kept answer
+// is printed ("phases" as third argument keeps the phase structure for it).
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <string>
+#include <vector>
 
 #include "Mgcg.hpp"
 
@@ -23,6 +28,7 @@ int main(int argc, char** argv)
     const int MIN_ITERATION = argc > 2 ? atoi(argv[2]) : 200;           // :25
     const int MAX_ITERATION = COUNT;                                    // :30
     const double ALLOWABLE_RESIDUAL = 1e-8;                             // :35
+    const bool usePhasesOnly = argc > 3 && std::string(argv[3]) == "phases";   // keep the reference's phase structure for the kept answer too
     printf("N=%d\n", COUNT);
     try {
         ConjugateGradientSingleGpu cgGpuSingle(COUNT, MAX_NONZERO_COUNT, MIN_ITERATION, MAX_ITERATION, ALLOWABLE_RESIDUAL);
@@ -63,11 +69,24 @@ int main(int argc, char** argv)
         const double singleSec = std::chrono::duration<double>(clk::now() - t0).count();
         cgGpuSingle.Read();
 
+        // the reference's own phase structure first (Solve0..3 + host-staged SyncP), then -- the answer that is kept -- the native loop
+        cgGpuParallel.UsePhases = true;
+        cgGpuParallel.Initialize();
+        t0 = clk::now();
+        cgGpuParallel.Solve();
+        const double phasesSec = std::chrono::duration<double>(clk::now() - t0).count();
+        const int phasesIteration = cgGpuParallel.Iteration;
+        cgGpuParallel.Read();
+        const std::vector<double> xPhases = cgGpuParallel.x;
+        for (int i = 0; i < COUNT; i++) cgGpuParallel.x[(size_t)i] = (double)i / 100;
+        cgGpuParallel.UsePhases = usePhasesOnly;
         cgGpuParallel.Initialize();
         t0 = clk::now();
         cgGpuParallel.Solve();
         const double parallelSec = std::chrono::duration<double>(clk::now() - t0).count();
         cgGpuParallel.Read();
+        double maxRelPhases = 0;
+        for (int i = 0; i < COUNT; i++) if (std::fabs(xPhases[(size_t)i]) > 0) maxRelPhases = std::max(maxRelPhases, std::fabs(xPhases[(size_t)i] - cgGpuParallel.x[(size_t)i]) / std::fabs(xPhases[(size_t)i]));
 
         int mismatches = 0;
         double checksum = 0, maxRel = 0;
@@ -79,12 +98,17 @@ int main(int argc, char** argv)
             checksum += ref * (double)((i % 7) + 1);
         }
         printf("single GPU  : %12.6f s / %d = %12.3f us per iteration\n", singleSec, cgGpuSingle.Iteration, 1e6 * singleSec / std::max(1, cgGpuSingle.Iteration));
-        printf("parallel GPU: %12.6f s / %d = %12.3f us per iteration (%d devices)\n", parallelSec, cgGpuParallel.Iteration,
-               1e6 * parallelSec / std::max(1, cgGpuParallel.Iteration), cgGpuParallel.DeviceCount());
-        printf("{\"count\": %d, \"devices\": %d, \"iteration_single\": %d, \"iteration_parallel\": %d, \"residual_single\": %.17g, "
-               "\"residual_parallel\": %.17g, \"mismatches\": %d, \"max_rel_single_vs_parallel\": %.3e, \"checksum\": %.17g, \"x0\": %.17g, \"xlast\": %.17g}\n",
-               COUNT, cgGpuParallel.DeviceCount(), cgGpuSingle.Iteration, cgGpuParallel.Iteration, cgGpuSingle.Residual, cgGpuParallel.Residual,
-               mismatches, maxRel, checksum, cgGpuSingle.x[0], cgGpuSingle.x[(size_t)COUNT - 1]);
+        printf("parallel GPU: %12.6f s / %d = %12.3f us per iteration (%d devices) -- %s\n", parallelSec, cgGpuParallel.Iteration,
+               1e6 * parallelSec / std::max(1, cgGpuParallel.Iteration), cgGpuParallel.DeviceCount(), cgGpuParallel.LastPath.c_str());
+        printf("   (phases) : %12.6f s / %d = %12.3f us per iteration -- host-driven phases (Solve0..3), the reference's structure\n", phasesSec, phasesIteration,
+               1e6 * phasesSec / std::max(1, phasesIteration));
+        printf("{\"count\": %d, \"devices\": %d, \"iteration_single\": %d, \"iteration_parallel\": %d, \"iteration_phases\": %d, \"residual_single\": %.17g, "
+               "\"residual_parallel\": %.17g, \"mismatches\": %d, \"max_rel_single_vs_parallel\": %.3e, \"max_rel_phases_vs_parallel\": %.3e, \"checksum\": %.17g, \"x0\": %.17g, \"xlast\": %.17g, "
+               "\"parallel_path\": \"%s\", \"us_per_iteration_single\": %.3f, \"us_per_iteration_parallel\": %.3f, \"us_per_iteration_phases\": %.3f}\n",
+               COUNT, cgGpuParallel.DeviceCount(), cgGpuSingle.Iteration, cgGpuParallel.Iteration, phasesIteration, cgGpuSingle.Residual, cgGpuParallel.Residual,
+               mismatches, maxRel, maxRelPhases, checksum, cgGpuSingle.x[0], cgGpuSingle.x[(size_t)COUNT - 1],
+               cgGpuParallel.LastPath.c_str(), 1e6 * singleSec / std::max(1, cgGpuSingle.Iteration), 1e6 * parallelSec / std::max(1, cgGpuParallel.Iteration),
+               1e6 * phasesSec / std::max(1, phasesIteration));
         return mismatches == 0 ? 0 : 1;
     } catch (std::exception& e) {
         printf("!!!!%s\n", e.what());

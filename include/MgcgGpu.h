@@ -321,6 +321,17 @@ int       MgcgCommGetUniqueId(void* id128);
 int       MgcgRcclAvailable(void);
 MgcgComm* MgcgCommInitRank(const void* id128, int nranks, int rank);
 void      MgcgCommDestroy(MgcgComm* comm);
+/* ONE process driving ndev devices, one host thread per device -- the shape of the reference's ConjugateGradientParallelGpu
+ * (Mgcg/cuBlas/Mgcg/ConjugateGradientParallelGpu.cs:264-324: every device of the process; :424-565: a Parallel.For per phase).
+ * Forms the ndev communicators of devices 0 .. ndev-1 at once, from the calling thread (ncclGroupStart / ndev x
+ * ncclCommInitRank / ncclGroupEnd): comms[d] is rank d of ndev and belongs to device d.  Call it before the devices'
+ * handles and vectors are created.  Afterwards thread d calls SetDevice(d) and SolveParallel / MgSetupParallel /
+ * SolveMgParallel(comms[d], ...); all ndev calls must be in flight together (they meet in collectives).
+ * With fewer physical devices than ndev (MGCG_VIRTUAL_DEVICES, tests) the communicators share an in-process loopback group;
+ * ndev == 1 gives a single-rank communicator.  Returns 0, or -1 with MgcgGetLastError() and every comms[d] NULL. */
+int       MgcgCommInitAll(MgcgComm* comms[], int ndev);
+/* "rccl", "loopback", "callbacks", "single" (one rank, no transport) or "none" (NULL). */
+const char* MgcgCommTransport(const MgcgComm* comm);
 int       MgcgCommRank(const MgcgComm* comm);
 int       MgcgCommSize(const MgcgComm* comm);
 /* In-process loopback transport: N ranks of ONE process (host threads, e.g. MGCG_VIRTUAL_DEVICES on one GPU)

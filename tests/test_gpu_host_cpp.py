@@ -25,8 +25,10 @@ def test_mgcg_main_driver(oracle, devices):
     s = problems.mgcg_main(count, 160)
     ref = oracle.cg(s, rule=oracle.RULE_NATIVE, min_iteration=min_it, max_iteration=count, hard_cap=count + 5)
     assert rec["devices"] == devices
-    assert rec["iteration_single"] == ref["iteration"] == rec["iteration_parallel"] == min_it
-    assert rec["mismatches"] == 0 and rec["max_rel_single_vs_parallel"] < 1e-8
+    assert rec["iteration_single"] == ref["iteration"] == rec["iteration_parallel"] == rec["iteration_phases"] == min_it
+    assert rec["mismatches"] == 0 and rec["max_rel_single_vs_parallel"] < 1e-8 and rec["max_rel_phases_vs_parallel"] < 1e-8
+    # ConjugateGradientParallelGpu.Solve() took the native loop (SolveParallel per device thread), not the host-driven phases
+    assert rec["parallel_path"] == "native loop (SolveParallel over %s)" % ("single" if devices == 1 else "loopback")
     w = (np.arange(count) % 7) + 1.0
     assert abs(rec["checksum"] - float(np.dot(ref["x"], w))) <= 1e-9 * abs(rec["checksum"])
     assert abs(rec["x0"] - ref["x"][0]) <= 1e-10 * abs(ref["x"][0]) and abs(rec["xlast"] - ref["x"][-1]) <= 1e-10 * abs(ref["x"][-1])
@@ -77,5 +79,24 @@ def test_command_line_driver(oracle):
     rec = run("--n", "16", "--mgcg", "--levels", "3", "--linear-transfer", "--compression", "0")
     assert rec["iteration"] == lref["iteration"] < mref["iteration"]
     assert abs(rec["sum_x"] - lref["x"].sum()) <= 1e-9 * np.abs(lref["x"]).sum()
+    # --ranks R: R devices of ONE process, one host thread each, MgcgCommInitAll + SolveParallel / MgSetupParallel + SolveMgParallel
+    # (the single-process shape of ConjugateGradientParallelGpu.cs:264-324); same counts and sums as the single-rank runs
+    def run_ranks(r, *flags):
+        out = subprocess.run([exe, "--ranks", str(r), *flags], env=dict(os.environ, MGCG_VIRTUAL_DEVICES=str(r)), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        return json.loads(out.stdout.splitlines()[-1])
+
+    rec = run_ranks(2, "--n", "16", "--rule", "csharp", "--compression", "0")
+    assert rec["ranks"] == 2 and rec["transport"] == "loopback" and rec["iteration"] == ref["iteration"]
+    assert abs(rec["sum_x"] - ref["x"].sum()) <= 1e-9 * np.abs(ref["x"]).sum()
+    for r in (2, 4):
+        rec = run_ranks(r, "--n", "16", "--mgcg", "--levels", "3" if r == 2 else "2", "--compression", "0")
+        m = mref if r == 2 else oracle.Multigrid(s, levels=2).pcg(rule=oracle.RULE_CSHARP, max_iteration=400)
+        assert rec["ranks"] == r and rec["levels"] == (3 if r == 2 else 2) and rec["iteration"] == m["iteration"]
+        assert abs(rec["sum_x"] - m["x"].sum()) <= 1e-9 * np.abs(m["x"]).sum()
+    rec = run_ranks(2, "--n", "16", "--mgcg", "--levels", "3", "--linear-transfer", "--compression", "0")
+    assert rec["iteration"] == lref["iteration"] and abs(rec["sum_x"] - lref["x"].sum()) <= 1e-9 * np.abs(lref["x"]).sum()
+    bad = subprocess.run([exe, "--ranks", "3", "--n", "16"], env=dict(os.environ, MGCG_VIRTUAL_DEVICES="3"), capture_output=True, text=True)
+    assert bad.returncode == 1 and "must divide nz" in bad.stderr
     bad = subprocess.run([exe, "--rule", "nonsense"], capture_output=True, text=True)
     assert bad.returncode == 1 and "unknown --rule" in bad.stderr

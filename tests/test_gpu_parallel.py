@@ -72,6 +72,102 @@ def test_rccl_binding_one_rank_communicator(oracle):
     L.MgcgCommDestroy(comm)
 
 
+@pytest.mark.parametrize("overlap", ["0", "2"])
+def test_one_rank_rccl_communicator_takes_the_several_ranks_path(oracle, mgcg_env, overlap):
+    """MGCG_FORCE_MULTIRANK: a REAL one-rank RCCL communicator is sent through the code path of N > 1 -- reduction launches +
+    ncclAllReduce on the stream, the fold behind the all-reduce, a grouped ncclSend/ncclRecv (to itself), fork / join with the
+    interior rows on the side stream and both boundary ranges in one launch, full-length multigrid iterates with per-level
+    exchanges and the batched {r.r, r.z} all-reduce.  The sum over one rank is the rank's own value, so the results are those
+    of the single-rank loop: same iteration index as the oracle, x to 1e-10."""
+    from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu
+
+    L = _lib.lib()
+    L.SetDevice(0)
+    buf = (C.c_char * 128)()
+    assert L.MgcgCommGetUniqueId(buf) == 0, _lib.last_error()
+    comm = L.MgcgCommInitRank(buf, 1, 0)
+    assert comm and L.MgcgCommTransport(comm) == b"rccl", _lib.last_error()
+    n = 32
+    mgcg_env.setenv("MGCG_FORCE_MULTIRANK", str(n * n))         # one grid plane plays the halo and each boundary
+    mgcg_env.setenv("MGCG_OVERLAP", overlap)
+    s = problems.poisson(n, n, n)
+    ref = oracle.cg(s, rule=oracle.RULE_CSHARP, max_iteration=2000, trace=True)
+    cg = ConjugateGradientRankGpu(s.Count, 7, 0, 2000, 1e-8, rank=0, world=1, comm=comm)
+    cg.InitializePoisson(n, n, n)
+    cg.Solve(trace=True)
+    cg.Read()
+    active, i0, i1 = cg.LastOverlap()
+    assert (active, i0, i1) == ((True, n * n, s.Count - n * n) if overlap == "2" else (False, 0, 0))
+    assert cg.Iteration == ref["iteration"]
+    assert np.abs(cg.x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
+    from tests.gpu_util import assert_trace_close
+    assert_trace_close(cg.trace, ref["trace"])
+    cg.Dispose()
+    cg = ConjugateGradientRankGpu(s.Count, 7, 0, 2000, 1e-8, rank=0, world=1, comm=comm)
+    cg.InitializePoisson(n, n, n)
+    res = cg.Steps(5, restart=True)                             # bench.py's fixed-length form on the same path
+    assert abs(res - ref["trace"][4]) <= 1e-10 * ref["trace"][4]
+    cg.Dispose()
+    mref = oracle.Multigrid(s, levels=3).pcg(rule=oracle.RULE_CSHARP, max_iteration=400)
+    for interpolation in (0, 1):
+        m = mref if interpolation == 0 else oracle.Multigrid(s, levels=3, interpolation=1).pcg(rule=oracle.RULE_CSHARP, max_iteration=400)
+        mg = ConjugateGradientMgRankGpu(s.Count, 7, 0, 400, 1e-8, (n, n, n), rank=0, world=1, comm=comm, levels=3, interpolation=interpolation)
+        mg.InitializePoisson(n, n, n)
+        mg.Setup()
+        mg.Solve()
+        mg.Read()
+        assert mg.Iteration == m["iteration"]
+        assert np.abs(mg.x - m["x"]).max() <= 1e-10 * np.abs(m["x"]).max()
+        mg.Dispose()
+    L.MgcgCommDestroy(comm)
+
+
+def test_comm_init_all_single_process(oracle, mgcg_env):
+    """MgcgCommInitAll: the communicators of every device of ONE process (ConjugateGradientParallelGpu's shape); on this box
+    the 3 devices are virtual, so the group is the in-process loopback; each device's thread runs the whole native loop."""
+    import threading
+
+    world = 3
+    mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    L = _lib.lib()
+    comms = (C.c_void_p * world)()
+    assert L.MgcgCommInitAll(comms, world) == 0, _lib.last_error()
+    assert all(comms[d] for d in range(world)) and L.MgcgCommTransport(comms[0]) == b"loopback"
+    assert [L.MgcgCommRank(comms[d]) for d in range(world)] == [0, 1, 2] and L.MgcgCommSize(comms[1]) == world
+    s = problems.mgcg_main(2403, 160)
+    ref = oracle.cg_parallel(s, world, max_iteration=s.Count)
+    out, errs = [None] * world, [None] * world
+
+    def run(r):
+        try:
+            cg = ConjugateGradientRankGpu(s.Count, 160, 0, s.Count, 1e-8, rank=r, world=world, comm=comms[r], device=r).load(s)
+            cg.Initialize()
+            cg.Solve()
+            cg.Read()
+            out[r] = (cg.Iteration, cg.x[cg.part.offset: cg.part.offset + cg.part.count].copy(), cg.part.offset)
+            cg.Dispose()
+        except Exception as e:      # noqa: BLE001
+            errs[r] = e
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert errs == [None] * world, errs
+    x = np.concatenate([o[1] for o in out])
+    assert all(o[0] == ref["iteration"] for o in out)
+    assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
+    for d in range(world):
+        L.MgcgCommDestroy(comms[d])
+    one = (C.c_void_p * 1)()
+    assert L.MgcgCommInitAll(one, 1) == 0 and L.MgcgCommTransport(one[0]) == b"single"
+    L.MgcgCommDestroy(one[0])
+    many = (C.c_void_p * 64)()
+    assert L.MgcgCommInitAll(many, 64) == -1 and "device" in _lib.last_error() and not any(many)
+    L.MgcgClearLastError()
+
+
 def test_phased_ranks_share_the_gpu_over_gloo(oracle, tmp_path):
     """Two processes (the box has one GPU; both ranks use it), HIP phase functions, gloo collectives."""
     import subprocess
