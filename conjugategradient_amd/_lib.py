@@ -67,6 +67,7 @@ SIGNATURES = {
     "MgcgAbiVersion": (_i, []),
     "MgcgCommInitAll": (_i, [_vp, _i]),
     "MgcgCommTransport": (C.c_char_p, [_vp]),
+    "MgcgCommProbe": (_d, [_vp, _i, _i, _i]),
     "MgcgSetTuning": (_i, [C.c_char_p, _i]),
     "MgcgGetTuning": (_i, [C.c_char_p, _pi]),
     "MgcgReloadEnvironment": (None, []),

@@ -593,6 +593,56 @@ const char* MgcgCommTransport(const MgcgComm* c)
     return "single";
 }
 
+__global__ void probe_empty_kernel(int* p) { if (p) *p = 0; }
+
+double MgcgCommProbe(MgcgComm* c, int what, int count, int reps)
+{
+    DeviceState* d = device_state();
+    if (!d || !c || reps < 1 || count < 0 || what < 0 || what > 3) { if (d) set_error("MgcgCommProbe: bad argument"); return NAN; }
+    hipStream_t s = c->stream ? c->stream : d->stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double* buf = nullptr;
+    const size_t n = (size_t)(count > 8 ? count : 8);
+    bool ok = MGCG_HIP(hipEventCreate(&e0)) && MGCG_HIP(hipEventCreate(&e1)) && MGCG_HIP(hipMalloc((void**)&buf, sizeof(double) * 2 * n)) &&
+              MGCG_HIP(hipMemsetAsync(buf, 0, sizeof(double) * 2 * n, s));
+    Rccl* r = (c->comm != nullptr) ? rccl() : nullptr;
+    auto once = [&]() -> bool {
+        switch (what) {
+        case 0: return comm_allreduce_sum(c, buf, count > 8 ? 8 : (count < 1 ? 1 : count), s);
+        case 1: {
+            if (!r) return true;                                   // host-staged transports: nothing to time on the device
+            bool g = nccl_ok(r->GroupStart(), "ncclGroupStart");
+            for (int q = 0; g && q < c->nranks; ++q) {
+                if (q == c->rank && c->nranks > 1) continue;
+                g = g && nccl_ok(r->Send(buf, (size_t)count, NCCL_DOUBLE, q, c->comm, s), "ncclSend");
+                g = g && nccl_ok(r->Recv(buf + n, (size_t)count, NCCL_DOUBLE, q, c->comm, s), "ncclRecv");
+            }
+            return nccl_ok(r->GroupEnd(), "ncclGroupEnd") && g;
+        }
+        case 2: {
+            if (!c->haloStream && (!MGCG_HIP(hipStreamCreateWithFlags(&c->haloStream, hipStreamNonBlocking)) ||
+                                   !MGCG_HIP(hipEventCreateWithFlags(&c->evReady, hipEventDisableTiming)) || !MGCG_HIP(hipEventCreateWithFlags(&c->evHalo, hipEventDisableTiming)))) return false;
+            hipStream_t side = halo_overlap_fork(c, s);
+            if (!side) return false;
+            hipLaunchKernelGGL(probe_empty_kernel, dim3(1), dim3(1), 0, side, (int*)nullptr);
+            return halo_overlap_join(c, s);
+        }
+        default: hipLaunchKernelGGL(probe_empty_kernel, dim3(1), dim3(1), 0, s, (int*)nullptr); return true;
+        }
+    };
+    for (int i = 0; ok && i < 3; ++i) ok = once();                // warm-up (RCCL builds its channels at the first use)
+    ok = ok && MGCG_HIP(hipEventRecord(e0, s));
+    for (int i = 0; ok && i < reps; ++i) ok = once();
+    ok = ok && MGCG_HIP(hipEventRecord(e1, s)) && MGCG_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    ok = ok && MGCG_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipStreamSynchronize(s);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (buf) (void)hipFree(buf);
+    return ok ? 1e3 * (double)ms / reps : NAN;
+}
+
 MgcgLoopback* MgcgLoopbackCreate(int nranks)
 {
     if (nranks < 1 || nranks > 64) { set_error("MgcgLoopbackCreate: bad rank count %d", nranks); return nullptr; }

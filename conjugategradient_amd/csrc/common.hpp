@@ -57,8 +57,8 @@ struct Tuning {
     std::atomic<int> verbose{0};             // MGCG_VERBOSE            errors also go to stderr
     std::atomic<int> lazyCodeObjects{0};     // MGCG_LAZY_CODE_OBJECTS
     std::atomic<int> virtualDevices{0};      // MGCG_VIRTUAL_DEVICES    one physical GPU shown as n devices (tests)
+    std::atomic<int> haloStream{1};          // MGCG_HALO_STREAM        overlap schedule: 1 the halo exchange on the side stream, the rows on the main stream; 0 the interior rows on the side stream
     std::atomic<int> forceMultiRank{0};      // MGCG_FORCE_MULTIRANK    a one-rank communicator takes the several-ranks code path (measurement)
-    std::atomic<int> wideAllReduce{0};       // MGCG_WIDE_ALLREDUCE     several ranks: all-reduce the partial-sum arrays (no reduction launch)
 };
 Tuning& tuning();
 void tuning_reload();
@@ -169,7 +169,7 @@ struct DcsrMatrix {
     double* tileVals = nullptr; int* tileCols = nullptr; int* tileRowIds = nullptr; int nTiles = 0; long long tileRows = 0;
     std::vector<int> tileStart;
     bool usable = false;
-    bool stale = false;          // a write through the library touched the arrays the analysis was made from: analyse again at the next use
+    std::atomic<bool> stale{false};   // a write through the library touched the arrays the analysis was made from: analyse again at the next use
     void release();
     DcsrView view() const
     {

@@ -38,11 +38,11 @@ const Knob kKnobs[] = {
     { "MGCG_NO_INDEXED_HALO", "no_indexed_halo", &Tuning::noIndexedHalo, 0, true },
     { "MGCG_TILE_NT", "tile_nt", &Tuning::tileNt, 0, false },
     { "MGCG_TILE_SHIFT", "tile_shift", &Tuning::tileShift, 0, false },
-    { "MGCG_VERBOSE", "verbose", &Tuning::verbose, 0, true },
+    { "MGCG_VERBOSE", "verbose", &Tuning::verbose, 0, false },
     { "MGCG_LAZY_CODE_OBJECTS", "lazy_code_objects", &Tuning::lazyCodeObjects, 0, true },
     { "MGCG_VIRTUAL_DEVICES", "virtual_devices", &Tuning::virtualDevices, 0, false },
+    { "MGCG_HALO_STREAM", "halo_stream", &Tuning::haloStream, 1, false },
     { "MGCG_FORCE_MULTIRANK", "force_multirank", &Tuning::forceMultiRank, 0, false },
-    { "MGCG_WIDE_ALLREDUCE", "wide_allreduce", &Tuning::wideAllReduce, 0, false },
 };
 Tuning g_tuning;
 std::once_flag g_tuningOnce;
@@ -182,7 +182,7 @@ void analysis_note_write(const void* p, size_t bytes)
     for (DcsrMatrix* m : g_analysed)
         if (hits(m->elements, sizeof(double) * (size_t)m->nnz) || hits(m->columnIndeces, sizeof(int) * (size_t)m->nnz) ||
             hits(m->rowOffsets, sizeof(int) * (size_t)(m->rows + 1)))
-            m->stale = true;
+            m->stale.store(true, std::memory_order_release);
 }
 
 const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* rowOffsets, const int* columnIndeces,
@@ -192,31 +192,36 @@ const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* 
     DcsrMatrix* m = nullptr;
     for (DcsrMatrix* q : h->analysed)
         if (q->elements == elements && q->rowOffsets == rowOffsets && q->columnIndeces == columnIndeces && q->rows == rows && q->nnz == nnz && q->rowBase == rowBase) {
-            if (!q->stale) return q->usable ? q : nullptr;
+            if (!q->stale.load(std::memory_order_acquire)) return q->usable ? q : nullptr;
             m = q;                                          // written to since: same slot, new analysis
             break;
         }
     if (m == nullptr && (rows <= 0 || nnz < 8)) return nullptr;
     const double avg = rows > 0 ? (double)nnz / (double)rows : 0.0;
     if (m == nullptr && avg > 64.0) return nullptr;
+    // The identity fields are what analysis_note_write (any thread, any device) compares a written range with: they change only under
+    // the registry's mutex.  stale is cleared BEFORE the arrays are read again, so a write that arrives while the new analysis is being
+    // built marks it stale once more instead of being lost.
+    auto identify = [&] { m->elements = elements; m->rowOffsets = rowOffsets; m->columnIndeces = columnIndeces; m->rows = rows; m->nnz = nnz; m->rowBase = rowBase; };
     if (m != nullptr) {
         (void)hipStreamSynchronize(h->ws.stream);           // kernels that still read the old form
+        std::lock_guard<std::mutex> lock(g_analysedMutex);
         m->release();
-        m->stale = false;
+        m->stale.store(false, std::memory_order_release);
+        identify();
     } else {
         m = new DcsrMatrix();
+        identify();
         h->analysed.push_back(m);
         registry_add(m);
     }
-    auto identify = [&] { m->elements = elements; m->rowOffsets = rowOffsets; m->columnIndeces = columnIndeces; m->rows = rows; m->nnz = nnz; m->rowBase = rowBase; };
-    identify();
     // 1. one byte per row (few distinct rows-as-sequences), 2. one or two bytes per nonzero (few distinct offsets / values;
     //    the wide loads of that kernel need 16-byte aligned values and short average rows: one pass per 64-row block)
     // 3. a column-tiled copy for matrices whose gathers have no locality (sorted rows, entries far from the diagonal)
     if (h->compression == 1 && avg <= 32.0 && pattern_build(h->ws.stream, elements, rowOffsets, columnIndeces, rows, nnz, rowBase, m) && m->patternId != nullptr) {
         m->usable = true;
     } else if ((((uintptr_t)elements) & 15) == 0 && avg <= 7.75) {
-        if (!dcsr_build(h->ws.stream, elements, rowOffsets, columnIndeces, rows, nnz, rowBase, m)) { m->release(); identify(); }
+        if (!dcsr_build(h->ws.stream, elements, rowOffsets, columnIndeces, rows, nnz, rowBase, m)) { std::lock_guard<std::mutex> lock(g_analysedMutex); m->release(); identify(); }
     }
     if (!m->usable && h->compression == 1 && columns > 0) {
         if (tiled_build(h->ws.stream, elements, rowOffsets, columnIndeces, rows, nnz, rowBase, columns, m) && m->tileVals != nullptr) m->usable = true;

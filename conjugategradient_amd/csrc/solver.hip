@@ -9,6 +9,7 @@
 // later kernel exits at its first instruction, so x, r, p, Iteration and Residual are exactly those
 // of the iteration the reference would have stopped at.
 #include "common.hpp"
+#include <chrono>
 
 namespace mgcg {
 
@@ -48,9 +49,14 @@ struct MgcgMg {
     MgcgComm* comm = nullptr;              // not owned
     int nranks = 1;
     bool multi = false;                    // several ranks (or one rank forced onto that path, comm_multi): full-length iterates, halo exchanges, all-reduces
+    bool haloOnSide = true;                // overlap schedule (tuning knob halo_stream, resolved at set-up)
     // r.z of the PCG loop rides on the V-cycle's last sweep (single rank): partial sums go here, fusedDotCount of them
     double* fuseDotPartials = nullptr;
     int fusedDotCount = 0;
+    // several ranks: the last sweep of the cycle writes the rank's rows of z = M^-1 r straight into the caller's vector (nobody needs the
+    // halo of the final iterate) instead of into a full-length buffer that is then copied out
+    double* finalOut = nullptr;
+    bool finalWritten = false;
 };
 
 namespace mgcg {
@@ -68,7 +74,9 @@ static bool plan_overlap(hipStream_t s, MgcgComm* comm, bool multi, const int* r
 {
     *active = false; *i0 = 0; *i1 = 0;
     const int mode = tuning().overlap.load(std::memory_order_relaxed);
-    if (!multi || mode == 0 || (mode == 1 && n < 4096)) return true;
+    // mode 1: only where the rows between fork and join outlast the two cross-stream hops (10 us each, measured) and the exchange --
+    // a row-tile SpMV streams ~55 k rows per us, so below ~3 M rows the exchange in line is the cheaper schedule (profiles/r3/slab_latency.json)
+    if (!multi || mode == 0 || (mode == 1 && n < 3000000)) return true;
     if (MgcgCommSize(comm) == 1) {
         // one rank forced onto the several-ranks path (measurement): an artificial split -- the first and last force_multirank rows
         // (rounded to SpMV tiles) play the boundary
@@ -97,19 +105,35 @@ static bool mg_halo(MgcgMg* mg, MgLevel& L, double* xfull)
 }
 
 // Halo of the full-length iterate a.x, then the SpMV-shaped pass; interior rows first when the level overlaps.
-static bool mg_spmv(MgcgMg* mg, MgLevel& L, int epilogue, const SpmvArgs& a, double* xfull)
+// partials / nPartials (dot epilogues): where the per-workgroup partial sums go and how many were written.
+static bool mg_spmv(MgcgMg* mg, MgLevel& L, int epilogue, const SpmvArgs& a, double* xfull, double* partials = nullptr, int* nPartials = nullptr)
 {
     hipStream_t s = mg->stream;
+    int n = 0;
+    if (nPartials) *nPartials = 0;
+    const int half = partials ? kMaxPartials / 2 : 0;
     if (!L.overlap) {
         if (!mg_halo(mg, L, xfull)) return false;
-        launch_spmv_auto(s, epilogue, a, L.cfg, L.dcsr);
+        SpmvArgs b = a; b.partials = partials;
+        n = launch_spmv_auto(s, epilogue, b, L.cfg, L.dcsr);
+        if (nPartials) *nPartials = n;
         return true;
     }
     hipStream_t side = halo_overlap_fork(mg->comm, s);
     if (!side) return false;
-    launch_spmv_range(side, epilogue, a, L.cfg, L.dcsr, L.interior0, L.interior1, nullptr, 0);
+    if (mg->haloOnSide) {
+        // the exchange on the side stream, all rows on the main stream: both cross-stream hops hide behind the interior rows
+        if (!halo_exchange(mg->comm, L.halo, xfull, side)) return false;
+        n = launch_spmv_range(s, epilogue, a, L.cfg, L.dcsr, L.interior0, L.interior1, partials, half);
+        if (!halo_overlap_join(mg->comm, s)) return false;
+        n += launch_spmv_two_ranges(s, epilogue, a, L.cfg, L.dcsr, L.interior0, L.interior1, partials ? partials + n : nullptr, half);   // the boundary rows either side of the interior
+        if (nPartials) *nPartials = n;
+        return true;
+    }
+    n = launch_spmv_range(side, epilogue, a, L.cfg, L.dcsr, L.interior0, L.interior1, partials, half);
     if (!mg_halo(mg, L, xfull)) return false;
-    launch_spmv_two_ranges(s, epilogue, a, L.cfg, L.dcsr, L.interior0, L.interior1, nullptr, 0);     // the boundary rows either side of the interior
+    n += launch_spmv_two_ranges(s, epilogue, a, L.cfg, L.dcsr, L.interior0, L.interior1, partials ? partials + n : nullptr, half);
+    if (nPartials) *nPartials = n;
     return halo_overlap_join(mg->comm, s);
 }
 
@@ -120,10 +144,16 @@ static bool mg_jacobi(MgcgMg* mg, MgLevel& L, const double* b, double* xin, doub
     a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = xin; a.y = xout + L.offset;
     a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal;
     a.w = xin + L.offset; a.b = b; a.dinv = L.dinv; a.dinvUniform = L.dinvUniform ? 1 : 0; a.dinvScalar = L.dinvScalar; a.omega = mg->omega; a.doneFlag = done;
-    if (withDot && !mg->multi && mg->fuseDotPartials != nullptr) {          // + partial sums of b . xout
-        a.partials = mg->fuseDotPartials;
-        mg->fusedDotCount = launch_spmv_auto(mg->stream, EPI_JACOBI_DOT, a, L.cfg, L.dcsr);
-        return true;
+    // withDot marks the LAST sweep of the cycle on the finest level: r.z of the PCG loop rides on it (partial sums of b . xout), and
+    // with several ranks it writes the rank's rows of the result where the caller wants them
+    if (withDot && mg->multi && mg->finalOut != nullptr) { a.y = mg->finalOut; mg->finalWritten = true; }
+    if (withDot && mg->fuseDotPartials != nullptr) {
+        if (!mg->multi) {
+            a.partials = mg->fuseDotPartials;
+            mg->fusedDotCount = launch_spmv_auto(mg->stream, EPI_JACOBI_DOT, a, L.cfg, L.dcsr);
+            return true;
+        }
+        return mg_spmv(mg, L, EPI_JACOBI_DOT, a, xin, mg->fuseDotPartials, &mg->fusedDotCount);
     }
     return mg_spmv(mg, L, EPI_JACOBI, a, xin);
 }
@@ -205,8 +235,11 @@ static bool mg_apply(MgcgMg* mg, const double* r, double* z, const int* done, do
         if (res != z) launch_copy(mg->stream, z, res, L0.n);       // not reached for the buffer choice above
         return true;
     }
-    if (!mg_vcycle(mg, 0, r, L0.xa, L0.xb, done, &res)) return false;
-    launch_copy(mg->stream, z, res + L0.offset, L0.n);
+    mg->finalOut = z; mg->finalWritten = false;
+    const bool ok = mg_vcycle(mg, 0, r, L0.xa, L0.xb, done, &res);
+    mg->finalOut = nullptr;
+    if (!ok) return false;
+    if (!mg->finalWritten) launch_copy(mg->stream, z, res + L0.offset, L0.n);   // (a cycle whose last step is not a Jacobi sweep: one level, one sweep)
     return true;
 }
 
@@ -231,7 +264,8 @@ struct CgRun {
     // rows [interior0, interior1) reference local columns only: they are multiplied (side stream) while the halo of p is in flight
     bool overlap = false;
     long long interior0 = 0, interior1 = 0;
-    bool noFoldedFinalize = false;         // tuning knob, resolved once per solve (every iteration of every rank takes the same path)
+    bool noFoldedFinalize = false;         // tuning knobs, resolved once per solve (every iteration of every rank takes the same path)
+    bool haloOnSide = true;
 };
 
 static thread_local long long t_lastOverlap[3] = { 0, 0, 0 };
@@ -287,7 +321,7 @@ static bool cg_enqueue_init(CgRun& R)
     int n;
     if (R.mg) {
         int nz = 0;
-        if (!mg_apply(R.mg, R.r, R.z, nullptr, !R.multi ? R.ws->partials : nullptr, &nz)) return false;   // z = M^-1 r (+ r.z)
+        if (!mg_apply(R.mg, R.r, R.z, nullptr, R.ws->partials, &nz)) return false;   // z = M^-1 r (+ r.z)
         launch_copy(s, pLoc, R.z, R.nLocal);                                         // p = z
         n = nz > 0 ? nz : launch_dot_partials(s, R.r, R.z, R.nLocal, R.ws->partials);   // rz = r.z
     } else {
@@ -319,10 +353,19 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
         prof_mark(R, true);
         hipStream_t side = halo_overlap_fork(R.comm, s);
         if (!side) return false;
-        n = launch_spmv_range(side, EPI_DOT, a, R.cfg, R.dcsr, R.interior0, R.interior1, R.ws->partials, kMaxPartials / 2);
-        if (!halo_exchange(R.comm, R.halo, R.p, s)) return false;
-        n += launch_spmv_two_ranges(s, EPI_DOT, a, R.cfg, R.dcsr, R.interior0, R.interior1, R.ws->partials + n, kMaxPartials / 2);   // boundary rows: one launch when the cuts fall on tiles
-        if (!halo_overlap_join(R.comm, s)) return false;
+        if (R.haloOnSide) {
+            // SyncP (:469) on the side stream, all rows on the main stream: the two cross-stream hops (10 us each, measured) and the wire
+            // time of the planes hide behind the interior rows; the join finds the exchange long finished
+            if (!halo_exchange(R.comm, R.halo, R.p, side)) return false;
+            n = launch_spmv_range(s, EPI_DOT, a, R.cfg, R.dcsr, R.interior0, R.interior1, R.ws->partials, kMaxPartials / 2);
+            if (!halo_overlap_join(R.comm, s)) return false;
+            n += launch_spmv_two_ranges(s, EPI_DOT, a, R.cfg, R.dcsr, R.interior0, R.interior1, R.ws->partials + n, kMaxPartials / 2);   // boundary rows: one launch when the cuts fall on tiles
+        } else {
+            n = launch_spmv_range(side, EPI_DOT, a, R.cfg, R.dcsr, R.interior0, R.interior1, R.ws->partials, kMaxPartials / 2);
+            if (!halo_exchange(R.comm, R.halo, R.p, s)) return false;
+            n += launch_spmv_two_ranges(s, EPI_DOT, a, R.cfg, R.dcsr, R.interior0, R.interior1, R.ws->partials + n, kMaxPartials / 2);
+            if (!halo_overlap_join(R.comm, s)) return false;
+        }
         prof_mark(R, false);
     } else {
         if (!halo_exchange(R.comm, R.halo, R.p, s)) return false;                    // SyncP  (:469)
@@ -360,7 +403,7 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
         // which costs one wasted V-cycle at the very end and saves a collective per iteration.
         launch_reduce_to(s, rrPartials, n, &sc->rrNew, done);                        // local r.r (before the V-cycle reuses the partial sums)
         int nz = 0;
-        if (!mg_apply(R.mg, R.r, R.z, done, nullptr, &nz)) return false;             // z = M^-1 r
+        if (!mg_apply(R.mg, R.r, R.z, done, R.ws->partials, &nz)) return false;      // z = M^-1 r (+ partial sums of r.z on the last sweep)
         n = nz > 0 ? nz : launch_dot_partials(s, R.r, R.z, R.nLocal, R.ws->partials);
         launch_reduce_to(s, R.ws->partials, n, &sc->rzNew, done);                    // local r.z
         if (!comm_allreduce_sum(R.comm, &sc->rrNew, 2, s)) return false;             // {rrNew, rzNew} are adjacent in CgScalars  (:525 and the PCG's r.z)
@@ -411,6 +454,7 @@ static int cg_solve(CgRun& R, int* iteration, double* residual, double* residual
     if (!devTraceCap) { R.ws->trace = nullptr; R.ws->traceCap = 0; } else R.ws->traceCap = devTraceCap;
 
     R.noFoldedFinalize = tuning().noFoldedFinalize.load(std::memory_order_relaxed) != 0;
+    R.haloOnSide = tuning().haloStream.load(std::memory_order_relaxed) != 0;
     int status = MGCG_ERROR;
     int checkEvery = 4;
     { const int v = tuning().checkEvery.load(std::memory_order_relaxed); if (v >= 1) checkEvery = v; }
@@ -564,11 +608,19 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     if (R.elementsCount >= 8) R.cfg.periodRows = spmv_period(cusparse, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.cfg.maxRow);
     R.cfg.flags |= 8;
     R.noFoldedFinalize = tuning().noFoldedFinalize.load(std::memory_order_relaxed) != 0;
+    R.haloOnSide = tuning().haloStream.load(std::memory_order_relaxed) != 0;
     if (ok && restart) ok = cg_enqueue_init(R);
     else if (ok) hipLaunchKernelGGL(clear_done_kernel, dim3(1), dim3(1), 0, R.ws->stream, R.ws->scalars);
+    const bool report = tuning().verbose.load(std::memory_order_relaxed) >= 2;      // MGCG_VERBOSE=2: is the host or the device the limit?
+    const auto h0 = std::chrono::steady_clock::now();
     for (int k = 0; ok && k < steps; ++k) ok = cg_enqueue_iteration(R, false);
     if (ok) hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(1), 0, R.ws->stream, R.ws->scalars, R.ws->mirror, (volatile int*)&R.ws->hostScalar[2]);
+    const auto h1 = std::chrono::steady_clock::now();
     ok = MGCG_HIP(hipStreamSynchronize(R.ws->stream)) && ok;
+    if (report && steps > 0) {
+        const double enq = std::chrono::duration<double, std::micro>(h1 - h0).count() / steps, all = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count() / steps;
+        fprintf(stderr, "[MgcgGpu] CgSteps: host enqueue %.1f us per iteration, enqueue + drain %.1f us per iteration (%d steps)\n", enq, all, steps);
+    }
     if (R.halo) halo_plan_destroy(R.halo);
     R.ws->trace = savedTrace; R.ws->traceCap = savedCap;
     return ok ? (double)R.ws->mirror->residual : NAN;
@@ -633,6 +685,7 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     mg->omega = omega; mg->nu = nu; mg->nuCoarse = nuCoarse; mg->sigma = sigma; mg->stream = s; mg->cfg = cfg_of(cusparse);
     mg->cfg.kernel = 0;   // every level picks its kernel from its own nnz/row
     mg->comm = comm; mg->nranks = nranks; mg->multi = comm_multi(comm);
+    mg->haloOnSide = tuning().haloStream.load(std::memory_order_relaxed) != 0;
     const bool multi = mg->multi;
     int* dErr = nullptr;
     int* dmm = nullptr;

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""One rank's slab on the several-ranks code path (MGCG_FORCE_MULTIRANK, a real one-rank RCCL communicator) for a kernel trace:
+    rocprofv3 --kernel-trace --output-format csv -d OUT -- python3 conjugategradient_amd/tools/forced_path_run.py --overlap 2 --halo-stream 1
+then tools/trace_timeline.py OUT prints the kernels of one iteration with the gaps between them.  Without the profiler it prints one
+JSON line with the milliseconds per iteration (tools/slab_latency.py runs every schedule in a fresh process through this)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nx", type=int, default=512)
+    ap.add_argument("--planes", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--overlap", type=int, default=2)
+    ap.add_argument("--halo-stream", type=int, default=1)
+    ap.add_argument("--force", type=int, default=-1, help="entries of the artificial halo (default one plane; 0: the plain single-rank loop)")
+    ap.add_argument("--solver", choices=["cg", "mgcg"], default="cg")
+    ap.add_argument("--repeats", type=int, default=1)
+    a = ap.parse_args()
+    from conjugategradient_amd import _lib
+    from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu, ConjugateGradientRankGpu
+
+    L = _lib.lib()
+    _lib.require_gpu()
+    L.SetDevice(0)
+    comm = None
+    force = a.nx * a.nx if a.force < 0 else a.force
+    if force > 0:
+        buf = (C.c_char * 128)()
+        assert L.MgcgCommGetUniqueId(buf) == 0, _lib.last_error()
+        comm = L.MgcgCommInitRank(buf, 1, 0)
+        _lib.check("MgcgCommInitRank")
+    L.MgcgSetTuning(b"force_multirank", force)
+    L.MgcgSetTuning(b"overlap", a.overlap)
+    L.MgcgSetTuning(b"halo_stream", a.halo_stream)
+    dims = (a.nx, a.nx, a.planes)
+    n = dims[0] * dims[1] * dims[2]
+    import json
+    import time
+
+    def timed(fn):
+        L.MgcgDeviceSynchronize()
+        t0 = time.perf_counter()
+        fn()
+        L.MgcgDeviceSynchronize()
+        return (time.perf_counter() - t0) * 1e3 / a.steps
+
+    if a.solver == "mgcg":
+        cg = ConjugateGradientMgRankGpu(n, 7, 0, 10**9, 1e300, dims, rank=0, world=1, comm=comm, rule=_lib.RULE_NATIVE, levels=3, nu=1, nuCoarse=4)
+        cg.InitializePoisson(*dims)
+        cg.Setup()
+        cg.MinIteration = a.steps - 1
+
+        def run():
+            L.MgcgFill(cg.vectorX.Ptr, 0.0)
+            cg.Solve()
+        run()
+    else:
+        cg = ConjugateGradientRankGpu(n, 7, 0, 10**9, 1e-8, rank=0, world=1, comm=comm)
+        cg.InitializePoisson(*dims)
+        cg.Steps(10, restart=True)
+
+        def run():
+            cg.Steps(a.steps, restart=False)
+    ms = [timed(run) for _ in range(a.repeats)]
+    active = cg.LastOverlap()[0] if a.solver == "cg" else None
+    print(json.dumps({"solver": a.solver, "grid": list(dims), "force_multirank": force, "overlap": a.overlap, "halo_stream": a.halo_stream,
+                      "steps": a.steps, "ms_per_iteration": min(ms), "ms_per_iteration_all": ms, "halo_overlap_active": active}))
+    cg.Dispose()
+
+
+if __name__ == "__main__":
+    main()

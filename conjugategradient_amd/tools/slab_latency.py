@@ -7,6 +7,9 @@ The per-rank problem of BASELINE config 4 is a 64-plane slab of the 512^3 grid (
      multi-rank code path -- halo plan, halo exchange, all-reduces, interior/boundary split -- with the loopback transport's
      host-staged collectives standing in for RCCL (each is a D2H copy + thread barrier + H2D copy: slower than an RCCL
      all-reduce over xGMI, so B - A is an upper bound of the per-iteration overhead),
+  C. the slab on one rank through the several-ranks code path with a real one-rank RCCL communicator (MGCG_FORCE_MULTIRANK): every
+     launch, collective call and event the path adds, on the device's own stream, without B's host synchronisations (and without
+     the xGMI wire time, which a one-GPU box cannot show); plus MgcgCommProbe's per-step prices,
 for plain CG and for the 3-level MGCG, and prints one JSON object with the implied 8-GPU ceiling
 T(512^3, 1 GPU) / (T_slab + overhead).  Run under `rocprofv3 --kernel-trace --stats` to get launches per iteration."""
 import argparse
@@ -26,6 +29,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--full", type=int, default=512, help="n of the n^3 single-GPU reference run (0: skip)")
     ap.add_argument("--skip-mg", action="store_true")
+    ap.add_argument("--skip-forced", action="store_true", help="skip section C (one-rank RCCL communicator on the several-ranks path)")
     a = ap.parse_args()
     os.environ["MGCG_VIRTUAL_DEVICES"] = "2"
     from conjugategradient_amd import _lib
@@ -65,6 +69,22 @@ def main():
             cg.Steps(k, restart=restart)
 
     kinds = ["cg"] + ([] if a.skip_mg else ["mgcg"])
+    rccl1 = None
+    if not a.skip_forced:
+        import ctypes as C
+
+        L.SetDevice(0)
+        buf = (C.c_char * 128)()
+        if L.MgcgCommGetUniqueId(buf) != 0:
+            raise SystemExit("no RCCL: " + _lib.last_error())
+        rccl1 = L.MgcgCommInitRank(buf, 1, 0)
+        _lib.check("MgcgCommInitRank")
+        # device-side price of each step the several-ranks path adds, back to back on the communicator's stream (HIP events)
+        probe = {}
+        for name, what, count in (("allreduce_8B_us", 0, 1), ("allreduce_16B_us", 0, 2), ("self_send_recv_one_plane_us", 1, nx * nx), ("self_send_recv_8B_us", 1, 1),
+                                  ("fork_join_us", 2, 0), ("kernel_boundary_us", 3, 0)):
+            probe[name] = L.MgcgCommProbe(rccl1, what, count, 200)
+        out["one_rank_rccl_probes"] = probe
     for kind in kinds:
         # A: one rank, the whole slab
         cg = make(kind, 0, 1, None, (nx, nx, nz))
@@ -107,6 +127,32 @@ def main():
         msB = max(r[0] for r in res)
         out[kind] = {"one_rank_ms_per_iteration": msA, "two_loopback_ranks_ms_per_iteration": msB,
                      "overhead_upper_bound_ms": msB - msA, "halo_overlap_active": res[0][1]}
+        # C: the whole slab on ONE rank again, but through the several-ranks code path with a REAL one-rank RCCL communicator
+        #    (MGCG_FORCE_MULTIRANK = one grid plane: reduction launches + ncclAllReduce on the stream, the fold behind it, a grouped
+        #    ncclSend/ncclRecv of one plane to itself, fork / join, interior + boundary row ranges) -- no host synchronisation inside
+        #    an iteration, unlike B.  Every schedule runs in a FRESH process (tools/forced_path_run.py), the plain single-rank loop too:
+        #    forced - plain = the device-side cost the path adds per iteration, without the xGMI wire time.
+        if not a.skip_forced:
+            import subprocess
+
+            exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "forced_path_run.py")
+
+            def fresh(*flags):
+                o = subprocess.run([sys.executable, exe, "--nx", str(nx), "--planes", str(nz), "--steps", str(a.steps), "--repeats", "3", "--solver", kind, *flags],
+                                   capture_output=True, text=True, timeout=600)
+                if o.returncode != 0:
+                    raise SystemExit(o.stdout[-2000:] + o.stderr[-2000:])
+                return json.loads([l for l in o.stdout.splitlines() if l.startswith("{")][-1])
+
+            plain = fresh("--force", "0")["ms_per_iteration"]
+            rows = []
+            for overlap, halo_stream in ((0, 1), (2, 0), (2, 1), (1, 1)):
+                r = fresh("--overlap", str(overlap), "--halo-stream", str(halo_stream))
+                rows.append({"overlap": overlap, "schedule": "exchange in line" if overlap == 0 else (("the library's own choice: " if overlap == 1 else "") + (
+                                 "exchange on the side stream, rows on the main stream" if halo_stream else "interior rows on the side stream, exchange on the main stream")),
+                             "ms_per_iteration": r["ms_per_iteration"], "added_us_vs_plain": 1e3 * (r["ms_per_iteration"] - plain), "halo_overlap_active": r["halo_overlap_active"]})
+            out[kind]["fresh_process_plain_ms_per_iteration"] = plain
+            out[kind]["one_rank_rccl_on_the_several_ranks_path"] = rows
     if a.full:
         n = a.full
         for kind in kinds:

@@ -165,7 +165,10 @@ int         MgcgAbiVersion(void);
  *   no_uniform_diagonal, no_zsweep, rowtile_nt / vec_nt (-1 by size, 0 / 1 forced), vec_grid, r_grid, xp_grid,
  *   pattern_group, pattern_waves, no_indexed_halo, tile_nt, tile_shift, verbose, lazy_code_objects,
  *   virtual_devices (MGCG_VIRTUAL_DEVICES: one physical GPU shown as n devices, tests only),
- *   force_multirank (a one-rank communicator takes the several-ranks code path, measurement only), wide_allreduce.
+ *   halo_stream (overlap schedule: 1 [default] the halo exchange runs on the communicator's side stream while the interior rows
+ *   run on the main stream, 0 the interior rows run on the side stream and the exchange on the main stream),
+ *   force_multirank (MGCG_FORCE_MULTIRANK = w > 0: a one-rank RCCL communicator takes the several-ranks code path with an
+ *   artificial halo of w entries, for measuring that path's device-side cost on a one-GPU box).
  * MgcgSetTuning / MgcgGetTuning take the knob's name or its environment variable; they return 0, or -1 for an unknown
  * name (MgcgGetLastError).  MgcgReloadEnvironment reads all variables again.  Change knobs only while no solve is running. */
 int         MgcgSetTuning(const char* name, int value);
@@ -332,6 +335,14 @@ void      MgcgCommDestroy(MgcgComm* comm);
 int       MgcgCommInitAll(MgcgComm* comms[], int ndev);
 /* "rccl", "loopback", "callbacks", "single" (one rank, no transport) or "none" (NULL). */
 const char* MgcgCommTransport(const MgcgComm* comm);
+/* Device-side cost of one collective step of the multi-rank loop on this communicator's stream: `reps` back-to-back
+ *   what = 0  all-reduces (sum) of `count` doubles (count <= 8),
+ *   what = 1  halo exchanges: one grouped send/recv of `count` doubles with every other rank (with itself on one rank),
+ *   what = 2  fork / join pairs of the overlap schedule (event record + stream wait on the side stream and back),
+ *   what = 3  empty single-workgroup kernel launches (the price of a kernel boundary on this stream),
+ * timed with HIP events around the batch; returns microseconds per repetition (NaN on error).  Collective: every rank
+ * of the communicator must make the same call. */
+double    MgcgCommProbe(MgcgComm* comm, int what, int count, int reps);
 int       MgcgCommRank(const MgcgComm* comm);
 int       MgcgCommSize(const MgcgComm* comm);
 /* In-process loopback transport: N ranks of ONE process (host threads, e.g. MGCG_VIRTUAL_DEVICES on one GPU)
