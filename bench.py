@@ -184,6 +184,34 @@ def vcycle_bytes(n: int, levels: int, nu: int, nu_coarse: int):
     return total, shell
 
 
+def vcycle_required_bytes(n: int, levels: int, nu: int, nu_coarse: int, fold: bool = True):
+    """Bytes that MUST move per MGCG iteration on the 7-point n^3 hierarchy as the library runs it (constant-coefficient operator:
+    every level's diagonal is uniform, so D^-1 is a scalar and its array is not read): sweep = 12 nnz + 4 (N + 1) + 24 N (x gathered once,
+    b, x written), first sweep from zero = 16 N, residual = 12 nnz + 4 (N + 1) + 24 N, restriction = 8 N + 8 N_c, prolongation = 16 N + 8 N_c
+    (it reads and rewrites the fine iterate).  fold (V(1,*) on one rank): the first sweep is not stored -- 0 bytes -- and the residual pass
+    gathers b itself: 12 nnz + 4 (N + 1) + 16 N.  Returns (V-cycle bytes, CG shell bytes)."""
+    def nnz(m):
+        return 7 * m**3 - 6 * m * m
+    total = 0
+    m = n
+    for lv in range(levels):
+        N = m**3
+        sweep = 12 * nnz(m) + 4 * (N + 1) + 24 * N
+        if lv == levels - 1:
+            total += 16 * N + (nu_coarse - 1) * sweep
+        else:
+            Nc = (m // 2) ** 3
+            folded = fold and nu == 1
+            total += (0 if folded else 16 * N) + (nu - 1) * sweep
+            total += 12 * nnz(m) + 4 * (N + 1) + (16 * N if folded else 24 * N)
+            total += (8 * N + 8 * Nc) + (16 * N + 8 * Nc)
+            total += nu * sweep
+        m //= 2
+    N0 = n**3
+    shell = 12 * nnz(n) + 4 * (N0 + 1) + 16 * N0 + 72 * N0
+    return total, shell
+
+
 def mgcg_extra(L, n: int):
     """BASELINE config 3 on one GPU: 3-level V(1,1) weighted-Jacobi MGCG on the 7-point n^3 system, plain CSR on every level
     (and, second, on the opt-in row-pattern form), solved to 1e-8 * ||b||."""
@@ -194,8 +222,13 @@ def mgcg_extra(L, n: int):
     tol = 1e-8 * (N ** 0.5)
     levels, nu, nuc = 3, 1, 4
     vb, shell = vcycle_bytes(n, levels, nu, nuc)
+    rb, rshell = vcycle_required_bytes(n, levels, nu, nuc)
     out = {"config": f"MGCG, V({nu},{nu}) cycle, {levels} levels, weighted Jacobi (omega = 6/7), {nuc} coarse sweeps, 7-pt Poisson {n}^3, b = 1, x0 = 0, stop at ||r|| <= 1e-8 ||b||",
-           "algorithmic_bytes_per_iteration": vb + shell, "vcycle_algorithmic_bytes": vb}
+           "algorithmic_bytes_per_iteration": vb + shell, "vcycle_algorithmic_bytes": vb,
+           "required_bytes_per_iteration": rb + rshell, "vcycle_required_bytes": rb,
+           "bytes_note": "algorithmic = SURVEY.md 8d per-pass formulas (D^-1 read as an array, prolongation 8 N + 8 N_c); required = what must move as the library "
+                         "runs the cycle (uniform diagonal: no D^-1 array; prolongation rewrites the fine iterate: 16 N + 8 N_c; V(1,1) on one rank: the first "
+                         "sweep is folded into the residual's gathers).  frac_of_peak is quoted on the REQUIRED bytes"}
     # third row: what a caller who is free to choose the cycle would run -- the hierarchy taken down to 4^3 and the cell-centred
     # linear transfer (MgSetInterpolation; profiles/r2/mgcg_levels_sweep_512_csr*.log); its bytes are its own (the transfers
     # move the same HBM bytes, their extra operands come from cache)
@@ -218,12 +251,15 @@ def mgcg_extra(L, n: int):
             dt = time.perf_counter() - t0
             its = mg.Iteration + 1
             ms = 1e3 * dt / its
+            rb_, rshell_ = vcycle_required_bytes(n, lv_, nu_, nuc_, fold=(interp == 0))
             out[key] = {"iterations": its, "residual": mg.Residual, "solve_s": dt, "ms_per_iteration": ms, "setup_s": setup,
-                        "achieved_gbps": ((vb_ + shell_) / (ms * 1e-3) / 1e9) if mode == 0 else None,
-                        "frac_of_peak": ((vb_ + shell_) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if mode == 0 else None}
+                        "achieved_gbps": ((rb_ + rshell_) / (ms * 1e-3) / 1e9) if mode == 0 else None,
+                        "frac_of_peak": ((rb_ + rshell_) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if mode == 0 else None,
+                        "frac_of_peak_on_survey_formula_bytes": ((vb_ + shell_) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if mode == 0 else None}
             if key != "csr" and mode == 0:
                 out[key]["config"] = f"V({nu_},{nu_}), {lv_} levels, {nuc_} coarse sweeps" + (", cell-centred linear transfer" if interp else "")
                 out[key]["algorithmic_bytes_per_iteration"] = vb_ + shell_
+                out[key]["required_bytes_per_iteration"] = rb_ + rshell_
         finally:
             mg.Dispose()
     return out

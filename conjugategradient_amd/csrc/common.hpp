@@ -243,7 +243,7 @@ struct SpmvArgs {
     double omega;            // EPI_JACOBI
     int dinvUniform;         // EPI_JACOBI: every diagonal is the same; dinvScalar is used and the dinv array is not read
     double dinvScalar;
-    int xScaled;             // row-pattern kernel only: the multiplied vector is xOuter * (xInner * x[col]), formed per gather
+    int xScaled;             // row-pattern and row-tile kernels: the multiplied vector is xOuter * (xInner * x[col]), formed per gather
     double xInner, xOuter;   //   (a first Jacobi sweep from zero folded into the residual pass of the V-cycle)
     double* partials;        // EPI_DOT / EPI_RESIDUAL_DOT / EPI_JACOBI_DOT: one double per workgroup
     const int* doneFlag;     // optional: exit at once when *doneFlag != 0
@@ -274,6 +274,13 @@ struct SpmvConfig { int kernel = 0; int rowsPerBlock = 64; int flags = 0; int gr
 
 // Launches the SpMV; returns the number of partials written (grid size) for dot epilogues.
 int launch_spmv(hipStream_t s, int epilogue, const SpmvArgs& a, const SpmvConfig& cfg);
+// Will launch_spmv hand this plain-CSR product to the row-tile kernel?  (the only CSR kernel that can scale x per gather: SpmvArgs::xScaled)
+inline bool spmv_takes_rowtile(const SpmvArgs& a, const SpmvConfig& cfg)
+{
+    int kernel = cfg.kernel;
+    if (kernel == 0) kernel = spmv_auto_kernel(a.rowCount > 0 ? (double)a.elementsCount / (double)a.rowCount : 0.0);
+    return kernel == 10 && (((uintptr_t)a.elements & 15) == 0) && (((uintptr_t)a.columnIndeces & 15) == 0) && a.elementsCount >= 8 && a.rowCount > 0;
+}
 // Row-tile kernel for short rows on plain CSR (kernels_rowtile.hip); periodRows = distance of the far band in rows (0: unknown),
 // gridReq = wavefronts (0: 8 per CU).  Needs 16-byte aligned elements / columnIndeces and elementsCount >= 8.
 int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int periodRows, int gridReq, int maxRow = 0, bool ntWindow = false,

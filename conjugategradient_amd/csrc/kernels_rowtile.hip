@@ -67,7 +67,9 @@ __device__ __forceinline__ RowsEpi tile_epi_prefetch(const SpmvArgs& a, int row)
 
 // NG = gathers issued per row in the fast path: 8, or 7 when no row of the matrix is longer (a 7-point stencil: one LDS read
 // pair, one gather and one product fewer per row, 1-2.5 % -- profiles/r2/spmv_lab_lab15_micro.log, spmv_lab_lab17_records.log).
-template <int EPI, int NG, bool NT = false>
+// XS: the multiplied vector is xOuter * (xInner * x[col]), formed per gather with the same two rounded products a stored first Jacobi
+// sweep from zero would have used (the V(1,*) fold of the multigrid's residual pass, solver.hip: one 16 N pass less per level).
+template <int EPI, int NG, bool NT = false, bool XS = false>
 __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, TileMap tm, int nTiles)
 {
     __shared__ __attribute__((aligned(16))) int s_colAll[kTCap * kTW];
@@ -89,7 +91,11 @@ __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, Tile
         const int tailRow = (nTiles + tm.gapSkip) * kTRows + (int)threadIdx.x;
         if (wg == 0 && tailRow <= lastRow) {
             double acc = 0.0;
-            for (int k = a.rowOffsets[tailRow]; k < a.rowOffsets[tailRow + 1]; ++k) { const double p = a.elements[k] * a.x[a.columnIndeces[k]]; acc += p; }
+            for (int k = a.rowOffsets[tailRow]; k < a.rowOffsets[tailRow + 1]; ++k) {
+                double xv = a.x[a.columnIndeces[k]];
+                if constexpr (XS) { const double t = a.xInner * xv; xv = a.xOuter * t; }
+                const double p = a.elements[k] * xv; acc += p;
+            }
             const RowsEpi eo = rows_epi_prefetch<EPI>(a, tailRow);
             a.y[tailRow] = rows_epilogue_value<EPI>(a, acc, eo, dot);
         }
@@ -163,7 +169,11 @@ __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, Tile
         } else {
 #pragma unroll
             for (int j = 0; j < NG; ++j) { cc[j] = 0; vv[j] = 0.0; }
-            for (int k = my_s; k < roA_e; ++k) { const double p = a.elements[k] * a.x[a.columnIndeces[k]]; accSlow += p; }
+            for (int k = my_s; k < roA_e; ++k) {
+                double xv = a.x[a.columnIndeces[k]];
+                if constexpr (XS) { const double t = a.xInner * xv; xv = a.xOuter * t; }
+                const double p = a.elements[k] * xv; accSlow += p;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);                         // all LDS reads in flight before the first gather waits for its column id
 #pragma unroll
@@ -177,6 +187,10 @@ __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, Tile
         load_ro(tileAfter, roB_s, roB_e);
         __builtin_amdgcn_sched_barrier(0);                         // no product in front of the prefetch: its wait would hold the raw loads back
         double acc = 0.0;
+        if constexpr (XS) {
+#pragma unroll
+            for (int j = 0; j < NG; ++j) { const double t = a.xInner * xg[j]; xg[j] = a.xOuter * t; }
+        }
 #pragma unroll
         for (int j = 0; j < NG; ++j) { const double p = vv[j] * xg[j]; acc += (j < cnt) ? p : 0.0; }
         acc = fast ? acc : accSlow;
@@ -259,6 +273,13 @@ static int launch_rowtile_epi(hipStream_t s, const SpmvArgs& a, int periodRows, 
     const int ntKnob = tuning().rowtileNt.load(std::memory_order_relaxed);
     const bool nt = ntKnob >= 0 ? ntKnob != 0 : (ntWindow && a.rowCount >= 8000000 && a.rowCount <= 36000000);
     const bool seven = maxRow > 0 && maxRow <= 7;
+    if (a.xScaled) {                                              // (only the multigrid's residual pass asks; never with the streaming hint)
+        if constexpr (EPI == EPI_RESIDUAL) {
+            if (seven) hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 7, false, true>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
+            else hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 8, false, true>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
+            return nWG * kTW;
+        } else { set_error("row-tile SpMV: a scaled multiplicand is implemented for the residual epilogue only"); return 0; }
+    }
     if (nt) {
         if (seven) hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 7, true>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
         else hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 8, true>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);

@@ -183,11 +183,16 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
     if (l == mg->levels - 1) return mg_smooth(mg, L, b, x0, x1, mg->nuCoarse, true, done, result, l == 0);
     MgLevel& C = mg->lv[l + 1];
     double* cur = nullptr;
-    // V(1,*) on one rank with a uniform diagonal and the row-pattern form: the first sweep x1 = omega (d0 b) is not stored;
-    // the residual pass forms x1[col] per gather and the prolongation forms x1[i] again when it adds the correction
+    // V(1,*) on one rank with a uniform diagonal: the first sweep x1 = omega (d0 b) is not stored; the residual pass forms x1[col] per
+    // gather (row-pattern form, or the row-tile kernel on plain CSR) and the prolongation forms x1[i] again when it adds the correction
     const bool linear = mg->interp == 1;
-    const bool fold = mg->nu == 1 && !mg->multi && !linear && L.dinvUniform && L.dcsr != nullptr && L.dcsr->usable && L.dcsr->patternId != nullptr &&
-                      tuning().noFold.load(std::memory_order_relaxed) == 0;
+    bool canScale = false;
+    if (L.dcsr != nullptr && L.dcsr->usable) canScale = L.dcsr->patternId != nullptr;
+    else {
+        SpmvArgs probe{}; probe.elements = L.elements; probe.columnIndeces = L.columnIndeces; probe.elementsCount = (int)L.nnz; probe.rowCount = (int)L.n;
+        canScale = spmv_takes_rowtile(probe, L.cfg);
+    }
+    const bool fold = mg->nu == 1 && !mg->multi && !linear && L.dinvUniform && canScale && tuning().noFold.load(std::memory_order_relaxed) == 0;
     if (fold) cur = x0;
     else if (!mg_smooth(mg, L, b, x0, x1, mg->nu, true, done, &cur)) return false;
     double* other = (cur == x0) ? x1 : x0;

@@ -184,3 +184,26 @@ def test_device_workers_under_thread_sanitizer(tmp_path):
     for n, phases in ((8, 4000), (1, 100), (3, 2000)):
         out = subprocess.run([str(exe), str(n), str(phases)], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0 and "ok 2" in out.stdout and "WARNING: ThreadSanitizer" not in out.stderr, out.stdout + out.stderr
+
+
+def test_required_bytes_of_the_vcycle():
+    """bench.py's second byte count: what must move as the library runs the cycle (no D^-1 array on constant-coefficient levels, the
+    prolongation rewrites the fine iterate, the folded first sweep), next to the SURVEY-formula count."""
+    import bench
+
+    def nnz(m):
+        return 7 * m**3 - 6 * m * m
+    n, N, Nc = 8, 512, 64
+    sweep = lambda m: 12 * nnz(m) + 4 * (m**3 + 1) + 24 * m**3     # noqa: E731
+    shell = 12 * nnz(n) + 4 * (N + 1) + 16 * N + 72 * N
+    v, s = bench.vcycle_required_bytes(n, 2, 1, 2, fold=False)
+    fine = 16 * N + (12 * nnz(n) + 4 * (N + 1) + 24 * N) + (8 * N + 8 * Nc) + (16 * N + 8 * Nc) + sweep(n)
+    coarse = 16 * Nc + sweep(4)
+    assert (v, s) == (fine + coarse, shell)
+    vf, _ = bench.vcycle_required_bytes(n, 2, 1, 2, fold=True)
+    assert v - vf == 16 * N + 8 * N                      # the first sweep's store, and the residual's separate read of x
+    v2, _ = bench.vcycle_required_bytes(n, 2, 2, 2, fold=True)
+    assert v2 == fine + coarse + 2 * sweep(n)            # V(2,2): nothing to fold, one more sweep either side
+    va, sa = bench.vcycle_bytes(512, 3, 1, 4)
+    vr, sr = bench.vcycle_required_bytes(512, 3, 1, 4)
+    assert sr == sa and vr < va
