@@ -54,6 +54,8 @@ struct Tuning {
     std::atomic<int> patternGroup{0}, patternWaves{16};    // MGCG_PATTERN_GROUP / MGCG_PATTERN_WAVES
     std::atomic<int> noIndexedHalo{0};       // MGCG_NO_INDEXED_HALO
     std::atomic<int> tileNt{0}, tileShift{0};              // MGCG_TILE_NT / MGCG_TILE_SHIFT (0: default 19)
+    std::atomic<int> tilePack{1};            // MGCG_TILE_PACK          column tiles with 12-byte entries (0: the 16-byte form)
+    std::atomic<int> autoTiles{1};           // MGCG_AUTO_TILES         Solve-family calls build the column tiles themselves for matrices without locality
     std::atomic<int> verbose{0};             // MGCG_VERBOSE            errors also go to stderr
     std::atomic<int> lazyCodeObjects{0};     // MGCG_LAZY_CODE_OBJECTS
     std::atomic<int> virtualDevices{0};      // MGCG_VIRTUAL_DEVICES    one physical GPU shown as n devices (tests)
@@ -123,7 +125,7 @@ struct Workspace {
     CgScalars* scalars = nullptr;    // device
     HostMirror* mirror = nullptr;    // pinned host, device-visible
     double* hostScalar = nullptr;    // pinned host, 4 doubles (Dot results)
-    int* devInts = nullptr;          // device, 4 ints (small integer results: far band, longest row)
+    int* devInts = nullptr;          // device, 8 ints (small integer results: far band, longest row, sampled distance; a 64-bit checksum in [4..5])
     double* trace = nullptr;         // device residual trace
     int traceCap = 0;
     bool init();
@@ -154,6 +156,13 @@ struct DcsrView {
     const int* tileCols;             // ... their column ids ...
     const int* tileRowIds;           // ... and (local) row ids
     const int* tileStartHost;        // HOST array [nTiles + 1]: first entry of every tile
+    // 12-byte entries (the default when the row ids fit): tilePacked[k] = column offset inside the tile (low tileShift bits) | row - base row
+    // of the entry's block of 1024 (high bits); tileHdr[b] = { base row, row of the entry in front of the block or -1 }, blocks numbered
+    // tile by tile from tileHdrBaseHost[t]; tileCols / tileRowIds are then not kept
+    const unsigned* tilePacked;
+    const int2* tileHdr;
+    const int* tileHdrBaseHost;      // HOST array [nTiles]: first header of the tile, or -1 for a tile that keeps 16-byte entries (its row ids do not fit)
+    int tileShift;
     int nTiles;
     long long tileRows;              // rows of the analysed matrix
 };
@@ -167,7 +176,10 @@ struct DcsrMatrix {
     unsigned char* patternId = nullptr; int* patCount = nullptr; int* patDelta = nullptr; double* patValue = nullptr;
     int nPattern = 0, patWidth = 0;
     double* tileVals = nullptr; int* tileCols = nullptr; int* tileRowIds = nullptr; int nTiles = 0; long long tileRows = 0;
-    std::vector<int> tileStart;
+    unsigned* tilePacked = nullptr; int2* tileHdr = nullptr; int tileShift = 0;
+    std::vector<int> tileStart, tileHdrBase;
+    unsigned long long checksum = 0;  // of the CSR arrays the analysis was made from (forms chosen without the caller asking are re-verified per solve)
+    bool automatic = false;           // built by the library's own choice (column tiles for a matrix without locality), not by MgcgSetMatrixCompression
     bool usable = false;
     std::atomic<bool> stale{false};   // a write through the library touched the arrays the analysis was made from: analyse again at the next use
     void release();
@@ -176,6 +188,7 @@ struct DcsrMatrix {
         DcsrView v; v.colCode = colCode; v.valCode = valCode; v.deltaDict = deltaDict; v.valueDict = valueDict; v.nDelta = nDelta; v.nValue = nValue; v.rowBase = rowBase;
         v.patternId = patternId; v.patCount = patCount; v.patDelta = patDelta; v.patValue = patValue; v.nPattern = nPattern; v.patWidth = patWidth;
         v.tileVals = tileVals; v.tileCols = tileCols; v.tileRowIds = tileRowIds; v.tileStartHost = tileStart.data(); v.nTiles = nTiles; v.tileRows = tileRows;
+        v.tilePacked = tilePacked; v.tileHdr = tileHdr; v.tileHdrBaseHost = tileHdrBase.data(); v.tileShift = tileShift;
         return v;
     }
 };
@@ -200,7 +213,7 @@ struct MgcgSparse {
     std::vector<mgcg::DcsrMatrix*> analysed;
     // far-band distance found per matrix (the tile order of the row-tile kernel; any value gives the same results, so a stale
     // entry can only cost locality): keyed by the array pointers and the row count
-    struct PeriodEntry { const int* rowOffsets; const int* columnIndeces; long long rows, rowBase; int period; int maxRow; };
+    struct PeriodEntry { const int* rowOffsets; const int* columnIndeces; long long rows, rowBase; int period; int maxRow; long long meanDistance; };
     std::vector<PeriodEntry> periods;
 };
 struct MgcgMatDescr { int type = 0; int base = 0; };
@@ -288,7 +301,7 @@ int launch_spmv_rowtile(hipStream_t s, int epilogue, const SpmvArgs& a, int peri
 // Distance (in rows) of the farthest band of the matrix, read off one row in the middle of the slice, and the longest row (one pass
 // over the row offsets; both remembered per handle -- stale values can only cost speed: any period gives the same results, and rows
 // longer than the remembered maximum take the kernel's slow path); the caller's hint (MgcgSetSpmvPeriod) wins for the period.
-int spmv_period(MgcgSparse* h, const int* rowOffsets, const int* columnIndeces, long long rows, long long rowBase, int* maxRow = nullptr);
+int spmv_period(MgcgSparse* h, const int* rowOffsets, const int* columnIndeces, long long rows, long long rowBase, int* maxRow = nullptr, long long* meanDistance = nullptr);
 void launch_matrix_shape(hipStream_t s, const int* rowOffsets, const int* columnIndeces, long long rows, long long row, long long rowBase, int* out2);
 // The same on the dictionary-compressed form of the matrix (a.elements / a.columnIndeces still serve array tails and long rows).
 int launch_spmv_rows(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView* m, int gridReq, int periodRows = 0);   // m == nullptr: plain CSR; periodRows: z sweep of the row-pattern kernel
@@ -304,7 +317,9 @@ bool tiled_build(hipStream_t s, const double* elements, const int* rowOffsets, c
 int launch_spmv_tiled(hipStream_t s, int epilogue, const SpmvArgs& a, const DcsrView& m);
 // Cached analysis of a matrix on a handle (nullptr: compression off, not applicable, or the build failed).
 const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* rowOffsets, const int* columnIndeces,
-                              long long rows, long long nnz, long long rowBase, long long columns = 0);   // columns: length of x (0: unknown, no column tiling)
+                              long long rows, long long nnz, long long rowBase, long long columns = 0,    // columns: length of x (0: unknown, no column tiling)
+                              long long autoMeanDistance = -1);   // >= 0: a Solve-family call; with compression off the library may still build column tiles for a matrix whose entries lie this far (on average) from the diagonal
+unsigned long long csr_checksum(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces, long long rows, long long nnz, unsigned long long* scratch);
 // Every export that writes device memory (or frees it) names the range here: analyses made from arrays it overlaps go stale
 // and are rebuilt at their next use (the reference re-uploads A into the same vectors on every Initialize():
 // Mgcg/cuBlas/Mgcg/ConjugateGradientSingleGpu.cs:134-147).  Costs one relaxed atomic load when nothing is analysed.

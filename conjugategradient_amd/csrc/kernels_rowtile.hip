@@ -203,9 +203,11 @@ __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, Tile
     finish();
 }
 
-// out[0] = distance of the farthest entry of row `row` from the diagonal, out[1] = longest row of the matrix (out zeroed by the caller)
+// out[0] = distance of the farthest entry of row `row` from the diagonal, out[1] = longest row of the matrix, out[2] / out[3] = sum of
+// |col - row| >> 16 and number of entries over a sample of ~8192 rows (how far from the diagonal the gathers reach)  (out zeroed by the caller)
 __global__ __launch_bounds__(kBlock) void matrix_shape_kernel(const int* __restrict__ rowOffsets, const int* __restrict__ columnIndeces, long long rows, long long row, long long rowBase, int* out)
 {
+    const long long sampleStride = rows > 8192 ? rows / 8192 : 1;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         long long far = 0;
         for (int k = rowOffsets[row]; k < rowOffsets[row + 1]; ++k) {
@@ -217,7 +219,14 @@ __global__ __launch_bounds__(kBlock) void matrix_shape_kernel(const int* __restr
     }
     int longest = 0;
     const long long stride = (long long)gridDim.x * kBlock;
-    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < rows; i += stride) { const int len = rowOffsets[i + 1] - rowOffsets[i]; longest = len > longest ? len : longest; }
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < rows; i += stride) {
+        const int len = rowOffsets[i + 1] - rowOffsets[i]; longest = len > longest ? len : longest;
+        if (i % sampleStride == 0 && len > 0 && len <= 4096) {
+            long long far = 0;
+            for (int k = rowOffsets[i]; k < rowOffsets[i + 1]; ++k) { long long d = (long long)columnIndeces[k] - (rowBase + i); far += (d < 0 ? -d : d) >> 16; }
+            atomicAdd(&out[2], (int)(far > 0x3fffffLL ? 0x3fffffLL : far)); atomicAdd(&out[3], len);
+        }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_down(longest, off, 64); longest = o > longest ? o : longest; }
     __shared__ int s_max[kBlock / 64];

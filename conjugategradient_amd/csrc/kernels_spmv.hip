@@ -509,7 +509,12 @@ static int launch_spmv_epi(hipStream_t s, const SpmvArgs& a, const SpmvConfig& c
 {
     int kernel = cfg.kernel;
     if (kernel == 0) {
-        kernel = spmv_auto_kernel(a.rowCount > 0 ? (double)a.elementsCount / (double)a.rowCount : 0.0);
+        const double avg = a.rowCount > 0 ? (double)a.elementsCount / (double)a.rowCount : 0.0;
+        kernel = spmv_auto_kernel(avg);
+        // gathers without locality (flag 16: the sampled entries lie beyond an L2's reach of the diagonal, x far larger than an L2): the
+        // product is bound by the gathers, not by the row shape, and the row-block stream form -- bit-identical to the oracle, unlike the
+        // lanes-per-row forms -- is the faster CSR kernel there (10 M-row random matrix: 5.77 ms against 6.08-6.31, profiles/r3/config5_*)
+        if ((cfg.flags & 16) != 0 && kernel >= 5 && kernel <= 7 && avg <= 64.0) kernel = 1;
     }
     if (kernel == 10) {     // row-tile kernel (four wavefronts per tile of 256 rows); 16-byte aligned arrays
         const bool ok = (((uintptr_t)a.elements & 15) == 0) && (((uintptr_t)a.columnIndeces & 15) == 0) && a.elementsCount >= 8;

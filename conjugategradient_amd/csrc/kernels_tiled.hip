@@ -179,6 +179,86 @@ __global__ __launch_bounds__(kBlock) void spmv_tile_pass_kernel(const double* __
     }
 }
 
+// The same pass on 12-byte entries (value + one packed word: column offset inside the tile | row - base row of the entry's block of
+// kTilePack entries; hdr[b] = { base row, row of the entry in front of the block or -1 }).  What conjugategradient_amd/tools/tile_lab.hip
+// measured on a 10 M-row matrix of config 5's shape (profiles/r3/tile_lab_*.log): the three kinds of traffic of the 16-byte pass do not
+// overlap -- entry streams 0.94 ms + gathers beyond L1 1.6 ms + y read-modify-write 0.6 ms = the 3.2 ms of the whole -- so the bytes of
+// the entry stream are time: 12-byte entries with non-temporal loads 2.57 ms (16-byte: 3.23; plain loads 2.71; 8 / 16 entries per thread
+// 2.66 / 3.29; y requested before the gathers 2.70; a persistent loop with the next block prefetched 3.09; tiles of 2^18 / 2^20 columns
+// 2.66 / 3.59).  Bit-identical to the 16-byte pass and to the CSR kernels.
+constexpr int kTilePack = kBlock * kTileE;     // entries per block header
+
+__global__ __launch_bounds__(kBlock) void spmv_tile_pass_packed_kernel(const double* __restrict__ x, double* __restrict__ y,
+                                                                       const double* __restrict__ tVals, const unsigned* __restrict__ tPacked, const int2* __restrict__ hdr,
+                                                                       int hdrBase, int kBegin, int kEnd, int tileCol0, int shift, const int* __restrict__ doneFlag)
+{
+    __shared__ double s_p[kTilePack];
+    __shared__ int s_r[kTilePack + 1];                              // s_r[j + 1] = row of entry j of the block, s_r[0] = row of the entry in front of it
+    if (doneFlag != nullptr && *doneFlag != 0) return;
+    const int blockBase = kBegin + (int)blockIdx.x * kTilePack;
+    const int blockCount = (kEnd - blockBase) < kTilePack ? (kEnd - blockBase) : kTilePack;
+    const int2 h = hdr[hdrBase + blockIdx.x];
+    const unsigned colMask = (1u << shift) - 1u;
+    double v[kTileE]; unsigned pk[kTileE]; int r[kTileE];
+#pragma unroll
+    for (int e = 0; e < kTileE; ++e) {
+        const int j = e * kBlock + (int)threadIdx.x;
+        const int k = blockBase + (j < blockCount ? j : 0);
+        v[e] = __builtin_nontemporal_load(tVals + k); pk[e] = __builtin_nontemporal_load(tPacked + k);
+    }
+#pragma unroll
+    for (int e = 0; e < kTileE; ++e) {
+        const int j = e * kBlock + (int)threadIdx.x;
+        r[e] = h.x + (int)(pk[e] >> shift);
+        s_r[j + 1] = j < blockCount ? r[e] : -2;
+    }
+    if (threadIdx.x == 0) s_r[0] = h.y;
+    double xv[kTileE];
+#pragma unroll
+    for (int e = 0; e < kTileE; ++e) xv[e] = x[tileCol0 + (int)(pk[e] & colMask)];
+#pragma unroll
+    for (int e = 0; e < kTileE; ++e) { const int j = e * kBlock + (int)threadIdx.x; s_p[j] = v[e] * xv[e]; }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < kTileE; ++e) {
+        const int j0 = e * kBlock + (int)threadIdx.x;
+        if (j0 >= blockCount || s_r[j0] == r[e]) continue;           // not the first entry of its (row, tile) segment
+        const int row = r[e];
+        double acc = y[row];
+        int j = j0;
+        while (j < blockCount && s_r[j + 1] == row) { acc += s_p[j]; ++j; }
+        if (j == blockCount) {                                      // the segment runs on into the next block's entries
+            for (int kk = blockBase + blockCount; kk < kEnd; ++kk) {
+                const int2 hn = hdr[hdrBase + (kk - kBegin) / kTilePack];
+                const unsigned p = tPacked[kk];
+                if (hn.x + (int)(p >> shift) != row) break;
+                const double q = tVals[kk] * x[tileCol0 + (int)(p & colMask)]; acc += q;
+            }
+        }
+        y[row] = acc;
+    }
+}
+
+// hdr and packed words of one tile's entries [kBegin, kEnd); *overflow is raised when a row id does not fit the packed word
+__global__ __launch_bounds__(kBlock) void tiled_pack_kernel(const int* __restrict__ tCols, const int* __restrict__ tRows, int kBegin, int kEnd, int shift,
+                                                            unsigned* __restrict__ tPacked, int2* __restrict__ hdr, int hdrBase, int* __restrict__ overflow)
+{
+    const int nBlocks = (kEnd - kBegin + kTilePack - 1) / kTilePack;
+    const unsigned colMask = (1u << shift) - 1u;
+    const int rowLimit = (shift >= 31) ? 1 : (int)((1u << (32 - shift)) - 1u);
+    for (int b = blockIdx.x; b < nBlocks; b += gridDim.x) {
+        const int base = kBegin + b * kTilePack;
+        const int end = base + kTilePack < kEnd ? base + kTilePack : kEnd;
+        const int baseRow = tRows[base];
+        if (threadIdx.x == 0) { int2 h; h.x = baseRow; h.y = base > kBegin ? tRows[base - 1] : -1; hdr[hdrBase + b] = h; }
+        for (int k = base + (int)threadIdx.x; k < end; k += kBlock) {
+            const int lr = tRows[k] - baseRow;
+            if (lr < 0 || lr > rowLimit) { *overflow = 1; continue; }
+            tPacked[k] = ((unsigned)lr << shift) | ((unsigned)tCols[k] & colMask);
+        }
+    }
+}
+
 // y[i] = epilogue(row sum y[i])  (+ partial sums of the fused dot product)
 template <int EPI>
 __global__ __launch_bounds__(kBlock) void tiled_epilogue_kernel(SpmvArgs a)
@@ -222,6 +302,11 @@ static int launch_tiled_epi(hipStream_t s, const SpmvArgs& a, const DcsrView& m)
         const int kb = m.tileStartHost[t], ke = m.tileStartHost[t + 1];
         if (ke <= kb) continue;
         const dim3 g((ke - kb + kBlock * kTileE - 1) / (kBlock * kTileE));
+        if (m.tilePacked != nullptr && m.tileHdrBaseHost[t] >= 0) {
+            hipLaunchKernelGGL(spmv_tile_pass_packed_kernel, g, dim3(kBlock), 0, s, a.x, a.y, m.tileVals, m.tilePacked, m.tileHdr, m.tileHdrBaseHost[t], kb, ke,
+                               (int)((long long)t << m.tileShift), m.tileShift, a.doneFlag);
+            continue;
+        }
         if (tile_streams_nontemporal()) hipLaunchKernelGGL(spmv_tile_pass_kernel<true>, g, dim3(kBlock), 0, s, a.x, a.y, m.tileVals, m.tileCols, m.tileRowIds, kb, ke, a.doneFlag);
         else hipLaunchKernelGGL(spmv_tile_pass_kernel<false>, g, dim3(kBlock), 0, s, a.x, a.y, m.tileVals, m.tileCols, m.tileRowIds, kb, ke, a.doneFlag);
     }
@@ -306,8 +391,69 @@ bool tiled_build(hipStream_t s, const double* elements, const int* rowOffsets, c
     if (!ok) return fail(true);
     if ((long long)starts[(size_t)nTiles] != nnz) { set_error("tiled analysis: %d of %lld nonzeros placed", starts[(size_t)nTiles], nnz); return fail(true); }
     (void)hipFree(stats); (void)hipFree(counts);
-    out->tileVals = tv; out->tileCols = tc; out->tileRowIds = tr; out->nTiles = nTiles; out->tileRows = rows; out->tileStart = starts;
+    out->tileVals = tv; out->tileCols = tc; out->tileRowIds = tr; out->nTiles = nTiles; out->tileRows = rows; out->tileStart = starts; out->tileShift = tileShift;
+    // 12-byte entries: one packed word instead of column id + row id, when every row id fits next to the column offset (else the
+    // 16-byte form above stays); MGCG_TILE_PACK=0 keeps the 16-byte form (A/B)
+    if (tuning().tilePack.load(std::memory_order_relaxed) != 0 && tileShift <= 24) {
+        std::vector<int> hdrBase((size_t)nTiles, 0);
+        long long nHdr = 0;
+        for (int t = 0; t < nTiles; ++t) { hdrBase[(size_t)t] = (int)nHdr; nHdr += ((long long)starts[(size_t)t + 1] - starts[(size_t)t] + kTilePack - 1) / kTilePack; }
+        unsigned* tp = nullptr; int2* th = nullptr; int* ovf = nullptr;
+        std::vector<int> hovf((size_t)nTiles, 0);
+        bool pok = MGCG_HIP(hipMalloc((void**)&tp, sizeof(unsigned) * (size_t)nnz)) && MGCG_HIP(hipMalloc((void**)&th, sizeof(int2) * (size_t)(nHdr + 1))) &&
+                   MGCG_HIP(hipMalloc((void**)&ovf, sizeof(int) * (size_t)nTiles)) && MGCG_HIP(hipMemsetAsync(ovf, 0, sizeof(int) * (size_t)nTiles, s));
+        for (int t = 0; pok && t < nTiles; ++t) {
+            const int kb = starts[(size_t)t], ke = starts[(size_t)t + 1];
+            if (ke <= kb) continue;
+            const long long nb = ((long long)ke - kb + kTilePack - 1) / kTilePack;
+            hipLaunchKernelGGL(tiled_pack_kernel, dim3((unsigned)(nb > kMaxGrid ? kMaxGrid : nb)), dim3(kBlock), 0, s, tc, tr, kb, ke, tileShift, tp, th, hdrBase[(size_t)t], ovf + t);
+        }
+        pok = pok && MGCG_HIP(hipGetLastError()) && MGCG_HIP(hipMemcpyAsync(hovf.data(), ovf, sizeof(int) * (size_t)nTiles, hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
+        if (ovf) (void)hipFree(ovf);
+        if (pok) {
+            // a tile whose entries are so sparse that 1024 of them span more rows than the packed word can name (the narrow last tile of a
+            // column range that is not a multiple of the tile width) keeps its 16-byte entries; the arrays they live in stay in that case
+            bool all = true;
+            for (int t = 0; t < nTiles; ++t) if (hovf[(size_t)t] != 0) { hdrBase[(size_t)t] = -1; all = false; }
+            out->tilePacked = tp; out->tileHdr = th; out->tileHdrBase = hdrBase;
+            if (all) { (void)hipFree(tc); (void)hipFree(tr); out->tileCols = nullptr; out->tileRowIds = nullptr; }     // the packed words carry both
+        } else {
+            if (tp) (void)hipFree(tp);
+            if (th) (void)hipFree(th);
+            (void)hipGetLastError();
+        }
+    }
     return true;
+}
+
+// 64-bit checksum of a CSR matrix (position-weighted sums of the bit patterns of the three arrays; the order of the additions does not
+// matter): forms the library built without being asked are re-verified with it before every solve.
+__global__ __launch_bounds__(kBlock) void csr_checksum_kernel(const double* __restrict__ elements, const int* __restrict__ rowOffsets, const int* __restrict__ columnIndeces,
+                                                              long long rows, long long nnz, unsigned long long* __restrict__ out)
+{
+    unsigned long long acc = 0;
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long k = (long long)blockIdx.x * kBlock + threadIdx.x; k < nnz; k += stride) {
+        const unsigned long long w = 2ull * (unsigned long long)k + 1ull;
+        acc += (unsigned long long)__double_as_longlong(__builtin_nontemporal_load(elements + k)) * w;
+        acc += ((unsigned long long)(unsigned)__builtin_nontemporal_load(columnIndeces + k) + 0x9E3779B97F4A7C15ull) * (w * 0xBF58476D1CE4E5B9ull);
+    }
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i <= rows; i += stride)
+        acc += ((unsigned long long)(unsigned)rowOffsets[i] + 0x94D049BB133111EBull) * (2ull * (unsigned long long)i + 0x632BE59BD9B4E019ull);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+unsigned long long csr_checksum(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces, long long rows, long long nnz, unsigned long long* scratch)
+{
+    unsigned long long v = 0;
+    if (!MGCG_HIP(hipMemsetAsync(scratch, 0, sizeof(unsigned long long), s))) return 0;
+    long long blocks = (nnz + kBlock - 1) / kBlock;
+    if (blocks > kMaxGrid) blocks = kMaxGrid;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(csr_checksum_kernel, dim3((int)blocks), dim3(kBlock), 0, s, elements, rowOffsets, columnIndeces, rows, nnz, scratch);
+    if (!MGCG_HIP(hipGetLastError()) || !MGCG_HIP(hipMemcpyAsync(&v, scratch, sizeof(v), hipMemcpyDeviceToHost, s)) || !MGCG_HIP(hipStreamSynchronize(s))) return 0;
+    return v | 1ull;                                                // never 0: 0 says "no checksum"
 }
 
 void preload_kernels_tiled() { preload_code_object(reinterpret_cast<const void*>(&scan_totals_kernel)); }

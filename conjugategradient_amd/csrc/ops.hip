@@ -20,7 +20,9 @@ static SpmvConfig cfg_of(const MgcgSparse* h)
 static SpmvConfig cfg_for(MgcgSparse* h, const SpmvArgs& a, long long rowBase)
 {
     SpmvConfig c = cfg_of(h);
-    if (a.elementsCount >= 8) c.periodRows = spmv_period(h, a.rowOffsets, a.columnIndeces, a.rowCount, rowBase, &c.maxRow);
+    long long meanDistance = 0;
+    if (a.elementsCount >= 8) c.periodRows = spmv_period(h, a.rowOffsets, a.columnIndeces, a.rowCount, rowBase, &c.maxRow, &meanDistance);
+    if (meanDistance >= (1LL << 19) && a.columnCount >= (8LL << 19)) c.flags |= 16;     // gathers without locality (kernels_spmv.hip: launch_spmv_epi)
     return c;
 }
 

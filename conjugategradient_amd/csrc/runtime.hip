@@ -38,6 +38,8 @@ const Knob kKnobs[] = {
     { "MGCG_NO_INDEXED_HALO", "no_indexed_halo", &Tuning::noIndexedHalo, 0, true },
     { "MGCG_TILE_NT", "tile_nt", &Tuning::tileNt, 0, false },
     { "MGCG_TILE_SHIFT", "tile_shift", &Tuning::tileShift, 0, false },
+    { "MGCG_TILE_PACK", "tile_pack", &Tuning::tilePack, 1, false },
+    { "MGCG_AUTO_TILES", "auto_tiles", &Tuning::autoTiles, 1, false },
     { "MGCG_VERBOSE", "verbose", &Tuning::verbose, 0, false },
     { "MGCG_LAZY_CODE_OBJECTS", "lazy_code_objects", &Tuning::lazyCodeObjects, 0, true },
     { "MGCG_VIRTUAL_DEVICES", "virtual_devices", &Tuning::virtualDevices, 0, false },
@@ -131,7 +133,7 @@ bool Workspace::init()
     if (!MGCG_HIP(hipHostMalloc((void**)&mirror, sizeof(HostMirror), hipHostMallocMapped))) return false;
     memset((void*)mirror, 0, sizeof(HostMirror));
     if (!MGCG_HIP(hipHostMalloc((void**)&hostScalar, sizeof(double) * 4, hipHostMallocMapped))) return false;
-    if (!MGCG_HIP(hipMalloc((void**)&devInts, sizeof(int) * 4))) return false;
+    if (!MGCG_HIP(hipMalloc((void**)&devInts, sizeof(int) * 8))) return false;
     return true;
 }
 void Workspace::destroy()
@@ -186,13 +188,28 @@ void analysis_note_write(const void* p, size_t bytes)
 }
 
 const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* rowOffsets, const int* columnIndeces,
-                              long long rows, long long nnz, long long rowBase, long long columns)
+                              long long rows, long long nnz, long long rowBase, long long columns, long long autoMeanDistance)
 {
-    if (!h || h->compression == 0) return nullptr;
+    if (!h) return nullptr;
+    // The library's own choice (compression off, a Solve-family call): column tiles for a large matrix whose gathers have no locality --
+    // x far beyond one L2 and the sampled entries a tile width or more from the diagonal (BASELINE config 5: 2.6 ms per product instead of
+    // 5.7-6.1).  The form is lossless and bit-identical; because the caller did not ask for a cache keyed by pointers, the CSR arrays are
+    // re-verified by checksum at every solve (one streaming read: 0.8 ms for 310 M nonzeros) and the form is rebuilt when they changed.
+    const bool automatic = h->compression == 0;
+    if (automatic) {
+        const long long tileCols = 1LL << 19;
+        if (autoMeanDistance < tileCols || columns < 8 * tileCols || nnz < (4LL << 20) || rows <= 0 || nnz > 48 * rows ||
+            tuning().autoTiles.load(std::memory_order_relaxed) == 0 || tuning().tileShift.load(std::memory_order_relaxed) != 0) return nullptr;
+    }
     DcsrMatrix* m = nullptr;
     for (DcsrMatrix* q : h->analysed)
-        if (q->elements == elements && q->rowOffsets == rowOffsets && q->columnIndeces == columnIndeces && q->rows == rows && q->nnz == nnz && q->rowBase == rowBase) {
-            if (!q->stale.load(std::memory_order_acquire)) return q->usable ? q : nullptr;
+        if (q->elements == elements && q->rowOffsets == rowOffsets && q->columnIndeces == columnIndeces && q->rows == rows && q->nnz == nnz && q->rowBase == rowBase &&
+            q->automatic == automatic) {                    // (forms the caller asked for and the library's own choice are separate entries)
+            if (!q->stale.load(std::memory_order_acquire)) {
+                if (!q->automatic) return q->usable ? q : nullptr;
+                if (!q->usable) return nullptr;
+                if (csr_checksum(h->ws.stream, elements, rowOffsets, columnIndeces, rows, nnz, (unsigned long long*)(h->ws.devInts + 4)) == q->checksum) return q;
+            }
             m = q;                                          // written to since: same slot, new analysis
             break;
         }
@@ -215,6 +232,12 @@ const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* 
         h->analysed.push_back(m);
         registry_add(m);
     }
+    m->automatic = automatic;
+    if (automatic) {
+        m->checksum = csr_checksum(h->ws.stream, elements, rowOffsets, columnIndeces, rows, nnz, (unsigned long long*)(h->ws.devInts + 4));
+        if (tiled_build(h->ws.stream, elements, rowOffsets, columnIndeces, rows, nnz, rowBase, columns, m) && m->tileVals != nullptr) m->usable = true;
+        return m->usable ? m : nullptr;
+    }
     // 1. one byte per row (few distinct rows-as-sequences), 2. one or two bytes per nonzero (few distinct offsets / values;
     //    the wide loads of that kernel need 16-byte aligned values and short average rows: one pass per 64-row block)
     // 3. a column-tiled copy for matrices whose gathers have no locality (sorted rows, entries far from the diagonal)
@@ -230,24 +253,28 @@ const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* 
     return m->usable ? m : nullptr;
 }
 
-int spmv_period(MgcgSparse* h, const int* rowOffsets, const int* columnIndeces, long long rows, long long rowBase, int* maxRow)
+int spmv_period(MgcgSparse* h, const int* rowOffsets, const int* columnIndeces, long long rows, long long rowBase, int* maxRow, long long* meanDistance)
 {
     if (maxRow) *maxRow = 0;
+    if (meanDistance) *meanDistance = 0;
     if (!h || rows < 4096) return h ? h->periodRows : 0;
     for (const auto& e : h->periods)
         if (e.rowOffsets == rowOffsets && e.columnIndeces == columnIndeces && e.rows == rows && e.rowBase == rowBase) {
             if (maxRow) *maxRow = e.maxRow;
+            if (meanDistance) *meanDistance = e.meanDistance;
             return h->periodRows > 0 ? h->periodRows : e.period;
         }
     int period = 0, longest = 0;
-    int got[2] = { 0, 0 };
-    bool ok = MGCG_HIP(hipMemsetAsync(h->ws.devInts, 0, 2 * sizeof(int), h->ws.stream));
+    long long mean = 0;
+    int got[4] = { 0, 0, 0, 0 };
+    bool ok = MGCG_HIP(hipMemsetAsync(h->ws.devInts, 0, 4 * sizeof(int), h->ws.stream));
     if (ok) launch_matrix_shape(h->ws.stream, rowOffsets, columnIndeces, rows, rows / 2, rowBase, h->ws.devInts);
     ok = ok && MGCG_HIP(hipGetLastError()) && MGCG_HIP(hipMemcpyAsync(got, h->ws.devInts, sizeof(got), hipMemcpyDeviceToHost, h->ws.stream)) && MGCG_HIP(hipStreamSynchronize(h->ws.stream));
-    if (ok) { period = got[0]; longest = got[1]; }
+    if (ok) { period = got[0]; longest = got[1]; mean = got[3] > 0 ? (((long long)got[2] << 16) / got[3]) : 0; }
     if (h->periods.size() >= 64) h->periods.clear();
-    h->periods.push_back({ rowOffsets, columnIndeces, rows, rowBase, period, longest });
+    h->periods.push_back({ rowOffsets, columnIndeces, rows, rowBase, period, longest, mean });
     if (maxRow) *maxRow = longest;
+    if (meanDistance) *meanDistance = mean;
     return h->periodRows > 0 ? h->periodRows : period;
 }
 

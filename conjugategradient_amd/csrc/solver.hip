@@ -311,8 +311,10 @@ __global__ void clear_done_kernel(CgScalars* sc) { sc->done = 0; sc->status = 0;
 static bool cg_enqueue_init(CgRun& R)
 {
     hipStream_t s = R.ws->stream;
-    if (R.cusparse) R.dcsr = dcsr_lookup(R.cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset, R.count);
-    if (R.cusparse && R.elementsCount >= 8) R.cfg.periodRows = spmv_period(R.cusparse, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.cfg.maxRow);
+    long long meanDistance = 0;
+    if (R.cusparse && R.elementsCount >= 8) R.cfg.periodRows = spmv_period(R.cusparse, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.cfg.maxRow, &meanDistance);
+    if (R.cusparse) R.dcsr = dcsr_lookup(R.cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset, R.count, R.mg ? -1 : meanDistance);
+    if (meanDistance >= (1LL << 19) && R.count >= (8LL << 19)) R.cfg.flags |= 16;      // gathers without locality: the stream form among the CSR kernels
     if (!R.mg) R.cfg.flags |= 8;                 // plain CG loop: the row-tile kernel may read the matrix with the non-temporal hint (kernels_rowtile.hip)
     CgScalars* sc = R.ws->scalars;
     double* pLoc = R.p + R.offset;
@@ -609,8 +611,10 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     R.ws->trace = nullptr; R.ws->traceCap = 0;
     bool ok = true;
     if (R.multi) { R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, R.columnIndeces, R.elementsCount); ok = R.halo != nullptr && cg_plan_overlap(R); }
-    R.dcsr = dcsr_lookup(cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset, R.count);
-    if (R.elementsCount >= 8) R.cfg.periodRows = spmv_period(cusparse, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.cfg.maxRow);
+    long long meanDistance = 0;
+    if (R.elementsCount >= 8) R.cfg.periodRows = spmv_period(cusparse, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.cfg.maxRow, &meanDistance);
+    R.dcsr = dcsr_lookup(cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset, R.count, meanDistance);
+    if (meanDistance >= (1LL << 19) && R.count >= (8LL << 19)) R.cfg.flags |= 16;
     R.cfg.flags |= 8;
     R.noFoldedFinalize = tuning().noFoldedFinalize.load(std::memory_order_relaxed) != 0;
     R.haloOnSide = tuning().haloStream.load(std::memory_order_relaxed) != 0;

@@ -239,10 +239,35 @@ def test_config5_at_full_size(oracle):
     L.MgcgFill(dx.Ptr, 1.0)
     L.CsrMV(*args(dx))
     assert np.abs(dy.to_numpy() - 1.0).max() <= 1e-12       # row sums: 1 + sum|off| - sum|off|
+    # the solve: with compression OFF the library builds the column tiles of this matrix itself (its sampled entries lie 3 M columns from
+    # the diagonal on average, x is 80 MB) -- class 4 with 12-byte entries, re-verified by checksum at every solve
+    assert L.MgcgAnalysisInfo(cg.cusparse, 0, None, None, None, None) == -1
     cg.Solve()
     cg.Read()
+    assert L.MgcgAnalysisInfo(cg.cusparse, 0, None, None, None, None) == 4
     assert 20 < cg.Iteration < 1000 and cg.Residual < 1e-8
     assert np.abs(cg.x - (xs + 2.0)).max() <= 1e-7
+    it_tiles, res_tiles, x_tiles = cg.Iteration, cg.Residual, cg.x.copy()
+    # the same solve on the CSR kernels (auto_tiles off; 16 lanes per row at this row length, whose sums differ from the stored-order
+    # sums of the tiles in the last bits): same iteration count, same answer to round-off
+    assert L.MgcgSetTuning(b"auto_tiles", 0) == 0
+    cg.x[:] = 0.0
+    cg.vectorX.CopyFrom(cg.x, N)
+    cg.Solve()
+    cg.Read()
+    L.MgcgSetTuning(b"auto_tiles", 1)
+    assert abs(cg.Iteration - it_tiles) <= 1 and np.abs(cg.x - x_tiles).max() <= 1e-8
+    # a second solve finds the cached form (checksum verified); after the matrix values changed it is rebuilt, not reused:
+    # A -> 2 A through Scal on the raw pointer of the values (the solution halves)
+    L.Scal(cg.cublas, cg.vectorA.ToRawPtr(), 2.0, nnz)
+    cg.x[:] = 0.0
+    cg.vectorX.CopyFrom(cg.x, N)
+    cg.Solve()
+    cg.Read()
+    assert np.abs(cg.x - 0.5 * (xs + 2.0)).max() <= 1e-7
+    L.Scal(cg.cublas, cg.vectorA.ToRawPtr(), 0.5, nnz)
+    cg.x[:] = x_tiles
+    cg.vectorX.CopyFrom(cg.x, N)
     L.Copy(cg.cublas, dx.ToRawPtr(), cg.vectorX.ToRawPtr(), N, 0, 0)
     L.CsrMV(*args(dx))
     r = cg.b - dy.to_numpy()
