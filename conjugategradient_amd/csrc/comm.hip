@@ -17,6 +17,7 @@ static const ncclDataType_t NCCL_DOUBLE = ncclDouble;
 static const ncclDataType_t NCCL_INT32 = ncclInt32;
 static const ncclRedOp_t NCCL_SUM = ncclSum;
 
+struct HaloPlan;
 struct Rccl {
     void* lib = nullptr;
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
@@ -98,8 +99,13 @@ struct MgcgComm {
     // callback transport (host-staged; MgcgCommInitCallbacks)
     MgcgAllGatherFn cbAllGather = nullptr; MgcgAllReduceFn cbAllReduce = nullptr; MgcgExchangeFn cbExchange = nullptr; void* cbUser = nullptr;
     std::vector<std::vector<double>> cbSend, cbRecv;
-    hipStream_t haloStream = nullptr;                 // side stream: interior rows run here while the halo travels on `stream`
+    hipStream_t haloStream = nullptr;                 // side stream of the overlap schedule
     hipEvent_t evReady = nullptr, evHalo = nullptr;
+    // The contiguous-range plan of the last SolveParallel / CgSteps on this communicator, reused when EVERY rank calls again with the same
+    // partition (agreed in one 8-byte all-reduce): rebuilding it costs an all-gather with two stream synchronisations, inside the timed
+    // solve.  Index-list plans depend on the column ids themselves and are rebuilt every time.
+    mgcg::HaloPlan* cachedPlan = nullptr;
+    long long cachedKey[5] = { -1, -1, -1, -1, -1 };  // count, offset, countLocal, minJ, maxJ
 };
 
 namespace mgcg {
@@ -154,6 +160,7 @@ struct HaloPlan {
     // instead of one contiguous range.  The lists of all peers are concatenated (peer q's part starts at sendAt[q] / recvAt[q]);
     // pack gathers p[sendIdx] into sendBuf, unpack scatters recvBuf into p[recvIdx].
     bool indexed = false;
+    bool cached = false;             // owned by the communicator's cache: halo_plan_destroy leaves it alone
     std::vector<long long> sendAt, recvAt;
     int* sendIdx = nullptr; int* recvIdx = nullptr;
     double* sendBuf = nullptr; double* recvBuf = nullptr;
@@ -240,7 +247,7 @@ static bool halo_plan_index(MgcgComm* c, HaloPlan* h, const std::vector<long lon
                             const int* columnIndeces, long long nnz);
 
 HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long long countLocal, int minJ, int maxJ,
-                           const int* columnIndeces, long long nnz)
+                           const int* columnIndeces, long long nnz, bool reuse)
 {
     HaloPlan* h = new HaloPlan();
     if (c && c->nranks == 1 && comm_multi(c) && countLocal > 0) {
@@ -253,6 +260,18 @@ HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long 
     if (!c || c->nranks == 1) return h;
     const int n = c->nranks;
     h->nranks = n;
+    if (reuse) {   // the same partition as last time on every rank?  (collective: one all-reduce of "mine changed")
+        const long long key[5] = { count, offset, countLocal, (long long)minJ, (long long)maxJ };
+        const bool same = c->cachedPlan != nullptr && memcmp(key, c->cachedKey, sizeof(key)) == 0;
+        double changed = same ? 0.0 : 1.0;
+        bool ok = MGCG_HIP(hipMemcpyAsync(c->scratch, &changed, sizeof(double), hipMemcpyHostToDevice, c->stream)) && MGCG_HIP(hipStreamSynchronize(c->stream));
+        ok = comm_allreduce_sum(c, c->scratch, 1, c->stream) && ok;
+        ok = ok && MGCG_HIP(hipMemcpyAsync(&changed, c->scratch, sizeof(double), hipMemcpyDeviceToHost, c->stream)) && MGCG_HIP(hipStreamSynchronize(c->stream));
+        if (!ok) { delete h; return nullptr; }
+        if (changed == 0.0) { delete h; return c->cachedPlan; }
+        if (c->cachedPlan) { c->cachedPlan->cached = false; halo_plan_destroy(c->cachedPlan); c->cachedPlan = nullptr; }
+        memcpy(c->cachedKey, key, sizeof(key));
+    }
     // all-gather (offset, count, minJ, maxJ) of every rank
     std::vector<long long> all(4 * (size_t)n);
     if (c->loop) {
@@ -305,6 +324,9 @@ HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long 
     if (wide && !noIndex && columnIndeces != nullptr && count < 0x7fffffffLL) {
         if (!halo_plan_index(c, h, all, count, offset, countLocal, columnIndeces, nnz)) { halo_plan_destroy(h); return nullptr; }
     }
+    // contiguous ranges are a function of the table every rank has just agreed on: keep them; `wide` is the same on every rank (same
+    // table), so every rank caches or none does
+    if (reuse && !wide) { h->cached = true; c->cachedPlan = h; }
     return h;
 }
 
@@ -386,7 +408,7 @@ static bool halo_plan_index(MgcgComm* c, HaloPlan* h, const std::vector<long lon
 
 void halo_plan_destroy(HaloPlan* h)
 {
-    if (!h) return;
+    if (!h || h->cached) return;
     if (h->sendIdx) (void)hipFree(h->sendIdx);
     if (h->recvIdx) (void)hipFree(h->recvIdx);
     if (h->sendBuf) (void)hipFree(h->sendBuf);
@@ -682,6 +704,7 @@ MgcgComm* MgcgCommInitCallbacks(int nranks, int rank, MgcgAllGatherFn allGather,
 void MgcgCommDestroy(MgcgComm* c)
 {
     if (!c) return;
+    if (c->cachedPlan) { c->cachedPlan->cached = false; halo_plan_destroy(c->cachedPlan); c->cachedPlan = nullptr; }
     if (c->comm) { Rccl* r = rccl(); if (r && r->CommDestroy) (void)r->CommDestroy(c->comm); }
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->evReady) (void)hipEventDestroy(c->evReady);

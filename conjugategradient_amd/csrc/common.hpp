@@ -409,8 +409,10 @@ bool comm_multi(const MgcgComm* c);   // several ranks, or one rank forced onto 
 struct HaloPlan;  // per-peer contiguous send/recv ranges of p
 // columnIndeces / nnz (device; may be null): when the slice is unstructured (the contiguous ranges come to a quarter of the vector or
 // more) the plan is rebuilt from the column ids actually referenced -- per-peer index lists, packed and unpacked around the exchange.
+// reuse: the plan of a solve's own vector p -- kept on the communicator and handed out again while every rank calls with the same partition
+// (one 8-byte all-reduce decides); such a plan is not freed by halo_plan_destroy.  Plans of multigrid levels are never shared.
 HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long long countLocal, int minJ, int maxJ,
-                           const int* columnIndeces = nullptr, long long nnz = 0);
+                           const int* columnIndeces = nullptr, long long nnz = 0, bool reuse = false);
 void halo_last(long long out[3]);   // calling thread's last exchange: {index lists used, entries received, entries the contiguous plan receives}
 void halo_plan_destroy(HaloPlan* h);
 bool halo_exchange(MgcgComm* c, HaloPlan* h, double* p, hipStream_t s);

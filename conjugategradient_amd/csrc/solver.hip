@@ -69,8 +69,9 @@ static SpmvConfig cfg_of(const MgcgSparse* h)
 
 // Can the halo of a row slice hide behind its interior rows?  (several ranks, most rows reference local columns only).
 // MGCG_OVERLAP: 0 off, 1 (default) when it pays, 2 whenever an interior exists (tests).
+// d2: two device ints of the caller's workspace (Workspace::devInts + 6)
 static bool plan_overlap(hipStream_t s, MgcgComm* comm, bool multi, const int* rowOffsets, const int* columnIndeces,
-                         long long n, long long offset, bool* active, long long* i0, long long* i1)
+                         long long n, long long offset, bool* active, long long* i0, long long* i1, int* d2)
 {
     *active = false; *i0 = 0; *i1 = 0;
     const int mode = tuning().overlap.load(std::memory_order_relaxed);
@@ -85,13 +86,10 @@ static bool plan_overlap(hipStream_t s, MgcgComm* comm, bool multi, const int* r
         if (n >= 4 * w && w > 0 && halo_overlap_available(comm)) { *active = true; *i0 = w; *i1 = n - w; }
         return true;
     }
-    int* d2 = nullptr;
-    if (!MGCG_HIP(hipMalloc((void**)&d2, 2 * sizeof(int)))) return false;
     int h2[2] = { 0, (int)n };
     bool ok = MGCG_HIP(hipMemcpyAsync(d2, h2, sizeof(h2), hipMemcpyHostToDevice, s));
     if (ok) launch_halo_rows(s, rowOffsets, columnIndeces, n, offset, d2);
     ok = ok && MGCG_HIP(hipMemcpyAsync(h2, d2, sizeof(h2), hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
-    (void)hipFree(d2);
     if (!ok) return false;
     const long long lo = h2[0], hi = h2[1] < n ? h2[1] : n;
     if (hi > lo && (mode == 2 || 2 * (hi - lo) >= n) && halo_overlap_available(comm)) { *active = true; *i0 = lo; *i1 = hi; }
@@ -278,7 +276,7 @@ static thread_local long long t_lastOverlap[3] = { 0, 0, 0 };
 static bool cg_plan_overlap(CgRun& R)
 {
     t_lastOverlap[0] = 0;
-    if (!plan_overlap(R.ws->stream, R.comm, R.multi, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.overlap, &R.interior0, &R.interior1)) return false;
+    if (!plan_overlap(R.ws->stream, R.comm, R.multi, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.overlap, &R.interior0, &R.interior1, R.ws->devInts + 6)) return false;
     if (R.overlap) { t_lastOverlap[0] = 1; t_lastOverlap[1] = R.interior0; t_lastOverlap[2] = R.interior1; }
     return true;
 }
@@ -583,7 +581,7 @@ int SolveParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMa
     R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice;
     R.tol = allowableResidual; R.minIt = minIteration; R.maxIt = maxIteration; R.rule = rule;
     if (R.multi) {
-        R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, R.columnIndeces, R.elementsCount);
+        R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, R.columnIndeces, R.elementsCount, true);
         if (!R.halo) return MGCG_ERROR;
         if (!cg_plan_overlap(R)) { halo_plan_destroy(R.halo); return MGCG_ERROR; }
     }
@@ -610,7 +608,7 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     double* savedTrace = R.ws->trace; const int savedCap = R.ws->traceCap;
     R.ws->trace = nullptr; R.ws->traceCap = 0;
     bool ok = true;
-    if (R.multi) { R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, R.columnIndeces, R.elementsCount); ok = R.halo != nullptr && cg_plan_overlap(R); }
+    if (R.multi) { R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, R.columnIndeces, R.elementsCount, true); ok = R.halo != nullptr && cg_plan_overlap(R); }
     long long meanDistance = 0;
     if (R.elementsCount >= 8) R.cfg.periodRows = spmv_period(cusparse, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.cfg.maxRow, &meanDistance);
     R.dcsr = dcsr_lookup(cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset, R.count, meanDistance);
@@ -773,7 +771,7 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
             ok = ok && MGCG_HIP(hipStreamSynchronize(s));
             L.minJ = out[0]; L.maxJ = out[1];
             if (ok) { L.halo = halo_plan_create(comm, L.nGlobal, L.offset, L.n, L.minJ, L.maxJ); ok = L.halo != nullptr; }
-            ok = ok && plan_overlap(s, comm, mg->multi, L.rowOffsets, L.columnIndeces, L.n, L.offset, &L.overlap, &L.interior0, &L.interior1);
+            ok = ok && plan_overlap(s, comm, mg->multi, L.rowOffsets, L.columnIndeces, L.n, L.offset, &L.overlap, &L.interior0, &L.interior1, cublas->ws.devInts + 6);
         }
         mg->lv.push_back(L);
         mg->levels = (int)mg->lv.size();
@@ -887,7 +885,7 @@ int SolveMgParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, Mgcg
     R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice;
     R.tol = allowableResidual; R.minIt = minIteration; R.maxIt = maxIteration; R.rule = rule;
     if (R.multi) {
-        R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, R.columnIndeces, R.elementsCount);
+        R.halo = halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, R.columnIndeces, R.elementsCount, true);
         if (!R.halo) return MGCG_ERROR;
         if (!cg_plan_overlap(R)) { halo_plan_destroy(R.halo); return MGCG_ERROR; }
     }

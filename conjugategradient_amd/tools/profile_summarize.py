@@ -44,6 +44,7 @@ def main(out):
             entry = {"kernel": k[:110], "launches": n, "read_bytes_per_launch": read_b, "write_bytes_per_launch": write_b,
                      "hbm_bytes_per_launch": read_b + write_b,
                      "tcc_hit": mean("TCC_HIT_sum", w), "tcc_miss": mean("TCC_MISS_sum", w)}
+            res.setdefault("spmv_all", []).append(entry)      # every SpMV kernel of the run (the loop's fused launch AND the bare CsrMV export)
             if res["spmv"] is None or n > res["spmv"]["launches"]:
                 res["spmv"] = entry
     print(json.dumps(res, indent=1))
