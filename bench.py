@@ -374,7 +374,13 @@ def main():
     transport = "single rank"
     comm = None
     if world > 1:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        if L.GetDeviceCount() < local_world and a.allow_fallback:
+            # fewer devices than ranks (the one-GPU rehearsal of the N > 1 path): RCCL cannot form, the host-staged transport will be
+            # used, and the ranks share the device(s) round-robin -- never a scaling result, the line says so
+            L.MgcgSetTuning(b"virtual_devices", local_world)
         L.SetDevice(local_rank)
+        L.MgcgClearLastError()          # (a rank without a device of its own is reported by the precondition below, not here)
         # RCCL communicator (the unique id travels over gloo).  Should it fail to form on this host, every rank falls back
         # to the library's host-staged callback transport over the same gloo group: slow, but the scaling line stays valid.
         import torch

@@ -264,7 +264,8 @@ def _run_ranks_in_threads(world, make_rank):
 
 
 @pytest.mark.parametrize("overlap", ["0", "2", None])
-@pytest.mark.parametrize("world,which", [(2, "banded"), (4, "banded"), (3, "poisson"), (2, "poisson32"), (2, "unstructured")])
+@pytest.mark.parametrize("world,which", [(2, "banded"), (4, "banded"), (3, "poisson"), (2, "poisson32"), (2, "unstructured"),
+                                         (8, "poisson32"), (8, "unstructured")])     # 8 ranks: the rank count of BASELINE configs 4 and 5
 def test_native_multirank_loop_over_loopback(oracle, mgcg_env, world, which, overlap):
     """SolveParallel with N > 1: partition, halo plan + exchange, all-reduced dot products and the per-chunk stop
     decision, against the multi-device oracle (ConjugateGradientParallelGpu.cs:424-565 restated).
@@ -281,7 +282,7 @@ def test_native_multirank_loop_over_loopback(oracle, mgcg_env, world, which, ove
     elif which == "poisson":
         s = problems.poisson(12, 10, 9)
     elif which == "poisson32":
-        s = problems.poisson(32, 32, 16)
+        s = problems.poisson(32, 32, 16 if world <= 4 else 4 * world)     # (at least two interior planes per rank)
     else:
         s = problems.random_spd(1500, mean_upper=6.0, seed=21)
         s.b[:] = np.cos(np.arange(s.Count) * 0.7) * (1.0 + np.arange(s.Count) % 5)     # (b = A.1 would converge at once)
@@ -322,7 +323,8 @@ def test_native_multirank_loop_over_loopback(oracle, mgcg_env, world, which, ove
 
 
 @pytest.mark.parametrize("world,dims,levels,interpolation", [(2, (8, 8, 16), 3, 0), (4, (16, 8, 16), 2, 0), (2, (12, 12, 8), 3, 0),
-                                                            (2, (8, 8, 16), 3, 1), (4, (16, 8, 16), 2, 1), (3, (8, 4, 24), 3, 1)])
+                                                            (2, (8, 8, 16), 3, 1), (4, (16, 8, 16), 2, 1), (3, (8, 4, 24), 3, 1),
+                                                            (8, (16, 16, 64), 3, 0), (8, (16, 16, 64), 3, 1)])   # config 4's shape: 8 z-slabs, 3 levels
 def test_distributed_multigrid_over_loopback(oracle, mgcg_env, world, dims, levels, interpolation):
     """Row-partitioned MGCG (config 4 in miniature): slab-local Galerkin set-up, per-level halo planes, V-cycle
     bit-identical to the single-domain oracle, PCG within the dot-product tolerance."""
