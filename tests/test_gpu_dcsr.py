@@ -214,12 +214,15 @@ def test_too_many_distinct_rows_fall_back_to_codes_or_csr(oracle):
     h.close()
 
 
-def test_column_tiled_form_for_matrices_without_locality(oracle, mgcg_env):
+@pytest.mark.parametrize("pack", ["1", "0"])
+def test_column_tiled_form_for_matrices_without_locality(oracle, mgcg_env, pack):
     """Class 4 (BASELINE config 5 in miniature; MGCG_TILE_SHIFT shrinks the tile so that a 40 000-column matrix needs 10
     tiles): sorted random rows are re-laid out by column tile, the running row sums travel through y from tile to tile
-    in stored order -- bit-identical products; unsorted rows make the analysis decline."""
+    in stored order -- bit-identical products; unsorted rows make the analysis decline.  pack: 12-byte entries (value + one
+    packed word, the default) or the 16-byte form (MGCG_TILE_PACK=0)."""
     L = _lib.lib()
     mgcg_env.setenv("MGCG_TILE_SHIFT", "12")
+    mgcg_env.setenv("MGCG_TILE_PACK", pack)
     s = problems.random_spd(40000, mean_upper=14.0, seed=3)
     rng = np.random.default_rng(8)
     x = rng.standard_normal(s.Count)

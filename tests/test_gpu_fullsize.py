@@ -241,6 +241,8 @@ def test_config5_at_full_size(oracle):
     assert np.abs(dy.to_numpy() - 1.0).max() <= 1e-12       # row sums: 1 + sum|off| - sum|off|
     # the solve: with compression OFF the library builds the column tiles of this matrix itself (its sampled entries lie 3 M columns from
     # the diagonal on average, x is 80 MB) -- class 4 with 12-byte entries, re-verified by checksum at every solve
+    L.MgcgSetMatrixCompression(cg.cusparse, 0)              # (also when MGCG_COMPRESSION pre-set a mode for every new handle)
+    L.MgcgAnalysisClear(cg.cusparse)
     assert L.MgcgAnalysisInfo(cg.cusparse, 0, None, None, None, None) == -1
     cg.Solve()
     cg.Read()
