@@ -300,12 +300,18 @@ def launch_ranks(n: int, argv: list[str], script: str | None = None, grace_s: fl
     reader = threading.Thread(target=lambda: lines.extend(l.decode(errors="replace") for l in children[0].stdout), daemon=True)
     reader.start()
     failed_at = None
+    # a run that has not finished after MGCG_BENCH_TIMEOUT seconds (default 1500; the bench takes about a minute) is ended the same way:
+    # ranks left in a collective that will never complete must not hold the node
+    deadline_all = time.monotonic() + float(os.environ.get("MGCG_BENCH_TIMEOUT", "1500"))
     while True:
         codes = [c.poll() for c in children]
         if all(c is not None for c in codes):
             break
         if failed_at is None and any(c not in (None, 0) for c in codes):
             failed_at = time.monotonic()
+        if failed_at is None and time.monotonic() > deadline_all:
+            print("bench.py: the ranks did not finish within MGCG_BENCH_TIMEOUT; ending them", file=sys.stderr, flush=True)
+            failed_at = time.monotonic() - grace_s - 1.0
         if failed_at is not None and time.monotonic() - failed_at > grace_s:
             for c in children:
                 if c.poll() is None:

@@ -59,7 +59,9 @@ struct Tuning {
     std::atomic<int> verbose{0};             // MGCG_VERBOSE            errors also go to stderr
     std::atomic<int> lazyCodeObjects{0};     // MGCG_LAZY_CODE_OBJECTS
     std::atomic<int> virtualDevices{0};      // MGCG_VIRTUAL_DEVICES    one physical GPU shown as n devices (tests)
-    std::atomic<int> haloStream{1};          // MGCG_HALO_STREAM        overlap schedule: 1 the halo exchange on the side stream, the rows on the main stream; 0 the interior rows on the side stream
+    std::atomic<int> haloStream{0};          // MGCG_HALO_STREAM        overlap schedule: 0 (default) the interior rows on the side stream, every RCCL call on the main stream;
+                                             //                         1 the halo exchange on the side stream, all rows on the main stream (measured faster on one GPU, solver.hip;
+                                             //                         opt-in until RCCL on two streams of one communicator has run on real multi-GPU hardware)
     std::atomic<int> forceMultiRank{0};      // MGCG_FORCE_MULTIRANK    a one-rank communicator takes the several-ranks code path (measurement)
 };
 Tuning& tuning();

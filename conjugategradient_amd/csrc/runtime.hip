@@ -43,7 +43,7 @@ const Knob kKnobs[] = {
     { "MGCG_VERBOSE", "verbose", &Tuning::verbose, 0, false },
     { "MGCG_LAZY_CODE_OBJECTS", "lazy_code_objects", &Tuning::lazyCodeObjects, 0, true },
     { "MGCG_VIRTUAL_DEVICES", "virtual_devices", &Tuning::virtualDevices, 0, false },
-    { "MGCG_HALO_STREAM", "halo_stream", &Tuning::haloStream, 1, false },
+    { "MGCG_HALO_STREAM", "halo_stream", &Tuning::haloStream, 0, false },
     { "MGCG_FORCE_MULTIRANK", "force_multirank", &Tuning::forceMultiRank, 0, false },
 };
 Tuning g_tuning;

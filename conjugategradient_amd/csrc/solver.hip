@@ -49,7 +49,7 @@ struct MgcgMg {
     MgcgComm* comm = nullptr;              // not owned
     int nranks = 1;
     bool multi = false;                    // several ranks (or one rank forced onto that path, comm_multi): full-length iterates, halo exchanges, all-reduces
-    bool haloOnSide = true;                // overlap schedule (tuning knob halo_stream, resolved at set-up)
+    bool haloOnSide = false;               // overlap schedule (tuning knob halo_stream, resolved at set-up)
     // r.z of the PCG loop rides on the V-cycle's last sweep (single rank): partial sums go here, fusedDotCount of them
     double* fuseDotPartials = nullptr;
     int fusedDotCount = 0;
@@ -268,7 +268,7 @@ struct CgRun {
     bool overlap = false;
     long long interior0 = 0, interior1 = 0;
     bool noFoldedFinalize = false;         // tuning knobs, resolved once per solve (every iteration of every rank takes the same path)
-    bool haloOnSide = true;
+    bool haloOnSide = false;
 };
 
 static thread_local long long t_lastOverlap[3] = { 0, 0, 0 };

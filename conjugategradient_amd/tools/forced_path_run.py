@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--planes", type=int, default=64)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--overlap", type=int, default=2)
-    ap.add_argument("--halo-stream", type=int, default=1)
+    ap.add_argument("--halo-stream", type=int, default=0)
     ap.add_argument("--force", type=int, default=-1, help="entries of the artificial halo (default one plane; 0: the plain single-rank loop)")
     ap.add_argument("--solver", choices=["cg", "mgcg"], default="cg")
     ap.add_argument("--repeats", type=int, default=1)

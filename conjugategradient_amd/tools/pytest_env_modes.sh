@@ -8,7 +8,7 @@ run MGCG_DEFAULT=1
 run MGCG_COMPRESSION=1
 run MGCG_COMPRESSION=2
 run MGCG_OVERLAP=2
-run MGCG_OVERLAP=2 MGCG_HALO_STREAM=0
+run MGCG_OVERLAP=2 MGCG_HALO_STREAM=1
 run MGCG_NO_FOLD=1
 run MGCG_NO_ZSWEEP=1
 run MGCG_TILE_PACK=0

@@ -146,10 +146,10 @@ def main():
 
             plain = fresh("--force", "0")["ms_per_iteration"]
             rows = []
-            for overlap, halo_stream in ((0, 1), (2, 0), (2, 1), (1, 1)):
+            for overlap, halo_stream in ((0, 0), (2, 0), (2, 1), (1, 0), (1, 1)):      # overlap 1 + halo_stream 0 = the library's defaults
                 r = fresh("--overlap", str(overlap), "--halo-stream", str(halo_stream))
-                rows.append({"overlap": overlap, "schedule": "exchange in line" if overlap == 0 else (("the library's own choice: " if overlap == 1 else "") + (
-                                 "exchange on the side stream, rows on the main stream" if halo_stream else "interior rows on the side stream, exchange on the main stream")),
+                rows.append({"overlap": overlap, "schedule": "exchange in line" if overlap == 0 else (("overlap where a level has >= 3 M rows (the default rule): " if overlap == 1 else "overlap on every level: ") + (
+                                 "exchange on the side stream, rows on the main stream (MGCG_HALO_STREAM=1)" if halo_stream else "interior rows on the side stream, every RCCL call on the main stream (default)")),
                              "ms_per_iteration": r["ms_per_iteration"], "added_us_vs_plain": 1e3 * (r["ms_per_iteration"] - plain), "halo_overlap_active": r["halo_overlap_active"]})
             out[kind]["fresh_process_plain_ms_per_iteration"] = plain
             out[kind]["one_rank_rccl_on_the_several_ranks_path"] = rows

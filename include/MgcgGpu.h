@@ -165,8 +165,9 @@ int         MgcgAbiVersion(void);
  *   no_uniform_diagonal, no_zsweep, rowtile_nt / vec_nt (-1 by size, 0 / 1 forced), vec_grid, r_grid, xp_grid,
  *   pattern_group, pattern_waves, no_indexed_halo, tile_nt, tile_shift, verbose, lazy_code_objects,
  *   virtual_devices (MGCG_VIRTUAL_DEVICES: one physical GPU shown as n devices, tests only),
- *   halo_stream (overlap schedule: 1 [default] the halo exchange runs on the communicator's side stream while the interior rows
- *   run on the main stream, 0 the interior rows run on the side stream and the exchange on the main stream),
+ *   halo_stream (overlap schedule: 0 [default] the interior rows run on the communicator's side stream and every RCCL call on the
+ *   main stream; 1 the halo exchange runs on the side stream and all rows on the main stream -- 19 us less per iteration on one
+ *   rank's slab, opt-in until RCCL on two streams of one communicator has been run on real multi-GPU hardware),
  *   force_multirank (MGCG_FORCE_MULTIRANK = w > 0: a one-rank RCCL communicator takes the several-ranks code path with an
  *   artificial halo of w entries, for measuring that path's device-side cost on a one-GPU box).
  * MgcgSetTuning / MgcgGetTuning take the knob's name or its environment variable; they return 0, or -1 for an unknown

@@ -88,3 +88,10 @@ def test_bench_parent_stays_gpu_free(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["argv"] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
+
+
+def test_a_run_that_never_finishes_is_ended(tmp_path, capfd, monkeypatch):
+    monkeypatch.setenv("MGCG_BENCH_TIMEOUT", "1")
+    s = _script(tmp_path, "import time; time.sleep(600)")
+    assert bench.launch_ranks(2, [], script=s, grace_s=0.2) == 128 + 15
+    assert "did not finish" in capfd.readouterr().err
