@@ -54,6 +54,7 @@ struct Tuning {
     std::atomic<int> patternGroup{0}, patternWaves{16};    // MGCG_PATTERN_GROUP / MGCG_PATTERN_WAVES
     std::atomic<int> noIndexedHalo{0};       // MGCG_NO_INDEXED_HALO
     std::atomic<int> tileNt{0}, tileShift{0};              // MGCG_TILE_NT / MGCG_TILE_SHIFT (0: default 19)
+    std::atomic<int> vectorValsNt{-1};       // MGCG_VECTOR_VALS_NT     lanes-per-row SpMV: values with the non-temporal hint (-1 by size)
     std::atomic<int> tilePack{1};            // MGCG_TILE_PACK          column tiles with 12-byte entries (0: the 16-byte form)
     std::atomic<int> autoTiles{1};           // MGCG_AUTO_TILES         Solve-family calls build the column tiles themselves for matrices without locality
     std::atomic<int> verbose{0};             // MGCG_VERBOSE            errors also go to stderr

@@ -347,8 +347,10 @@ __global__ __launch_bounds__(BLOCK) void spmv_stream_kernel(SpmvArgs a, int nRow
     }
 }
 
-// LANES lanes per row (power of two, 2..64).
-template <int EPI, int LANES>
+// LANES lanes per row (power of two, 2..64).  VNT: the values are read with the non-temporal hint and the column ids without it -- for a matrix
+// whose 12 bytes per nonzero exceed the 256 MB Infinity Cache while its column ids alone fit (the reference drivers' 200-350 k rows x 159:
+// 130-220 MB of column ids): the ids then stay cache-resident from one product of a solve to the next and only the values come from HBM.
+template <int EPI, int LANES, bool VNT = false>
 __global__ __launch_bounds__(kBlock) void spmv_vector_kernel(SpmvArgs a)
 {
     __shared__ double s_red[4];
@@ -368,14 +370,14 @@ __global__ __launch_bounds__(kBlock) void spmv_vector_kernel(SpmvArgs a)
             for (; k + 3 * LANES < e; k += 4 * LANES) {
                 double v[4]; int c[4]; double xv[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { v[u] = a.elements[k + u * LANES]; c[u] = a.columnIndeces[k + u * LANES]; }
+                for (int u = 0; u < 4; ++u) { v[u] = ld_stream<VNT>(a.elements + k + u * LANES); c[u] = a.columnIndeces[k + u * LANES]; }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) xv[u] = a.x[c[u]];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { const double prod = v[u] * xv[u]; acc += prod; }
             }
             for (; k < e; k += LANES) {
-                double prod = a.elements[k] * a.x[a.columnIndeces[k]];
+                double prod = ld_stream<VNT>(a.elements + k) * a.x[a.columnIndeces[k]];
                 acc += prod;
             }
         }
@@ -500,7 +502,12 @@ static int launch_vector_l(hipStream_t s, const SpmvArgs& a, const SpmvConfig& c
     int grid = cfg.gridBlocks > 0 ? cfg.gridBlocks : kMaxGrid;
     if (grid > blocks) grid = (int)blocks;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((spmv_vector_kernel<EPI, LANES>), dim3(grid), dim3(kBlock), 0, s, a);
+    // values past the Infinity Cache, column ids inside it (see the kernel): MGCG_VECTOR_VALS_NT=0/1 overrides
+    const int knob = tuning().vectorValsNt.load(std::memory_order_relaxed);
+    const long long idBytes = 4LL * a.elementsCount;
+    const bool vnt = knob >= 0 ? knob != 0 : (3 * idBytes > (256LL << 20) && idBytes <= (224LL << 20));
+    if (vnt) hipLaunchKernelGGL((spmv_vector_kernel<EPI, LANES, true>), dim3(grid), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((spmv_vector_kernel<EPI, LANES>), dim3(grid), dim3(kBlock), 0, s, a);
     return grid;
 }
 

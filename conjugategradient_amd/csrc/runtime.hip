@@ -38,6 +38,7 @@ const Knob kKnobs[] = {
     { "MGCG_NO_INDEXED_HALO", "no_indexed_halo", &Tuning::noIndexedHalo, 0, true },
     { "MGCG_TILE_NT", "tile_nt", &Tuning::tileNt, 0, false },
     { "MGCG_TILE_SHIFT", "tile_shift", &Tuning::tileShift, 0, false },
+    { "MGCG_VECTOR_VALS_NT", "vector_vals_nt", &Tuning::vectorValsNt, -1, false },
     { "MGCG_TILE_PACK", "tile_pack", &Tuning::tilePack, 1, false },
     { "MGCG_AUTO_TILES", "auto_tiles", &Tuning::autoTiles, 1, false },
     { "MGCG_VERBOSE", "verbose", &Tuning::verbose, 0, false },
