@@ -67,23 +67,25 @@ static SpmvConfig cfg_of(const MgcgSparse* h)
     return c;
 }
 
-// Can the halo of a row slice hide behind its interior rows?  (several ranks, most rows reference local columns only).
-// MGCG_OVERLAP: 0 off, 1 (default) when it pays, 2 whenever an interior exists (tests).
+// The interior rows of a row slice -- rows [*i0, *i1) reference local columns only -- and whether its halo exchange should hide behind them
+// (*active).  The range is found for every slice of several ranks (the multigrid's folded residual pass uses it with or without overlap);
+// MGCG_OVERLAP decides *active: 0 never, 1 (default) when it pays, 2 whenever an interior exists (tests).
 // d2: two device ints of the caller's workspace (Workspace::devInts + 6)
 static bool plan_overlap(hipStream_t s, MgcgComm* comm, bool multi, const int* rowOffsets, const int* columnIndeces,
                          long long n, long long offset, bool* active, long long* i0, long long* i1, int* d2)
 {
     *active = false; *i0 = 0; *i1 = 0;
+    if (!multi || n <= 0) return true;
     const int mode = tuning().overlap.load(std::memory_order_relaxed);
     // mode 1: only where the rows between fork and join outlast the two cross-stream hops (10 us each, measured) and the exchange --
     // a row-tile SpMV streams ~55 k rows per us, so below ~3 M rows the exchange in line is the cheaper schedule (profiles/r3/slab_latency.json)
-    if (!multi || mode == 0 || (mode == 1 && n < 3000000)) return true;
+    const bool wanted = mode == 2 || (mode == 1 && n >= 3000000);
     if (MgcgCommSize(comm) == 1) {
         // one rank forced onto the several-ranks path (measurement): an artificial split -- the first and last force_multirank rows
         // (rounded to SpMV tiles) play the boundary
         long long w = tuning().forceMultiRank.load(std::memory_order_relaxed);
         w = (w + 255) & ~255LL;
-        if (n >= 4 * w && w > 0 && halo_overlap_available(comm)) { *active = true; *i0 = w; *i1 = n - w; }
+        if (n >= 4 * w && w > 0) { *i0 = w; *i1 = n - w; *active = wanted && halo_overlap_available(comm); }
         return true;
     }
     int h2[2] = { 0, (int)n };
@@ -92,7 +94,10 @@ static bool plan_overlap(hipStream_t s, MgcgComm* comm, bool multi, const int* r
     ok = ok && MGCG_HIP(hipMemcpyAsync(h2, d2, sizeof(h2), hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
     if (!ok) return false;
     const long long lo = h2[0], hi = h2[1] < n ? h2[1] : n;
-    if (hi > lo && (mode == 2 || 2 * (hi - lo) >= n) && halo_overlap_available(comm)) { *active = true; *i0 = lo; *i1 = hi; }
+    if (hi > lo) {
+        *i0 = lo; *i1 = hi;
+        *active = wanted && (mode == 2 || 2 * (hi - lo) >= n) && halo_overlap_available(comm);
+    }
     return true;
 }
 
@@ -102,9 +107,12 @@ static bool mg_halo(MgcgMg* mg, MgLevel& L, double* xfull)
     return halo_exchange(mg->comm, L.halo, xfull, mg->stream);
 }
 
-// Halo of the full-length iterate a.x, then the SpMV-shaped pass; interior rows first when the level overlaps.
+// Halo of the full-length iterate xfull, then the SpMV-shaped pass; interior rows first when the level overlaps.
 // partials / nPartials (dot epilogues): where the per-workgroup partial sums go and how many were written.
-static bool mg_spmv(MgcgMg* mg, MgLevel& L, int epilogue, const SpmvArgs& a, double* xfull, double* partials = nullptr, int* nPartials = nullptr)
+// aInt describes the pass for the interior rows (they reference local columns only), aBnd for the boundary rows and for a level that
+// does not overlap: the same arguments except, for the folded residual pass of several ranks (mg_vcycle), the multiplied vector.
+static bool mg_spmv2(MgcgMg* mg, MgLevel& L, int epilogue, const SpmvArgs& aInt, const SpmvArgs& aBnd, double* xfull, double* partials = nullptr, int* nPartials = nullptr,
+                     bool splitInLine = false)
 {
     hipStream_t s = mg->stream;
     int n = 0;
@@ -112,8 +120,13 @@ static bool mg_spmv(MgcgMg* mg, MgLevel& L, int epilogue, const SpmvArgs& a, dou
     const int half = partials ? kMaxPartials / 2 : 0;
     if (!L.overlap) {
         if (!mg_halo(mg, L, xfull)) return false;
-        SpmvArgs b = a; b.partials = partials;
-        n = launch_spmv_auto(s, epilogue, b, L.cfg, L.dcsr);
+        if (splitInLine) {                           // two kinds of rows, one stream: interior rows with aInt, the rows either side with aBnd
+            n = launch_spmv_range(s, epilogue, aInt, L.cfg, L.dcsr, L.interior0, L.interior1, partials, half);
+            n += launch_spmv_two_ranges(s, epilogue, aBnd, L.cfg, L.dcsr, L.interior0, L.interior1, partials ? partials + n : nullptr, half);
+        } else {
+            SpmvArgs b = aBnd; b.partials = partials;
+            n = launch_spmv_auto(s, epilogue, b, L.cfg, L.dcsr);
+        }
         if (nPartials) *nPartials = n;
         return true;
     }
@@ -122,17 +135,21 @@ static bool mg_spmv(MgcgMg* mg, MgLevel& L, int epilogue, const SpmvArgs& a, dou
     if (mg->haloOnSide) {
         // the exchange on the side stream, all rows on the main stream: both cross-stream hops hide behind the interior rows
         if (!halo_exchange(mg->comm, L.halo, xfull, side)) return false;
-        n = launch_spmv_range(s, epilogue, a, L.cfg, L.dcsr, L.interior0, L.interior1, partials, half);
+        n = launch_spmv_range(s, epilogue, aInt, L.cfg, L.dcsr, L.interior0, L.interior1, partials, half);
         if (!halo_overlap_join(mg->comm, s)) return false;
-        n += launch_spmv_two_ranges(s, epilogue, a, L.cfg, L.dcsr, L.interior0, L.interior1, partials ? partials + n : nullptr, half);   // the boundary rows either side of the interior
+        n += launch_spmv_two_ranges(s, epilogue, aBnd, L.cfg, L.dcsr, L.interior0, L.interior1, partials ? partials + n : nullptr, half);   // the boundary rows either side of the interior
         if (nPartials) *nPartials = n;
         return true;
     }
-    n = launch_spmv_range(side, epilogue, a, L.cfg, L.dcsr, L.interior0, L.interior1, partials, half);
+    n = launch_spmv_range(side, epilogue, aInt, L.cfg, L.dcsr, L.interior0, L.interior1, partials, half);
     if (!mg_halo(mg, L, xfull)) return false;
-    n += launch_spmv_two_ranges(s, epilogue, a, L.cfg, L.dcsr, L.interior0, L.interior1, partials ? partials + n : nullptr, half);
+    n += launch_spmv_two_ranges(s, epilogue, aBnd, L.cfg, L.dcsr, L.interior0, L.interior1, partials ? partials + n : nullptr, half);
     if (nPartials) *nPartials = n;
     return halo_overlap_join(mg->comm, s);
+}
+static bool mg_spmv(MgcgMg* mg, MgLevel& L, int epilogue, const SpmvArgs& a, double* xfull, double* partials = nullptr, int* nPartials = nullptr)
+{
+    return mg_spmv2(mg, L, epilogue, a, a, xfull, partials, nPartials);
 }
 
 // xout_loc = xin_loc + omega * (dinv * (b - A xin)); xin / xout are full-length buffers
@@ -190,8 +207,24 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
         SpmvArgs probe{}; probe.elements = L.elements; probe.columnIndeces = L.columnIndeces; probe.elementsCount = (int)L.nnz; probe.rowCount = (int)L.n;
         canScale = spmv_takes_rowtile(probe, L.cfg);
     }
-    const bool fold = mg->nu == 1 && !mg->multi && !linear && L.dinvUniform && canScale && tuning().noFold.load(std::memory_order_relaxed) == 0;
+    const bool mayFold = mg->nu == 1 && !linear && L.dinvUniform && canScale && tuning().noFold.load(std::memory_order_relaxed) == 0;
+    const bool fold = mayFold && !mg->multi;
+    // Several ranks: the same fold for the INTERIOR rows (they reference local columns only: x1[col] formed per gather
+    // from the local right-hand side), while the boundary rows multiply the stored iterate, which therefore exists only where they reach --
+    // the local rows within two grid planes of a boundary (every level is a 27-point-neighbourhood operator: MgSetup's Galerkin pass has
+    // checked it) -- and, after the exchange, in the halo planes.
+    const long long plane = (long long)L.nx * L.ny;
+    const long long zoneLo = L.interior0 > 0 ? L.interior0 + 2 * plane : 0;                 // x1 stored for local rows [0, zoneLo) ...
+    const long long zoneHi = L.interior1 < L.n ? L.interior1 - 2 * plane : L.n;             // ... and [zoneHi, n)
+    // (worth two more launches only on a large level: 16 bytes per row saved against ~15 us of launches and a boundary pass of its own)
+    const bool foldInterior = mayFold && mg->multi && (L.dcsr == nullptr || !L.dcsr->usable) && zoneLo <= zoneHi && 2 * (L.interior1 - L.interior0) >= L.n &&
+                              (L.n >= 3000000 || tuning().overlap.load(std::memory_order_relaxed) == 2);
     if (fold) cur = x0;
+    else if (foldInterior) {
+        cur = x0;
+        if (zoneLo > 0) launch_jacobi_first(mg->stream, zoneLo, mg->omega, L.dinv, 1, L.dinvScalar, b, cur + L.offset, done);
+        if (zoneHi < L.n) launch_jacobi_first(mg->stream, L.n - zoneHi, mg->omega, L.dinv, 1, L.dinvScalar, b + zoneHi, cur + L.offset + zoneHi, done);
+    }
     else if (!mg_smooth(mg, L, b, x0, x1, mg->nu, true, done, &cur)) return false;
     double* other = (cur == x0) ? x1 : x0;
     SpmvArgs a{};
@@ -201,7 +234,13 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
     a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = fold ? b : cur; a.y = rFullLength ? other + L.offset : L.r;
     a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal; a.b = b; a.doneFlag = done;
     if (fold) { a.xScaled = 1; a.xInner = L.dinvScalar; a.xOuter = mg->omega; }
-    if (!mg_spmv(mg, L, EPI_RESIDUAL, a, cur)) return false;                                  // r = b - A x
+    if (foldInterior) {
+        SpmvArgs ai = a;
+        ai.x = b - L.offset;                         // global column ids of the interior rows are local: (b - offset)[col] = b[col - offset]
+        ai.xScaled = 1; ai.xInner = L.dinvScalar; ai.xOuter = mg->omega;
+        if (!mg_spmv2(mg, L, EPI_RESIDUAL, ai, a, cur, nullptr, nullptr, true)) return false;   // r = b - A x1, interior rows from b, boundary rows from the exchanged iterate
+    }
+    else if (!mg_spmv(mg, L, EPI_RESIDUAL, a, cur)) return false;                             // r = b - A x
     if (linear) {
         if (rFullLength && !halo_exchange(mg->comm, L.transferHalo, other, mg->stream)) return false;
         launch_restrict_linear(mg->stream, L.nx, L.ny, L.nz, L.z0, L.z1, rFullLength ? other : L.r, C.b, done);   // b_c = P^T r
@@ -214,7 +253,7 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
         if (mg->multi && !halo_exchange(mg->comm, C.transferHalo, e, mg->stream)) return false;
         launch_prolong_linear_add(mg->stream, L.nx, L.ny, L.nz, L.z0, L.z1, cur + L.offset, e, done);               // x += P e
     }
-    else if (fold) launch_prolong_scaled(mg->stream, L.nx, L.ny, L.z1 - L.z0, cur + L.offset, b, L.dinvScalar, mg->omega, e + C.offset, done);
+    else if (fold || foldInterior) launch_prolong_scaled(mg->stream, L.nx, L.ny, L.z1 - L.z0, cur + L.offset, b, L.dinvScalar, mg->omega, e + C.offset, done);
     else launch_prolong_add(mg->stream, L.nx, L.ny, L.z1 - L.z0, cur + L.offset, e + C.offset, done);   // x += P e (slab-local)
     return mg_smooth(mg, L, b, cur, other, mg->nu, false, done, result, l == 0);
 }
@@ -275,7 +314,7 @@ static thread_local long long t_lastOverlap[3] = { 0, 0, 0 };
 
 static bool cg_plan_overlap(CgRun& R)
 {
-    t_lastOverlap[0] = 0;
+    t_lastOverlap[0] = 0; t_lastOverlap[1] = 0; t_lastOverlap[2] = 0;
     if (!plan_overlap(R.ws->stream, R.comm, R.multi, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.overlap, &R.interior0, &R.interior1, R.ws->devInts + 6)) return false;
     if (R.overlap) { t_lastOverlap[0] = 1; t_lastOverlap[1] = R.interior0; t_lastOverlap[2] = R.interior1; }
     return true;
