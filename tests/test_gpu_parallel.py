@@ -122,6 +122,27 @@ def test_one_rank_rccl_communicator_takes_the_several_ranks_path(oracle, mgcg_en
     L.MgcgCommDestroy(comm)
 
 
+def test_comm_probe_prices_the_steps_of_the_several_ranks_path():
+    """MgcgCommProbe (tools/slab_latency.py): every kind of step returns a finite, positive time on a one-rank RCCL communicator and on
+    a communicator without a transport; bad arguments are refused."""
+    L = _lib.lib()
+    L.SetDevice(0)
+    buf = (C.c_char * 128)()
+    assert L.MgcgCommGetUniqueId(buf) == 0, _lib.last_error()
+    comm = L.MgcgCommInitRank(buf, 1, 0)
+    assert comm, _lib.last_error()
+    for what, count in ((0, 1), (0, 2), (1, 4096), (2, 0), (3, 0)):
+        us = L.MgcgCommProbe(comm, what, count, 20)
+        assert np.isfinite(us) and 0.0 < us < 1e5, (what, count, us, _lib.last_error())
+    assert np.isnan(L.MgcgCommProbe(comm, 9, 0, 20)) and "bad argument" in _lib.last_error()
+    L.MgcgClearLastError()
+    L.MgcgCommDestroy(comm)
+    one = (C.c_void_p * 1)()
+    assert L.MgcgCommInitAll(one, 1) == 0
+    assert np.isfinite(L.MgcgCommProbe(one[0], 3, 0, 10))
+    L.MgcgCommDestroy(one[0])
+
+
 def test_comm_init_all_single_process(oracle, mgcg_env):
     """MgcgCommInitAll: the communicators of every device of ONE process (ConjugateGradientParallelGpu's shape); on this box
     the 3 devices are virtual, so the group is the in-process loopback; each device's thread runs the whole native loop."""
