@@ -613,6 +613,8 @@ def main():
                                    f"b=1, x0=0, {world} z-slab partition(s)",
                        "rows": N, "nnz": nnz_total, "parallelism": f"row-range dp{world}", "transport": transport},
             "iteration_algorithmic_gbps": iter_bytes / (dt / a.steps) / 1e9,
+            "iteration_required_gbps": (sum(vcycle_required_bytes(n, a.mg_levels, a.mg_nu, a.mg_nu_coarse, fold=(a.mg_interpolation == 0 and world == 1))) / (dt / a.steps) / 1e9
+                                        if a.solver == "mgcg" else None),
             "gflops": (2 * nnz_total + 10 * N) * (a.steps / dt) / 1e9 if a.solver == "cg" else None,
             "residual_after_steps": res,
         }
