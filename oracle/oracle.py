@@ -33,7 +33,7 @@ def build(asan: bool = False) -> str:
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        path = os.environ.get("ORACLE_LIB_PATH") or os.path.join(_HERE, "liboracle.so")     # (the variable: the sanitizer build, make liboracle_asan.so)
         srcs = [os.path.join(_HERE, f) for f in ("cg_oracle.c", "mg_oracle.c")]
         if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs if os.path.exists(s)):
             build()
