@@ -233,7 +233,10 @@ def mgcg_extra(L, n: int):
     # linear transfer (MgSetInterpolation; profiles/r2/mgcg_levels_sweep_512_csr*.log); its bytes are its own (the transfers
     # move the same HBM bytes, their extra operands come from cache)
     deep = (8, 1, 4) if n == 512 else None
-    rows = [("csr", 0, (levels, nu, nuc), 0), ("row_pattern", 1, (levels, nu, nuc), 0)] + ([("csr_8_levels_linear_transfer", 0, deep, 1)] if deep else [])
+    # fourth row: the same 3-level V(1,1) cycle with 64 Jacobi sweeps on the coarsest level instead of 4 (a 128^3 sweep costs 35 us at 512^3; the
+    # coarse-level error is what limits a 3-level cycle): 53 instead of 157 iterations
+    rows = ([("csr", 0, (levels, nu, nuc), 0), ("row_pattern", 1, (levels, nu, nuc), 0)] + ([("csr_8_levels_linear_transfer", 0, deep, 1)] if deep else []) +
+            ([("csr_3_levels_64_coarse_sweeps", 0, (3, 1, 64), 0)] if n >= 256 else []))
     for key, mode, (lv_, nu_, nuc_), interp in rows:
         mg = ConjugateGradientMgGpu(N, 7, 0, 5000, tol, (n, n, n), levels=lv_, nu=nu_, nuCoarse=nuc_, rule=_lib.RULE_CSHARP, interpolation=interp)
         vb_, shell_ = vcycle_bytes(n, lv_, nu_, nuc_)
