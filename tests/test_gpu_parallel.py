@@ -286,7 +286,8 @@ def _run_ranks_in_threads(world, make_rank):
 
 @pytest.mark.parametrize("overlap", ["0", "2", None])
 @pytest.mark.parametrize("world,which", [(2, "banded"), (4, "banded"), (3, "poisson"), (2, "poisson32"), (2, "unstructured"),
-                                         (8, "poisson32"), (8, "unstructured")])     # 8 ranks: the rank count of BASELINE configs 4 and 5
+                                         (8, "poisson32"), (8, "unstructured"),      # 8 ranks: the rank count of BASELINE configs 4 and 5
+                                         (3, "poisson64x12x9"), (3, "poisson64x12x10")])   # planes of 768 rows = 3 SpMV tiles; the second splits ranks mid-plane
 def test_native_multirank_loop_over_loopback(oracle, mgcg_env, world, which, overlap):
     """SolveParallel with N > 1: partition, halo plan + exchange, all-reduced dot products and the per-chunk stop
     decision, against the multi-device oracle (ConjugateGradientParallelGpu.cs:424-565 restated).
@@ -302,6 +303,8 @@ def test_native_multirank_loop_over_loopback(oracle, mgcg_env, world, which, ove
         s = problems.mgcg_main(2403, 160)
     elif which == "poisson":
         s = problems.poisson(12, 10, 9)
+    elif which.startswith("poisson64x"):
+        s = problems.poisson(*[int(v) for v in which[len("poisson"):].split("x")])
     elif which == "poisson32":
         s = problems.poisson(32, 32, 16 if world <= 4 else 4 * world)     # (at least two interior planes per rank)
     else:
@@ -322,7 +325,7 @@ def test_native_multirank_loop_over_loopback(oracle, mgcg_env, world, which, ove
             assert not active
         else:
             assert active and 0 <= i0 < i1 <= cg.part.count
-            if which in ("poisson", "poisson32"):       # interior = the slab minus the planes that touch a neighbour
+            if which in ("poisson", "poisson32", "poisson64x12x9"):       # interior = the slab minus the planes that touch a neighbour
                 plane = s.grid[0] * s.grid[1]
                 assert i0 == (plane if rank > 0 else 0) and i1 == cg.part.count - (plane if rank < world - 1 else 0)
         cg.Read()
