@@ -166,6 +166,7 @@ struct DcsrView {
     const int2* tileHdr;
     const int* tileHdrBaseHost;      // HOST array [nTiles]: first header of the tile, or -1 for a tile that keeps 16-byte entries (its row ids do not fit)
     int tileShift;
+    int tileWidth;                   // columns per tile (equal-width tiles, <= 2^tileShift)
     int nTiles;
     long long tileRows;              // rows of the analysed matrix
 };
@@ -179,7 +180,7 @@ struct DcsrMatrix {
     unsigned char* patternId = nullptr; int* patCount = nullptr; int* patDelta = nullptr; double* patValue = nullptr;
     int nPattern = 0, patWidth = 0;
     double* tileVals = nullptr; int* tileCols = nullptr; int* tileRowIds = nullptr; int nTiles = 0; long long tileRows = 0;
-    unsigned* tilePacked = nullptr; int2* tileHdr = nullptr; int tileShift = 0;
+    unsigned* tilePacked = nullptr; int2* tileHdr = nullptr; int tileShift = 0, tileWidth = 0;
     std::vector<int> tileStart, tileHdrBase;
     unsigned long long checksum = 0;  // of the CSR arrays the analysis was made from (forms chosen without the caller asking are re-verified per solve)
     bool automatic = false;           // built by the library's own choice (column tiles for a matrix without locality), not by MgcgSetMatrixCompression
@@ -191,7 +192,7 @@ struct DcsrMatrix {
         DcsrView v; v.colCode = colCode; v.valCode = valCode; v.deltaDict = deltaDict; v.valueDict = valueDict; v.nDelta = nDelta; v.nValue = nValue; v.rowBase = rowBase;
         v.patternId = patternId; v.patCount = patCount; v.patDelta = patDelta; v.patValue = patValue; v.nPattern = nPattern; v.patWidth = patWidth;
         v.tileVals = tileVals; v.tileCols = tileCols; v.tileRowIds = tileRowIds; v.tileStartHost = tileStart.data(); v.nTiles = nTiles; v.tileRows = tileRows;
-        v.tilePacked = tilePacked; v.tileHdr = tileHdr; v.tileHdrBaseHost = tileHdrBase.data(); v.tileShift = tileShift;
+        v.tilePacked = tilePacked; v.tileHdr = tileHdr; v.tileHdrBaseHost = tileHdrBase.data(); v.tileShift = tileShift; v.tileWidth = tileWidth;
         return v;
     }
 };

@@ -217,7 +217,7 @@ void DcsrMatrix::release()
     if (tilePacked) (void)hipFree(tilePacked);
     if (tileHdr) (void)hipFree(tileHdr);
     tileVals = nullptr; tileCols = nullptr; tileRowIds = nullptr; nTiles = 0; tileRows = 0; tileStart.clear();
-    tilePacked = nullptr; tileHdr = nullptr; tileShift = 0; tileHdrBase.clear(); checksum = 0;
+    tilePacked = nullptr; tileHdr = nullptr; tileShift = 0; tileWidth = 0; tileHdrBase.clear(); checksum = 0;
     colCode = valCode = nullptr; deltaDict = nullptr; valueDict = nullptr; nDelta = nValue = 0;
     patternId = nullptr; patCount = nullptr; patDelta = nullptr; patValue = nullptr; nPattern = patWidth = 0;
     usable = false;

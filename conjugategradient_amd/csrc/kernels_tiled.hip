@@ -23,7 +23,7 @@ constexpr int kScanPer = 8;                    // elements per thread in the sca
 // One pass over the rows: are the column ids of every row ascending?  how far from the diagonal is the typical entry?
 // and counts[t * rows + i] = entries of row i in column tile t.
 __global__ __launch_bounds__(kBlock) void tiled_count_kernel(const int* __restrict__ rowOffsets, const int* __restrict__ columnIndeces,
-                                                             long long rows, long long rowBase, int tileShift, int nTiles,
+                                                             long long rows, long long rowBase, int tileWidth, int nTiles,
                                                              int* __restrict__ counts, unsigned long long* stats /* [0] unsorted rows, [1] sum |col-row| >> 10 */)
 {
     const long long stride = (long long)gridDim.x * kBlock;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kBlock) void tiled_count_kernel(const int* __restri
             prev = c;
             const long long d = (long long)c - (rowBase + i);
             far += (unsigned long long)((d < 0 ? -d : d) >> 10);
-            const int t = c >> tileShift;
+            const int t = c / tileWidth;
             if (t != tile) { if (tile >= 0 && tile < nTiles) counts[(long long)tile * rows + i] = run; tile = t; run = 0; }
             ++run;
         }
@@ -113,7 +113,7 @@ static int grid_rows(long long n)
 
 // entries of row i go to [ptr[t * rows + i], ...) of tile t in stored (= ascending column) order, each with its row id
 __global__ __launch_bounds__(kBlock) void tiled_scatter_kernel(const double* __restrict__ elements, const int* __restrict__ rowOffsets,
-                                                               const int* __restrict__ columnIndeces, long long rows, int tileShift,
+                                                               const int* __restrict__ columnIndeces, long long rows, int tileWidth,
                                                                const int* __restrict__ ptr, double* __restrict__ tVals, int* __restrict__ tCols, int* __restrict__ tRows)
 {
     const long long stride = (long long)gridDim.x * kBlock;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kBlock) void tiled_scatter_kernel(const double* __r
         int tile = -1, pos = 0;
         for (int k = s; k < e; ++k) {
             const int c = columnIndeces[k];
-            const int t = c >> tileShift;
+            const int t = c / tileWidth;
             if (t != tile) { tile = t; pos = ptr[(long long)t * rows + i]; }
             tVals[pos] = elements[k]; tCols[pos] = c; tRows[pos] = (int)i;
             ++pos;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void spmv_tile_pass_packed_kernel(const dou
 }
 
 // hdr and packed words of one tile's entries [kBegin, kEnd); *overflow is raised when a row id does not fit the packed word
-__global__ __launch_bounds__(kBlock) void tiled_pack_kernel(const int* __restrict__ tCols, const int* __restrict__ tRows, int kBegin, int kEnd, int shift,
+__global__ __launch_bounds__(kBlock) void tiled_pack_kernel(const int* __restrict__ tCols, const int* __restrict__ tRows, int kBegin, int kEnd, int shift, int tileCol0,
                                                             unsigned* __restrict__ tPacked, int2* __restrict__ hdr, int hdrBase, int* __restrict__ overflow)
 {
     const int nBlocks = (kEnd - kBegin + kTilePack - 1) / kTilePack;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void tiled_pack_kernel(const int* __restric
         for (int k = base + (int)threadIdx.x; k < end; k += kBlock) {
             const int lr = tRows[k] - baseRow;
             if (lr < 0 || lr > rowLimit) { *overflow = 1; continue; }
-            tPacked[k] = ((unsigned)lr << shift) | ((unsigned)tCols[k] & colMask);
+            tPacked[k] = ((unsigned)lr << shift) | ((unsigned)(tCols[k] - tileCol0) & colMask);
         }
     }
 }
@@ -304,7 +304,7 @@ static int launch_tiled_epi(hipStream_t s, const SpmvArgs& a, const DcsrView& m)
         const dim3 g((ke - kb + kBlock * kTileE - 1) / (kBlock * kTileE));
         if (m.tilePacked != nullptr && m.tileHdrBaseHost[t] >= 0) {
             hipLaunchKernelGGL(spmv_tile_pass_packed_kernel, g, dim3(kBlock), 0, s, a.x, a.y, m.tileVals, m.tilePacked, m.tileHdr, m.tileHdrBaseHost[t], kb, ke,
-                               (int)((long long)t << m.tileShift), m.tileShift, a.doneFlag);
+                               (int)((long long)t * m.tileWidth), m.tileShift, a.doneFlag);
             continue;
         }
         if (tile_streams_nontemporal()) hipLaunchKernelGGL(spmv_tile_pass_kernel<true>, g, dim3(kBlock), 0, s, a.x, a.y, m.tileVals, m.tileCols, m.tileRowIds, kb, ke, a.doneFlag);
@@ -356,6 +356,9 @@ bool tiled_build(hipStream_t s, const double* elements, const int* rowOffsets, c
     { const int v = tuning().tileShift.load(std::memory_order_relaxed); if (v >= 8 && v <= 26) tileShift = v; }
     const long long tileCols = 1LL << tileShift;
     const int nTiles = (int)((columns + tileCols - 1) / tileCols);
+    // equal-width tiles (not the last one narrow): tile t = columns [t * tileWidth, (t + 1) * tileWidth), tileWidth <= 2^tileShift -- every tile
+    // then has the same share of a uniformly spread matrix, and the packed entries (below) fit in all of them
+    const int tileWidth = nTiles > 0 ? (int)((columns + nTiles - 1) / nTiles) : (int)tileCols;
     if (rows <= 0 || nnz <= 0 || nTiles < 4 || nTiles > 256) return true;            // x fits a few L2s, or absurdly many passes
     const long long cells = (long long)nTiles * rows;
     {   // the analysis needs 4 B per (tile, row) cell and the tiled copy 16 B per nonzero: decline rather than exhaust the device
@@ -372,17 +375,17 @@ bool tiled_build(hipStream_t s, const double* elements, const int* rowOffsets, c
     if (!ok) return fail(true);
     long long blocks = (rows + kBlock - 1) / kBlock;
     if (blocks > kMaxGrid) blocks = kMaxGrid;
-    hipLaunchKernelGGL(tiled_count_kernel, dim3((int)blocks), dim3(kBlock), 0, s, rowOffsets, columnIndeces, rows, rowBase, tileShift, nTiles, counts, stats);
+    hipLaunchKernelGGL(tiled_count_kernel, dim3((int)blocks), dim3(kBlock), 0, s, rowOffsets, columnIndeces, rows, rowBase, tileWidth, nTiles, counts, stats);
     unsigned long long hs[2] = { 0, 0 };
     ok = MGCG_HIP(hipMemcpyAsync(hs, stats, sizeof(hs), hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
     if (!ok) return fail(true);
     const double meanDistance = (double)hs[1] * 1024.0 / (double)nnz;
-    if (hs[0] != 0 || meanDistance < (double)tileCols) return fail(false);            // unsorted rows, or gathers that are local anyway
+    if (hs[0] != 0 || meanDistance < (double)tileWidth) return fail(false);            // unsorted rows, or gathers that are local anyway
     if (!exclusive_scan(s, counts, cells + 1)) return fail(true);
     ok = MGCG_HIP(hipMalloc((void**)&tv, sizeof(double) * (size_t)nnz)) && MGCG_HIP(hipMalloc((void**)&tc, sizeof(int) * (size_t)nnz)) &&
          MGCG_HIP(hipMalloc((void**)&tr, sizeof(int) * (size_t)nnz));
     if (!ok) return fail(true);
-    hipLaunchKernelGGL(tiled_scatter_kernel, dim3((int)blocks), dim3(kBlock), 0, s, elements, rowOffsets, columnIndeces, rows, tileShift, counts, tv, tc, tr);
+    hipLaunchKernelGGL(tiled_scatter_kernel, dim3((int)blocks), dim3(kBlock), 0, s, elements, rowOffsets, columnIndeces, rows, tileWidth, counts, tv, tc, tr);
     std::vector<int> starts((size_t)nTiles + 1, 0);                  // first entry of every tile = the flat scan at (tile, row 0)
     ok = MGCG_HIP(hipGetLastError());
     for (int t = 0; ok && t <= nTiles; ++t)
@@ -391,7 +394,7 @@ bool tiled_build(hipStream_t s, const double* elements, const int* rowOffsets, c
     if (!ok) return fail(true);
     if ((long long)starts[(size_t)nTiles] != nnz) { set_error("tiled analysis: %d of %lld nonzeros placed", starts[(size_t)nTiles], nnz); return fail(true); }
     (void)hipFree(stats); (void)hipFree(counts);
-    out->tileVals = tv; out->tileCols = tc; out->tileRowIds = tr; out->nTiles = nTiles; out->tileRows = rows; out->tileStart = starts; out->tileShift = tileShift;
+    out->tileVals = tv; out->tileCols = tc; out->tileRowIds = tr; out->nTiles = nTiles; out->tileRows = rows; out->tileStart = starts; out->tileShift = tileShift; out->tileWidth = tileWidth;
     // 12-byte entries: one packed word instead of column id + row id, when every row id fits next to the column offset (else the
     // 16-byte form above stays); MGCG_TILE_PACK=0 keeps the 16-byte form (A/B)
     if (tuning().tilePack.load(std::memory_order_relaxed) != 0 && tileShift <= 24) {
@@ -406,7 +409,7 @@ bool tiled_build(hipStream_t s, const double* elements, const int* rowOffsets, c
             const int kb = starts[(size_t)t], ke = starts[(size_t)t + 1];
             if (ke <= kb) continue;
             const long long nb = ((long long)ke - kb + kTilePack - 1) / kTilePack;
-            hipLaunchKernelGGL(tiled_pack_kernel, dim3((unsigned)(nb > kMaxGrid ? kMaxGrid : nb)), dim3(kBlock), 0, s, tc, tr, kb, ke, tileShift, tp, th, hdrBase[(size_t)t], ovf + t);
+            hipLaunchKernelGGL(tiled_pack_kernel, dim3((unsigned)(nb > kMaxGrid ? kMaxGrid : nb)), dim3(kBlock), 0, s, tc, tr, kb, ke, tileShift, (int)((long long)t * tileWidth), tp, th, hdrBase[(size_t)t], ovf + t);
         }
         pok = pok && MGCG_HIP(hipGetLastError()) && MGCG_HIP(hipMemcpyAsync(hovf.data(), ovf, sizeof(int) * (size_t)nTiles, hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
         if (ovf) (void)hipFree(ovf);
