@@ -97,11 +97,15 @@ __global__ __launch_bounds__(kBlock) void pass_v1(const double* __restrict__ x, 
         const int j = e * kBlock + (int)threadIdx.x;
         lead[e] = j < blockCount && s_r[j] != r[e];
         yv[e] = 0.0;
-        if (YEARLY && lead[e]) yv[e] = y[r[e]];
+        if (YEARLY == 1 && lead[e]) yv[e] = y[r[e]];
     }
     double xv[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) xv[e] = x[tileCol0 + (int)(pk[e] & colMask)];
+    if (YEARLY == 2) {                                             // y requested BEHIND the gathers: its latency overlaps the products and the barrier
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (lead[e]) yv[e] = y[r[e]];
+    }
 #pragma unroll
     for (int e = 0; e < E; ++e) { const int j = e * kBlock + (int)threadIdx.x; s_p[j] = v[e] * xv[e]; }
     __syncthreads();
@@ -122,6 +126,57 @@ __global__ __launch_bounds__(kBlock) void pass_v1(const double* __restrict__ x, 
             }
         }
         if (YMODE & 1) __builtin_nontemporal_store(acc, y + row); else y[row] = acc;
+    }
+}
+
+// ---------------------------------------------------------------- V1b: the production ordering (kernels_tiled.hip): one barrier, leaders found after it
+__global__ __launch_bounds__(kBlock) void pass_v1b(const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ tVals, const unsigned* __restrict__ tPacked,
+                                                   const int2* __restrict__ hdr, int hdrBase, int kBegin, int kEnd, int tileCol0, int shift, const int* __restrict__ doneFlag)
+{
+    __shared__ double s_p[kEnt];
+    __shared__ int s_r[kEnt + 1];
+    if (doneFlag != nullptr && *doneFlag != 0) return;
+    const int blockBase = kBegin + (int)blockIdx.x * kEnt;
+    const int blockCount = (kEnd - blockBase) < kEnt ? (kEnd - blockBase) : kEnt;
+    const int2 h = hdr[hdrBase + blockIdx.x];
+    const unsigned colMask = (1u << shift) - 1u;
+    double v[kTileE]; unsigned pk[kTileE]; int r[kTileE];
+#pragma unroll
+    for (int e = 0; e < kTileE; ++e) {
+        const int j = e * kBlock + (int)threadIdx.x;
+        const int k = blockBase + (j < blockCount ? j : 0);
+        v[e] = __builtin_nontemporal_load(tVals + k); pk[e] = __builtin_nontemporal_load(tPacked + k);
+    }
+#pragma unroll
+    for (int e = 0; e < kTileE; ++e) {
+        const int j = e * kBlock + (int)threadIdx.x;
+        r[e] = h.x + (int)(pk[e] >> shift);
+        s_r[j + 1] = j < blockCount ? r[e] : -2;
+    }
+    if (threadIdx.x == 0) s_r[0] = h.y;
+    double xv[kTileE];
+#pragma unroll
+    for (int e = 0; e < kTileE; ++e) xv[e] = x[tileCol0 + (int)(pk[e] & colMask)];
+#pragma unroll
+    for (int e = 0; e < kTileE; ++e) { const int j = e * kBlock + (int)threadIdx.x; s_p[j] = v[e] * xv[e]; }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < kTileE; ++e) {
+        const int j0 = e * kBlock + (int)threadIdx.x;
+        if (j0 >= blockCount || s_r[j0] == r[e]) continue;
+        const int row = r[e];
+        double acc = y[row];
+        int j = j0;
+        while (j < blockCount && s_r[j + 1] == row) { acc += s_p[j]; ++j; }
+        if (j == blockCount) {
+            for (int kk = blockBase + blockCount; kk < kEnd; ++kk) {
+                const int2 hn = hdr[hdrBase + (kk - kBegin) / kEnt];
+                const unsigned p = tPacked[kk];
+                if (hn.x + (int)(p >> shift) != row) break;
+                const double q = tVals[kk] * x[tileCol0 + (int)(p & colMask)]; acc += q;
+            }
+        }
+        y[row] = acc;
     }
 }
 
@@ -294,6 +349,13 @@ int main(int argc, char** argv)
 #define V2(E, G) [&] { hipLaunchKernelGGL(zero_kernel, dim3(2048), dim3(256), 0, 0, dy, rows); \
         for (int t = 0; t < T; ++t) { const int kb = tileStart[(size_t)t], ke = tileStart[(size_t)t + 1]; if (ke <= kb) continue; const int nb = (ke - kb + kBlock * E - 1) / (kBlock * E); \
             pass_v2<E><<<dim3(nb < (G) ? nb : (G)), dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t << shift, shift, nb); } }
+    run("V1 12 B entries, y requested behind the gathers", V1(2), true);
+    run("V1b production ordering (one barrier)", PASSES(pass_v1b<<<g, dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t << shift, shift, (const int*)nullptr)), true);
+    {   // the same with 8 GB of other allocations alive (the product holds the CSR arrays next to the tiled copy)
+        void* extra = nullptr; CK(hipMalloc(&extra, 8ull << 30)); CK(hipMemset(extra, 1, 8ull << 30));
+        run("V1b with 8 GB of other allocations alive", PASSES(pass_v1b<<<g, dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t << shift, shift, (const int*)nullptr)), true);
+        CK(hipFree(extra));
+    }
     run("V2 persistent, next block prefetched, 2048 wgs", V2(4, 2048), true);
 #define V1E(E, NT) [&] { hipLaunchKernelGGL(zero_kernel, dim3(2048), dim3(256), 0, 0, dy, rows); \
         for (int t = 0; t < T; ++t) { const int kb = tileStart[(size_t)t], ke = tileStart[(size_t)t + 1]; if (ke <= kb) continue; const dim3 g((ke - kb + kBlock * E - 1) / (kBlock * E)); \
