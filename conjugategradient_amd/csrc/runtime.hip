@@ -199,8 +199,12 @@ const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* 
     const bool automatic = h->compression == 0;
     if (automatic) {
         const long long tileCols = 1LL << 19;
-        if (autoMeanDistance < tileCols || columns < 8 * tileCols || nnz < (4LL << 20) || rows <= 0 || nnz > 48 * rows ||
-            tuning().autoTiles.load(std::memory_order_relaxed) == 0 || tuning().tileShift.load(std::memory_order_relaxed) != 0) return nullptr;
+        const bool take = !(autoMeanDistance < tileCols || columns < 8 * tileCols || nnz < (4LL << 20) || rows <= 0 || nnz > 64 * rows ||
+                            tuning().autoTiles.load(std::memory_order_relaxed) == 0 || tuning().tileShift.load(std::memory_order_relaxed) != 0);
+        if (tuning().verbose.load(std::memory_order_relaxed) >= 2 && autoMeanDistance >= 0)
+            fprintf(stderr, "[MgcgGpu] column tiles by the library's choice: %s (rows %lld, columns %lld, nnz %lld, sampled distance %lld)\n",
+                    take ? "considered" : "no", rows, columns, nnz, autoMeanDistance);
+        if (!take) return nullptr;
     }
     DcsrMatrix* m = nullptr;
     for (DcsrMatrix* q : h->analysed)

@@ -15,6 +15,7 @@
 #pragma once
 #include <atomic>
 #include <chrono>
+#include <algorithm>
 #include <cmath>
 #include <condition_variable>
 #include <functional>
@@ -224,6 +225,8 @@ public:
 class ConjugateGradientParallelGpu : public ConjugateGradientGpu {
 public:
     bool UsePhases = false;
+    bool BalanceNonzeros = false;        // not in the reference: row ranges of equal NONZERO count instead of floor(count / devices) rows, chosen at
+                                         // Initialize() from A's row offsets (a matrix with uneven rows: the slowest device sets the iteration time)
     std::string LastPath = "none";       // "native loop (SolveParallel over <transport>)" or "host-driven phases (Solve0..3)"
 private:
     int deviceCount;
@@ -285,8 +288,30 @@ public:
         }
     }
     int DeviceCount() const { return deviceCount; }
+    int OffsetForDevice(int d) const { return offsetsForDevice[(size_t)d]; }
     void Initialize() override
     {
+        if (BalanceNonzeros) {
+            const int n = Count();
+            std::vector<int> off((size_t)deviceCount + 1, 0);
+            const long long first = A->RowOffsets[0], nnz = (long long)A->RowOffsets[(size_t)n] - first;
+            for (int r = 1; r < deviceCount; r++) {           // the first row whose offset reaches r / devices of the nonzeros
+                const int target = (int)(first + (long long)r * nnz / deviceCount);
+                const int cut = (int)(std::lower_bound(A->RowOffsets.begin(), A->RowOffsets.begin() + n + 1, target) - A->RowOffsets.begin());
+                off[(size_t)r] = std::max(std::min(cut, n), off[(size_t)r - 1]);
+            }
+            off[(size_t)deviceCount] = n;
+            const std::vector<int> old = offsetsForDevice;
+            offsetsForDevice = off;
+            ParallelFor([&](int d) {
+                const size_t i = (size_t)d; const int c = CountForDevice(d);
+                if (c == old[i + 1] - old[i]) return;
+                delete vectorElements[i]; delete vectorColumnIndeces[i]; delete vectorRowOffsets[i]; delete vectorX[i]; delete vectorB[i]; delete vectorAp[i]; delete vectorR[i];
+                const int e = std::max(ElementCount(d), 1);
+                vectorElements[i] = new VectorDouble(e); vectorColumnIndeces[i] = new VectorInt(e); vectorRowOffsets[i] = new VectorInt(c + 1);
+                vectorX[i] = new VectorDouble(c); vectorB[i] = new VectorDouble(c); vectorAp[i] = new VectorDouble(c); vectorR[i] = new VectorDouble(c);
+            });
+        }
         ParallelFor([&](int d) {
             const size_t i = (size_t)d;
             ::Initialize(A->Elements.data(), A->RowOffsets.data(), A->ColumnIndeces.data(), x.data(), b.data(),

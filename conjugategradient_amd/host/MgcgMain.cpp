@@ -5,7 +5,7 @@
 // compared with each other here and tests/test_gpu_host_cpp.py compares the printed solution
 // checksum with the CPU oracle.
 //
-//   MgcgMain [COUNT] [MIN_ITERATION] [phases]      (defaults: 34567*6 and 200, the reference's constants)
+//   MgcgMain [COUNT] [MIN_ITERATION] [phases] [balance]      (defaults: 34567*6 and 200, the reference's constants)
 // The multi-device solver runs twice: on the reference's host-driven phases (Solve0..3, P2Host / P2Device) and on the native
 // loop (SolveParallel on every device's own thread, collectives on the device streams); which path produced the kept answer
 // is printed ("phases" as third argument keeps the phase structure for it).
@@ -28,7 +28,11 @@ int main(int argc, char** argv)
     const int MIN_ITERATION = argc > 2 ? atoi(argv[2]) : 200;           // :25
     const int MAX_ITERATION = COUNT;                                    // :30
     const double ALLOWABLE_RESIDUAL = 1e-8;                             // :35
-    const bool usePhasesOnly = argc > 3 && std::string(argv[3]) == "phases";   // keep the reference's phase structure for the kept answer too
+    bool usePhasesOnly = false, balance = false;
+    for (int i = 3; i < argc; i++) {
+        if (std::string(argv[i]) == "phases") usePhasesOnly = true;           // keep the reference's phase structure for the kept answer too
+        if (std::string(argv[i]) == "balance") balance = true;                // row ranges of equal nonzero count (BalanceNonzeros) instead of equal row count
+    }
     printf("N=%d\n", COUNT);
     try {
         ConjugateGradientSingleGpu cgGpuSingle(COUNT, MAX_NONZERO_COUNT, MIN_ITERATION, MAX_ITERATION, ALLOWABLE_RESIDUAL);
@@ -54,6 +58,7 @@ int main(int argc, char** argv)
         }
         cgGpuSingle.A = &A;
         cgGpuParallel.A = &A;
+        cgGpuParallel.BalanceNonzeros = balance;
         for (int i = 0; i < COUNT; i++) {                               // :91-104
             const double b_i = std::cos((double)i) * 10;
             const double x_i = (double)i / 100;
@@ -102,10 +107,13 @@ int main(int argc, char** argv)
                1e6 * parallelSec / std::max(1, cgGpuParallel.Iteration), cgGpuParallel.DeviceCount(), cgGpuParallel.LastPath.c_str());
         printf("   (phases) : %12.6f s / %d = %12.3f us per iteration -- host-driven phases (Solve0..3), the reference's structure\n", phasesSec, phasesIteration,
                1e6 * phasesSec / std::max(1, phasesIteration));
-        printf("{\"count\": %d, \"devices\": %d, \"iteration_single\": %d, \"iteration_parallel\": %d, \"iteration_phases\": %d, \"residual_single\": %.17g, "
+        std::string offsets = "[";
+        for (int d = 0; d <= cgGpuParallel.DeviceCount(); d++) offsets += (d ? ", " : "") + std::to_string(cgGpuParallel.OffsetForDevice(d));
+        offsets += "]";
+        printf("{\"offsets\": %s, \"count\": %d, \"devices\": %d, \"iteration_single\": %d, \"iteration_parallel\": %d, \"iteration_phases\": %d, \"residual_single\": %.17g, "
                "\"residual_parallel\": %.17g, \"mismatches\": %d, \"max_rel_single_vs_parallel\": %.3e, \"max_rel_phases_vs_parallel\": %.3e, \"checksum\": %.17g, \"x0\": %.17g, \"xlast\": %.17g, "
                "\"parallel_path\": \"%s\", \"us_per_iteration_single\": %.3f, \"us_per_iteration_parallel\": %.3f, \"us_per_iteration_phases\": %.3f}\n",
-               COUNT, cgGpuParallel.DeviceCount(), cgGpuSingle.Iteration, cgGpuParallel.Iteration, phasesIteration, cgGpuSingle.Residual, cgGpuParallel.Residual,
+               offsets.c_str(), COUNT, cgGpuParallel.DeviceCount(), cgGpuSingle.Iteration, cgGpuParallel.Iteration, phasesIteration, cgGpuSingle.Residual, cgGpuParallel.Residual,
                mismatches, maxRel, maxRelPhases, checksum, cgGpuSingle.x[0], cgGpuSingle.x[(size_t)COUNT - 1],
                cgGpuParallel.LastPath.c_str(), 1e6 * singleSec / std::max(1, cgGpuSingle.Iteration), 1e6 * parallelSec / std::max(1, cgGpuParallel.Iteration),
                1e6 * phasesSec / std::max(1, phasesIteration));

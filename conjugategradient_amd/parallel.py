@@ -44,8 +44,8 @@ class RankPartition:
     maxJ: int = -1
 
     @classmethod
-    def of(cls, Count: int, world: int, rank: int, RowOffsets=None):
-        off = partition_offsets(Count, world)
+    def of(cls, Count: int, world: int, rank: int, RowOffsets=None, balance: str = "rows"):
+        off = partition_offsets(Count, world, RowOffsets, balance)
         p = cls(rank, world, Count, off[rank], off[rank + 1] - off[rank])
         if RowOffsets is not None:
             p.elementOffset = int(RowOffsets[off[rank]])
@@ -170,10 +170,11 @@ class ConjugateGradientRankGpu(ConjugateGradientGpu):
     this rank's slice of ``x``."""
 
     def __init__(self, count, maxNonZeroCount, _minIteration, _maxIteration, allowableResidual,
-                 rank: int = 0, world: int = 1, comm=None, rule=_lib.RULE_CSHARP, device: int | None = None):
+                 rank: int = 0, world: int = 1, comm=None, rule=_lib.RULE_CSHARP, device: int | None = None, balance: str = "rows"):
         super().__init__(count, maxNonZeroCount, _minIteration, _maxIteration, allowableResidual)
         _lib.require_gpu()
         self.rank, self.world, self.rule = rank, world, rule
+        self.balance = balance                  # "rows": the reference's partition; "nnz": equal nonzero counts (problems.partition_offsets)
         self.SetDevice(rank % _lib.device_count() if device is None else device)
         self.comm = comm
         self._own_comm = False
@@ -220,7 +221,13 @@ class ConjugateGradientRankGpu(ConjugateGradientGpu):
 
     def Initialize(self):
         """Upload this rank's partition from the host arrays (A, x, b), as :358-379 does per device."""
-        p = RankPartition.of(self.Count, self.world, self.rank, self.A.RowOffsets)
+        p = RankPartition.of(self.Count, self.world, self.rank, self.A.RowOffsets, self.balance)
+        if p.count != self.part.count:          # (a partition that follows the matrix is only known now)
+            for name in ("vectorX", "vectorB", "vectorAp", "vectorR"):
+                getattr(self, name).Dispose()
+                setattr(self, name, VectorDouble(p.count))
+            self.vectorRowOffsets.Dispose()
+            self.vectorRowOffsets = VectorInt(p.count + 1)
         self.vectorElements = VectorDouble(max(p.elementCount, 1))
         self.vectorColumnIndeces = VectorInt(max(p.elementCount, 1))
         mn, mx = C.c_int(0), C.c_int(0)

@@ -203,11 +203,27 @@ def random_spd(n: int, mean_upper: float = 14.0, seed: int = 12345, sort_columns
                         np.zeros(n), b, f"random_spd{n}")
 
 
-def partition_offsets(count: int, device_count: int) -> list[int]:
+def partition_offsets(count: int, device_count: int, row_offsets=None, balance: str = "rows") -> list[int]:
     """Row-range partition of Mgcg/cuBlas/Mgcg/ConjugateGradientParallelGpu.cs:271-277:
-    floor(count/device_count) rows each, the last device takes the remainder."""
+    floor(count/device_count) rows each, the last device takes the remainder.
+    balance="nnz" (not in the reference; needs row_offsets): row ranges of equal NONZERO count instead -- rank r starts at the first
+    row whose offset reaches r/devices of the nonzeros.  For a matrix with uneven rows (BASELINE config 5: the last of eight
+    row-count slabs holds 3.7 times the nonzeros of the first) the slowest rank sets the iteration time."""
     import math
 
+    if balance == "nnz":
+        if row_offsets is None:
+            raise ValueError("balance='nnz' needs the row offsets")
+        ro = np.asarray(row_offsets)
+        nnz = int(ro[count]) - int(ro[0])
+        targets = int(ro[0]) + (np.arange(1, device_count, dtype=np.int64) * nnz) // device_count
+        cuts = np.searchsorted(ro[: count + 1], targets, side="left")
+        off = [0] + [int(min(max(c, 0), count)) for c in cuts] + [count]
+        for i in range(1, device_count + 1):                  # monotone (empty ranks only when there are fewer rows than ranks)
+            off[i] = max(off[i], off[i - 1])
+        return off
+    if balance != "rows":
+        raise ValueError("balance must be 'rows' or 'nnz'")
     off = [0] * (device_count + 1)
     for i in range(1, device_count):
         off[i] = off[i - 1] + int(math.floor(float(count) / device_count))

@@ -249,13 +249,31 @@ void oracle_minmax_column(const int *columnIndeces, const int *rowOffsets,
  * numerically identical; what differs from oracle_cg is the association of the
  * dot-product sums.  Stop rule: ConjugateGradient.cs:56-79.
  */
+int oracle_cg_parallel_offsets(const double *elements, const int *columnIndeces, const int *rowOffsets,
+                               int64_t count, int deviceCount, const int64_t *offsets, double *x, const double *b,
+                               double allowableResidual, int minIteration, int maxIteration,
+                               int *iteration, double *residual, double *trace, int64_t traceCap);
+
 int oracle_cg_parallel(const double *elements, const int *columnIndeces, const int *rowOffsets,
                        int64_t count, int deviceCount, double *x, const double *b,
                        double allowableResidual, int minIteration, int maxIteration,
                        int *iteration, double *residual, double *trace, int64_t traceCap)
 {
     int64_t *off = (int64_t *)malloc(sizeof(int64_t) * (size_t)(deviceCount + 1));
-    oracle_partition(count, deviceCount, off);
+    oracle_partition(count, deviceCount, off);                   /* the reference's rule: floor(count / devices) rows each */
+    int st = oracle_cg_parallel_offsets(elements, columnIndeces, rowOffsets, count, deviceCount, off, x, b,
+                                        allowableResidual, minIteration, maxIteration, iteration, residual, trace, traceCap);
+    free(off);
+    return st;
+}
+
+/* The same loop over ANY row-range partition offsets[0..deviceCount] (the reference only has the one above; the product also offers
+ * slabs of equal nonzero count, which changes nothing but where the partial dot-product sums are cut). */
+int oracle_cg_parallel_offsets(const double *elements, const int *columnIndeces, const int *rowOffsets,
+                               int64_t count, int deviceCount, const int64_t *off, double *x, const double *b,
+                               double allowableResidual, int minIteration, int maxIteration,
+                               int *iteration, double *residual, double *trace, int64_t traceCap)
+{
     double *r = (double *)malloc(sizeof(double) * 3 * (size_t)count);
     double *p = r + count, *Ap = r + 2 * count;
     int status = ORACLE_OK;
@@ -317,7 +335,7 @@ int oracle_cg_parallel(const double *elements, const int *columnIndeces, const i
     }
     *iteration = it;
     *residual = res;
-    free(r); free(off);
+    free(r);
     return status;
 }
 

@@ -54,6 +54,9 @@ def lib():
         L.oracle_cg_parallel.argtypes = [_dp, _ip, _ip, C.c_int64, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int,
                                          C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p, C.c_int64]
         L.oracle_cg_parallel.restype = C.c_int
+        L.oracle_cg_parallel_offsets.argtypes = [_dp, _ip, _ip, C.c_int64, C.c_int, _lp, _dp, _dp, C.c_double, C.c_int, C.c_int,
+                                                 C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p, C.c_int64]
+        L.oracle_cg_parallel_offsets.restype = C.c_int
         L.oracle_poisson_nnz.argtypes = [C.c_int, C.c_int, C.c_int]
         L.oracle_poisson_nnz.restype = C.c_int64
         L.oracle_poisson_fill.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _ip, _ip]
@@ -144,7 +147,8 @@ def cg(system, rule=RULE_CSHARP, allowable_residual=1e-8, min_iteration=0, max_i
     return out
 
 
-def cg_parallel(system, device_count, allowable_residual=1e-8, min_iteration=0, max_iteration=None, trace=False):
+def cg_parallel(system, device_count, allowable_residual=1e-8, min_iteration=0, max_iteration=None, trace=False, offsets=None):
+    """offsets: device_count + 1 row offsets of another row-range partition than the reference's floor(count / devices)."""
     n = system.Count
     x = _f(system.x).copy()
     max_iteration = n if max_iteration is None else max_iteration
@@ -152,9 +156,16 @@ def cg_parallel(system, device_count, allowable_residual=1e-8, min_iteration=0, 
     res = C.c_double(0)
     cap = max_iteration + 3
     tr = np.zeros(cap) if trace else None
-    st = lib().oracle_cg_parallel(_f(system.Elements), _i(system.ColumnIndeces), _i(system.RowOffsets), n, device_count,
-                                  x, _f(system.b), allowable_residual, min_iteration, max_iteration,
-                                  C.byref(it), C.byref(res), tr.ctypes.data if trace else None, cap if trace else 0)
+    if offsets is None:
+        st = lib().oracle_cg_parallel(_f(system.Elements), _i(system.ColumnIndeces), _i(system.RowOffsets), n, device_count,
+                                      x, _f(system.b), allowable_residual, min_iteration, max_iteration,
+                                      C.byref(it), C.byref(res), tr.ctypes.data if trace else None, cap if trace else 0)
+    else:
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        assert off.shape == (device_count + 1,) and off[0] == 0 and off[-1] == n and np.all(np.diff(off) >= 0)
+        st = lib().oracle_cg_parallel_offsets(_f(system.Elements), _i(system.ColumnIndeces), _i(system.RowOffsets), n, device_count, off,
+                                              x, _f(system.b), allowable_residual, min_iteration, max_iteration,
+                                              C.byref(it), C.byref(res), tr.ctypes.data if trace else None, cap if trace else 0)
     out = dict(x=x, iteration=it.value, residual=res.value, status=st)
     if trace:
         out["trace"] = tr[: it.value + 1].copy()

@@ -145,9 +145,12 @@ def test_config3_mgcg_at_full_size():
     mg.Dispose()
 
 
-def test_config4_rank_slabs_at_full_size(mgcg_env):
-    """BASELINE config 4's per-rank problem at true size on ONE GPU: 512 x 512 z-slabs of 32 planes, three loopback ranks
-    (the middle one has a halo plane on BOTH sides, as six of the eight ranks of the 8-GPU run have), 3-level V(1,1) MGCG.
+@pytest.mark.parametrize("world,nz", [(3, 96), (8, 512)])
+def test_config4_rank_slabs_at_full_size(mgcg_env, world, nz):
+    """BASELINE config 4 on ONE GPU.  (3, 96): its per-rank problem, 512 x 512 z-slabs of 32 planes on three loopback ranks (the
+    middle one has a halo plane on BOTH sides, as six of the eight ranks of the 8-GPU run have).  (8, 512): the configuration AS
+    STATED -- 7-point Poisson 512^3 row-partitioned over EIGHT ranks (slabs of 64 planes = 16.8 M rows each), every rank a host
+    thread on a virtual device of the one card, joined by the loopback transport where the 8-GPU node has RCCL.  3-level V(1,1) MGCG.
     Properties (no oracle can run 25 M rows in seconds): the partitioned solve takes exactly as many iterations as the
     single-domain solve of the same grid and agrees with it, the preconditioner is independent of the partition bit for bit,
     and the reported recurrence residual equals ||b - A x|| recomputed from the gathered x."""
@@ -155,7 +158,7 @@ def test_config4_rank_slabs_at_full_size(mgcg_env):
     from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu
     from tests.test_gpu_parallel import _run_ranks_in_threads
 
-    world, nx, nz = 3, 512, 96
+    nx = 512
     dims = (nx, nx, nz)
     N = nx * nx * nz
     L = _lib.lib()
@@ -278,3 +281,75 @@ def test_config5_at_full_size(oracle):
     for v in (dx, dy):
         v.Dispose()
     cg.Dispose()
+
+
+@pytest.mark.parametrize("balance", ["rows", "nnz"])
+def test_config5_eight_rank_leg_at_full_size(oracle, mgcg_env, balance):
+    """BASELINE config 5's 8-GPU leg at true size on ONE GPU: the 10 M-row random SPD matrix row-partitioned over eight loopback
+    ranks (nearly every x entry of the other seven ranks is in a rank's halo, since the columns are uniform), plain CG against a
+    manufactured solution.  balance="rows": the reference's partition, 1.25 M rows each -- 21 M to 78 M nonzeros per rank, because this
+    generator's rows grow with the row number; "nnz": row ranges of 38.7 M nonzeros each (problems.partition_offsets).  Checked: the same iteration count (+-1) and answer as the single-domain solve, identical
+    all-reduced residual bits on every rank, ||b - A x|| recomputed by the oracle's product from the gathered x, and that each
+    rank's slab (1.25 M x 10 M) took the column tiles the library builds for matrices without locality."""
+    import conjugategradient_amd.problems as problems
+    from conjugategradient_amd.solver import ConjugateGradientSingleGpu, VectorInt
+    from tests.test_gpu_parallel import _run_ranks_in_threads
+
+    world = 8
+    s = problems.random_spd(10_000_000, mean_upper=14.0, seed=12345)
+    N, nnz = s.Count, s.nnz
+    maxnz = int(np.diff(s.RowOffsets).max())
+    L = _lib.lib()
+    xs = np.cos(np.arange(N) * 0.01)
+    ref = oracle.spmv(s.Elements, s.ColumnIndeces, s.RowOffsets, xs)
+    s.b[:] = ref + 2.0                                       # A.(xs + 2) = ref + 2 (row sums are 1)
+    s.x[:] = 0.0
+    # single domain
+    cg = ConjugateGradientSingleGpu(N, maxnz, 0, 1000, 1e-8, rule=_lib.RULE_CSHARP)
+    cg.A = type("M", (), {})()
+    cg.A.Elements, cg.A.ColumnIndeces, cg.A.RowOffsets = s.Elements, s.ColumnIndeces, s.RowOffsets
+    cg.vectorA.Dispose(); cg.vectorColumnIndeces.Dispose()
+    cg.vectorA, cg.vectorColumnIndeces = VectorDouble(nnz), VectorInt(nnz)
+    cg.x[:] = 0.0
+    cg.b[:] = s.b
+    cg.Initialize()
+    cg.Solve()
+    cg.Read()
+    it1, res1, x1 = cg.Iteration, cg.Residual, cg.x.copy()
+    cg.Dispose()
+    assert 20 < it1 < 1000 and res1 < 1e-8
+
+    mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+
+    def make_rank(rank, comm):
+        rk = ConjugateGradientRankGpu(N, maxnz, 0, 1000, 1e-8, rank=rank, world=world, comm=comm, device=rank, balance=balance).load(s)
+        rk.Initialize()
+        if balance == "rows":
+            assert rk.part.count == N // world
+        else:
+            assert abs(rk.part.elementCount - nnz / world) <= maxnz
+        L.MgcgSetMatrixCompression(rk.cusparse, 0)
+        rk.Solve()
+        form = L.MgcgAnalysisInfo(rk.cusparse, 0, None, None, None, None)
+        rk.Read()
+        off, cnt = rk.part.offset, rk.part.count
+        out = (off, cnt, rk.x[off: off + cnt].copy(), rk.Iteration, rk.Residual, form, rk.part.elementCount / cnt)
+        rk.Dispose()
+        return out
+
+    res = _run_ranks_in_threads(world, make_rank)
+    x = np.empty(N)
+    for off, cnt, xr, it, resid, form, per_row in res:
+        x[off: off + cnt] = xr
+        assert abs(it - it1) <= 1, (it, it1)
+        assert it == res[0][3] and resid == res[0][4]        # one stop decision, the same all-reduced bits everywhere
+        # the slab took the column tiles (12-byte entries) -- up to 64 nonzeros per row; beyond (the last slab of the equal-nonzero
+        # partition has 76) 32 lanes per row are as fast and nothing is built
+        assert form == (4 if per_row <= 64 else -1), (form, per_row)
+    assert sum(1 for r in res if r[5] == 4) >= world - 1
+    assert res[0][4] < 1e-8
+    assert np.abs(x - (xs + 2.0)).max() <= 1e-7
+    assert np.abs(x - x1).max() <= 1e-8
+    r = s.b - oracle.spmv(s.Elements, s.ColumnIndeces, s.RowOffsets, x)
+    true_res = float(np.sqrt(np.dot(r, r)))
+    assert abs(true_res - res[0][4]) <= 0.05 * res[0][4] + 1e-10, (true_res, res[0][4])

@@ -13,16 +13,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "conjugategradient_amd", "host", "MgcgMain")
 
 
-@pytest.mark.parametrize("devices", [1, 3])
-def test_mgcg_main_driver(oracle, devices):
+@pytest.mark.parametrize("devices,balance", [(1, False), (3, False), (3, True)])
+def test_mgcg_main_driver(oracle, devices, balance):
     if not os.path.exists(EXE):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(EXE)])
     count, min_it = 20003, 40
     env = dict(os.environ, MGCG_VIRTUAL_DEVICES=str(devices))
-    out = subprocess.run([EXE, str(count), str(min_it)], env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([EXE, str(count), str(min_it)] + (["balance"] if balance else []), env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     s = problems.mgcg_main(count, 160)
+    # BalanceNonzeros (not in the reference): the C++ class cuts where problems.partition_offsets(..., "nnz") does -- the short rows at both
+    # ends of the band move the cuts off floor(count / devices)
+    assert rec["offsets"] == problems.partition_offsets(count, devices, s.RowOffsets, "nnz" if balance else "rows")
+    if balance:
+        assert rec["offsets"] != problems.partition_offsets(count, devices)
     ref = oracle.cg(s, rule=oracle.RULE_NATIVE, min_iteration=min_it, max_iteration=count, hard_cap=count + 5)
     assert rec["devices"] == devices
     assert rec["iteration_single"] == ref["iteration"] == rec["iteration_parallel"] == rec["iteration_phases"] == min_it

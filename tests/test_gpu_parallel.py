@@ -349,6 +349,42 @@ def test_native_multirank_loop_over_loopback(oracle, mgcg_env, world, which, ove
     assert np.abs(x - ref["x"]).max() <= xtol * np.abs(ref["x"]).max()
 
 
+@pytest.mark.parametrize("world", [3, 8])
+def test_partition_of_equal_nonzero_counts_over_loopback(oracle, mgcg_env, world):
+    """balance="nnz" (row ranges of equal nonzero count, not in the reference): ranks of different row counts through the same
+    SolveParallel, against the multi-device oracle cut at the same offsets."""
+    mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    s = problems.random_spd(1500, mean_upper=6.0, seed=21)
+    s.b[:] = np.cos(np.arange(s.Count) * 0.7) * (1.0 + np.arange(s.Count) % 5)
+    off = problems.partition_offsets(s.Count, world, s.RowOffsets, "nnz")
+    assert off != problems.partition_offsets(s.Count, world)
+    ref = oracle.cg_parallel(s, world, max_iteration=s.Count, trace=True, offsets=off)
+    maxnz = int(np.diff(s.RowOffsets).max())
+
+    def make_rank(rank, comm):
+        cg = ConjugateGradientRankGpu(s.Count, maxnz, 0, s.Count, 1e-8, rank=rank, world=world, comm=comm, device=rank, balance="nnz").load(s)
+        cg.Initialize()
+        assert (cg.part.offset, cg.part.count) == (off[rank], off[rank + 1] - off[rank])
+        assert (cg.part.minJ, cg.part.maxJ) == oracle.minmax_column(s, off[rank], off[rank + 1])
+        cg.Solve(trace=True)
+        cg.Read()
+        out = (cg.part.offset, cg.part.count, cg.x[cg.part.offset: cg.part.offset + cg.part.count].copy(), cg.Iteration, cg.Residual, cg.trace, cg.part.elementCount)
+        cg.Dispose()
+        return out
+
+    res = _run_ranks_in_threads(world, make_rank)
+    x = np.zeros(s.Count)
+    from tests.gpu_util import assert_trace_close
+    for o, cnt, xs, it, resid, tr, nnz in res:
+        x[o: o + cnt] = xs
+        assert it == ref["iteration"] and resid == res[0][4]
+        assert_trace_close(tr, ref["trace"], loose=1.0)
+        assert abs(nnz - s.nnz / world) <= maxnz
+    # (this random system's iterates are chaotic below 1e-6 r0 even between two ORACLE partitions, see test_native_multirank_loop_over_loopback:
+    #  1.2e-10 at the stopping index here; the systems with structure meet the 1e-10 of the north star)
+    assert np.abs(x - ref["x"]).max() <= 5e-10 * np.abs(ref["x"]).max()
+
+
 @pytest.mark.parametrize("world,dims,levels,interpolation", [(2, (8, 8, 16), 3, 0), (4, (16, 8, 16), 2, 0), (2, (12, 12, 8), 3, 0),
                                                             (2, (8, 8, 16), 3, 1), (4, (16, 8, 16), 2, 1), (3, (8, 4, 24), 3, 1),
                                                             (8, (16, 16, 64), 3, 0), (8, (16, 16, 64), 3, 1)])   # config 4's shape: 8 z-slabs, 3 levels

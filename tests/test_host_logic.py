@@ -17,6 +17,28 @@ def test_partition_matches_reference_formula():
         assert off[0] == 0 and off[-1] == n and all(b >= a for a, b in zip(off, off[1:]))
 
 
+def test_partition_of_equal_nonzero_counts():
+    """balance="nnz" (not in the reference): contiguous row ranges, every rank within one row's length of nnz / ranks."""
+    s = problems.random_spd(3000, mean_upper=6.0, seed=5)          # rows get longer towards the end of this generator's matrices
+    ro = s.RowOffsets
+    longest = int(np.diff(ro).max())
+    for w in (1, 2, 3, 8):
+        off = problems.partition_offsets(s.Count, w, ro, "nnz")
+        assert off[0] == 0 and off[-1] == s.Count and len(off) == w + 1 and all(b >= a for a, b in zip(off, off[1:]))
+        per = [int(ro[off[r + 1]] - ro[off[r]]) for r in range(w)]
+        assert sum(per) == s.nnz and max(abs(v - s.nnz / w) for v in per) <= longest
+        parts = [RankPartition.of(s.Count, w, r, ro, "nnz") for r in range(w)]
+        assert [p.offset for p in parts] == off[:-1] and [p.elementCount for p in parts] == per
+    rows = problems.partition_offsets(s.Count, 8)
+    per_rows = [int(ro[rows[r + 1]] - ro[rows[r]]) for r in range(8)]
+    assert max(per_rows) > 1.5 * s.nnz / 8                          # what the option is for
+    assert problems.partition_offsets(5, 8, np.arange(6) * 3, "nnz")[-1] == 5      # fewer rows than ranks: empty ranks, still monotone
+    with pytest.raises(ValueError):
+        problems.partition_offsets(10, 2, None, "nnz")
+    with pytest.raises(ValueError):
+        problems.partition_offsets(10, 2, None, "columns")
+
+
 def test_rank_partition_halo_widths():
     s = problems.mgcg_main(1000, 160)
     ro = s.RowOffsets

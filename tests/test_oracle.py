@@ -137,6 +137,12 @@ def test_partition_and_parallel_oracle(oracle):
         np.testing.assert_allclose(par["x"], serial["x"], rtol=1e-10, atol=1e-13)
     one = oracle.cg_parallel(s, 1, max_iteration=1200)
     assert np.array_equal(one["x"], serial["x"])       # one device == the serial order exactly
+    # explicit offsets: the reference's own partition gives the same bits; another row-range partition only re-cuts the dot-product sums
+    same = oracle.cg_parallel(s, 3, max_iteration=1200, offsets=problems.partition_offsets(s.Count, 3))
+    assert np.array_equal(same["x"], oracle.cg_parallel(s, 3, max_iteration=1200)["x"])
+    other = oracle.cg_parallel(s, 3, max_iteration=1200, offsets=[0, 100, 1000, 1200])
+    assert other["iteration"] == serial["iteration"]
+    np.testing.assert_allclose(other["x"], serial["x"], rtol=1e-10, atol=1e-13)
 
 
 def test_oracle_asan_build_runs():
