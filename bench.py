@@ -184,12 +184,17 @@ def vcycle_bytes(n: int, levels: int, nu: int, nu_coarse: int):
     return total, shell
 
 
+FOLD_UP_MAX_ROWS = 100_000_000      # csrc/solver.hip kFoldUpMaxRows
+
+
 def vcycle_required_bytes(n: int, levels: int, nu: int, nu_coarse: int, fold: bool = True):
     """Bytes that MUST move per MGCG iteration on the 7-point n^3 hierarchy as the library runs it (constant-coefficient operator:
     every level's diagonal is uniform, so D^-1 is a scalar and its array is not read): sweep = 12 nnz + 4 (N + 1) + 24 N (x gathered once,
     b, x written), first sweep from zero = 16 N, residual = 12 nnz + 4 (N + 1) + 24 N, restriction = 8 N + 8 N_c, prolongation = 16 N + 8 N_c
     (it reads and rewrites the fine iterate).  fold (V(1,*) on one rank): the first sweep is not stored -- 0 bytes -- and the residual pass
-    gathers b itself: 12 nnz + 4 (N + 1) + 16 N.  Returns (V-cycle bytes, CG shell bytes)."""
+    gathers b itself: 12 nnz + 4 (N + 1) + 16 N.  V(1,1), power-of-two n, levels of up to FOLD_UP_MAX_ROWS rows: the prolongation is folded
+    into the post-smoothing sweep as well -- no prolongation pass, and that sweep moves 12 nnz + 4 (N + 1) + 16 N + 8 N_c.
+    Returns (V-cycle bytes, CG shell bytes)."""
     def nnz(m):
         return 7 * m**3 - 6 * m * m
     total = 0
@@ -204,8 +209,12 @@ def vcycle_required_bytes(n: int, levels: int, nu: int, nu_coarse: int, fold: bo
             folded = fold and nu == 1
             total += (0 if folded else 16 * N) + (nu - 1) * sweep
             total += 12 * nnz(m) + 4 * (N + 1) + (16 * N if folded else 24 * N)
-            total += (8 * N + 8 * Nc) + (16 * N + 8 * Nc)
-            total += nu * sweep
+            fold_up = folded and N <= FOLD_UP_MAX_ROWS and m >= 2 and (m & (m - 1)) == 0
+            total += 8 * N + 8 * Nc
+            if fold_up:
+                total += 12 * nnz(m) + 4 * (N + 1) + 16 * N + 8 * Nc
+            else:
+                total += (16 * N + 8 * Nc) + nu * sweep
         m //= 2
     N0 = n**3
     shell = 12 * nnz(n) + 4 * (N0 + 1) + 16 * N0 + 72 * N0
@@ -228,7 +237,8 @@ def mgcg_extra(L, n: int):
            "required_bytes_per_iteration": rb + rshell, "vcycle_required_bytes": rb,
            "bytes_note": "algorithmic = SURVEY.md 8d per-pass formulas (D^-1 read as an array, prolongation 8 N + 8 N_c); required = what must move as the library "
                          "runs the cycle (uniform diagonal: no D^-1 array; prolongation rewrites the fine iterate: 16 N + 8 N_c; V(1,1) on one rank: the first "
-                         "sweep is folded into the residual's gathers).  frac_of_peak is quoted on the REQUIRED bytes"}
+                         "sweep is folded into the residual's gathers, and on levels of up to 100 M rows the prolongation into the last sweep's).  "
+                         "frac_of_peak is quoted on the REQUIRED bytes"}
     # third row: what a caller who is free to choose the cycle would run -- the hierarchy taken down to 4^3 and the cell-centred
     # linear transfer (MgSetInterpolation; profiles/r2/mgcg_levels_sweep_512_csr*.log); its bytes are its own (the transfers
     # move the same HBM bytes, their extra operands come from cache)

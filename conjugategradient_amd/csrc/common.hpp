@@ -44,6 +44,8 @@ bool hip_ok(hipError_t e, const char* what, const char* file, int line);
 struct Tuning {
     std::atomic<int> overlap{1};             // MGCG_OVERLAP            0 off, 1 when it pays, 2 whenever an interior exists
     std::atomic<int> noFold{0};              // MGCG_NO_FOLD            V(1,*): store the first sweep instead of forming it per gather
+    std::atomic<int> foldUp{-1};             // MGCG_FOLD_UP            V(1,1): x1 + P e formed per gather of the last sweep instead of a prolongation kernel + stored iterate:
+                                             //                         -1 by level size (it pays up to a few ten million rows), 0 never, 1 wherever possible
     std::atomic<int> noFoldedFinalize{0};    // MGCG_NO_FOLDED_FINALIZE separate finalisation kernel
     std::atomic<int> checkEvery{4};          // MGCG_CHECK_EVERY        iterations the host enqueues ahead of the stop flag
     std::atomic<int> noUniformDiagonal{0};   // MGCG_NO_UNIFORM_DIAGONAL read the D^-1 array even when it is constant
@@ -262,6 +264,11 @@ struct SpmvArgs {
     double dinvScalar;
     int xScaled;             // row-pattern and row-tile kernels: the multiplied vector is xOuter * (xInner * x[col]), formed per gather
     double xInner, xOuter;   //   (a first Jacobi sweep from zero folded into the residual pass of the V-cycle)
+    // xScaled == 2 (row-tile kernel, Jacobi epilogues): ... + xCoarse[parent(col)] on top -- the piecewise-constant prolongation of the coarse
+    // correction folded into the last sweep of a V(1,1) cycle; the sweep's own iterate (w) is formed the same way from b.  The grid has
+    // power-of-two nx, ny: parent(c) = (ix >> 1) + ((iy >> cSy) << cLgNX) + ((iz >> cSz) << cLgNXY), ix = c & cMaskX, iy = (c >> cLx) & cMaskY, iz = c >> cLxy
+    const double* xCoarse;
+    int cMaskX, cMaskY, cLx, cLxy, cSy, cSz, cLgNX, cLgNXY;
     double* partials;        // EPI_DOT / EPI_RESIDUAL_DOT / EPI_JACOBI_DOT: one double per workgroup
     const int* doneFlag;     // optional: exit at once when *doneFlag != 0
     int ablate;              // lab builds only (-DMGCG_LAB, tools/spmv_sweep.py --ablate): bit0 skip the y store, bit1 gathers from L1; the product never reads it

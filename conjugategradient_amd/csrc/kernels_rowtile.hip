@@ -48,11 +48,15 @@ constexpr int kTCap = 512;          // nonzeros a wavefront stages per trip
 // (A variant in which the eight XCDs read eight separate runs per trip measured 6 % slower: profiles/r2/spmv_sweep_rows_vs_rowtile_disjoint_runs.log.)
 // (struct TileMap: common.hpp; tile_map_trips / tile_map_tile: spmv_epilogue.hpp; make_tile_map below)
 
-template <int EPI>
+template <int EPI, int XS>
 __device__ __forceinline__ RowsEpi tile_epi_prefetch(const SpmvArgs& a, int row)
 {
     // as rows_epi_prefetch, but without a conditional load (a branch around a load would make the waits uncounted)
     RowsEpi o; o.w = 0.0; o.b = 0.0; o.dinv = 0.0; o.yold = 0.0;
+    if constexpr (XS == 2) {       // Jacobi sweep on x1 + P e formed on the fly (uniform diagonal): w is finished by tile_epi_own below
+        o.b = a.b[row]; o.w = a.xCoarse[coarse_of(a, row)]; o.dinv = a.dinvScalar;
+        return o;
+    }
     if constexpr (EPI == EPI_AXPBY_BETA) o.yold = a.y[row];
     if constexpr (EPI == EPI_DOT) o.w = a.w[row];
     if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_DOT) o.b = a.b[row];
@@ -65,11 +69,20 @@ __device__ __forceinline__ RowsEpi tile_epi_prefetch(const SpmvArgs& a, int row)
     return o;
 }
 
+// xScaled == 2: the sweep's own iterate x1[row] + e[parent(row)], x1 = xOuter * (xInner * b[row]) (o.w holds e[parent] so far)
+template <int XS>
+__device__ __forceinline__ void tile_epi_own(const SpmvArgs& a, RowsEpi& o)
+{
+    if constexpr (XS == 2) { const double t = a.xInner * o.b; const double x1 = a.xOuter * t; o.w = x1 + o.w; }
+}
+
 // NG = gathers issued per row in the fast path: 8, or 7 when no row of the matrix is longer (a 7-point stencil: one LDS read
 // pair, one gather and one product fewer per row, 1-2.5 % -- profiles/r2/spmv_lab_lab15_micro.log, spmv_lab_lab17_records.log).
 // XS: the multiplied vector is xOuter * (xInner * x[col]), formed per gather with the same two rounded products a stored first Jacobi
 // sweep from zero would have used (the V(1,*) fold of the multigrid's residual pass, solver.hip: one 16 N pass less per level).
-template <int EPI, int NG, bool NT = false, bool XS = false>
+// XS == 2: ... + xCoarse[parent(col)] -- the prolongation of the coarse correction folded into the last sweep of a V(1,1) cycle as well
+// (the prolongation kernel and the stored x1 + P e go: 33 N bytes less per level); a second gather per entry, from a vector an eighth the size.
+template <int EPI, int NG, bool NT = false, int XS = 0>
 __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, TileMap tm, int nTiles)
 {
     __shared__ __attribute__((aligned(16))) int s_colAll[kTCap * kTW];
@@ -92,11 +105,15 @@ __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, Tile
         if (wg == 0 && tailRow <= lastRow) {
             double acc = 0.0;
             for (int k = a.rowOffsets[tailRow]; k < a.rowOffsets[tailRow + 1]; ++k) {
-                double xv = a.x[a.columnIndeces[k]];
-                if constexpr (XS) { const double t = a.xInner * xv; xv = a.xOuter * t; }
+                const int col = a.columnIndeces[k];
+                double xv = a.x[col];
+                if constexpr (XS != 0) { const double t = a.xInner * xv; xv = a.xOuter * t; }
+                if constexpr (XS == 2) xv = xv + a.xCoarse[coarse_of(a, col)];
                 const double p = a.elements[k] * xv; acc += p;
             }
-            const RowsEpi eo = rows_epi_prefetch<EPI>(a, tailRow);
+            RowsEpi eo;
+            if constexpr (XS == 2) { eo = tile_epi_prefetch<EPI, XS>(a, tailRow); tile_epi_own<XS>(a, eo); }
+            else eo = rows_epi_prefetch<EPI>(a, tailRow);
             a.y[tailRow] = rows_epilogue_value<EPI>(a, acc, eo, dot);
         }
         if constexpr (epi_has_dot(EPI)) {
@@ -170,15 +187,22 @@ __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, Tile
 #pragma unroll
             for (int j = 0; j < NG; ++j) { cc[j] = 0; vv[j] = 0.0; }
             for (int k = my_s; k < roA_e; ++k) {
-                double xv = a.x[a.columnIndeces[k]];
-                if constexpr (XS) { const double t = a.xInner * xv; xv = a.xOuter * t; }
+                const int col = a.columnIndeces[k];
+                double xv = a.x[col];
+                if constexpr (XS != 0) { const double t = a.xInner * xv; xv = a.xOuter * t; }
+                if constexpr (XS == 2) xv = xv + a.xCoarse[coarse_of(a, col)];
                 const double p = a.elements[k] * xv; accSlow += p;
             }
         }
         __builtin_amdgcn_sched_barrier(0);                         // all LDS reads in flight before the first gather waits for its column id
 #pragma unroll
         for (int j = 0; j < NG; ++j) xg[j] = a.x[cc[j]];
-        const RowsEpi eo = tile_epi_prefetch<EPI>(a, row);
+        double eg[XS == 2 ? NG : 1];
+        if constexpr (XS == 2) {
+#pragma unroll
+            for (int j = 0; j < NG; ++j) eg[j] = a.xCoarse[coarse_of(a, cc[j])];
+        }
+        RowsEpi eo = tile_epi_prefetch<EPI, XS>(a, row);
         // the previous trip's result, then the next trip's raw stream and the row offsets of the trip after it
         __builtin_nontemporal_store(pend, a.y + pendRow);
         load_raw(__builtin_amdgcn_readfirstlane(roB_s));
@@ -187,9 +211,14 @@ __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, Tile
         load_ro(tileAfter, roB_s, roB_e);
         __builtin_amdgcn_sched_barrier(0);                         // no product in front of the prefetch: its wait would hold the raw loads back
         double acc = 0.0;
-        if constexpr (XS) {
+        if constexpr (XS != 0) {
 #pragma unroll
             for (int j = 0; j < NG; ++j) { const double t = a.xInner * xg[j]; xg[j] = a.xOuter * t; }
+        }
+        if constexpr (XS == 2) {
+#pragma unroll
+            for (int j = 0; j < NG; ++j) xg[j] = xg[j] + eg[j];
+            tile_epi_own<XS>(a, eo);
         }
 #pragma unroll
         for (int j = 0; j < NG; ++j) { const double p = vv[j] * xg[j]; acc += (j < cnt) ? p : 0.0; }
@@ -282,10 +311,18 @@ static int launch_rowtile_epi(hipStream_t s, const SpmvArgs& a, int periodRows, 
     const int ntKnob = tuning().rowtileNt.load(std::memory_order_relaxed);
     const bool nt = ntKnob >= 0 ? ntKnob != 0 : (ntWindow && a.rowCount >= 8000000 && a.rowCount <= 36000000);
     const bool seven = maxRow > 0 && maxRow <= 7;
+    if (a.xScaled == 2) {                                         // (the multigrid's last sweep of a V(1,1) cycle: x1 + P e per gather)
+        if constexpr (EPI == EPI_JACOBI || EPI == EPI_JACOBI_DOT) {
+            if (a.xCoarse == nullptr || !a.dinvUniform) { set_error("row-tile SpMV: the folded prolongation needs the coarse vector and a uniform diagonal"); return 0; }
+            if (seven) hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 7, false, 2>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
+            else hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 8, false, 2>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
+            return nWG * kTW;
+        } else { set_error("row-tile SpMV: the folded prolongation is implemented for the Jacobi epilogues only"); return 0; }
+    }
     if (a.xScaled) {                                              // (only the multigrid's residual pass asks; never with the streaming hint)
         if constexpr (EPI == EPI_RESIDUAL) {
-            if (seven) hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 7, false, true>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
-            else hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 8, false, true>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
+            if (seven) hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 7, false, 1>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
+            else hipLaunchKernelGGL((spmv_rowtile_kernel<EPI, 8, false, 1>), dim3(nWG), dim3(64 * kTW), 0, s, a, tm, nTiles);
             return nWG * kTW;
         } else { set_error("row-tile SpMV: a scaled multiplicand is implemented for the residual epilogue only"); return 0; }
     }

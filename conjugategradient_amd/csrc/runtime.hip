@@ -25,6 +25,7 @@ const Knob kKnobs[] = {
     { "MGCG_OVERLAP", "overlap", &Tuning::overlap, 1, false },
     { "MGCG_NO_FOLD", "no_fold", &Tuning::noFold, 0, true },
     { "MGCG_NO_FOLDED_FINALIZE", "no_folded_finalize", &Tuning::noFoldedFinalize, 0, true },
+    { "MGCG_FOLD_UP", "fold_up", &Tuning::foldUp, -1, false },
     { "MGCG_CHECK_EVERY", "check_every", &Tuning::checkEvery, 4, false },
     { "MGCG_NO_UNIFORM_DIAGONAL", "no_uniform_diagonal", &Tuning::noUniformDiagonal, 0, true },
     { "MGCG_NO_ZSWEEP", "no_zsweep", &Tuning::noZsweep, 0, true },

@@ -153,12 +153,27 @@ static bool mg_spmv(MgcgMg* mg, MgLevel& L, int epilogue, const SpmvArgs& a, dou
 }
 
 // xout_loc = xin_loc + omega * (dinv * (b - A xin)); xin / xout are full-length buffers
-static bool mg_jacobi(MgcgMg* mg, MgLevel& L, const double* b, double* xin, double* xout, const int* done, bool withDot = false)
+constexpr long long kFoldUpMaxRows = 100000000;     // (bench.py FOLD_UP_MAX_ROWS counts the bytes with the same limit)
+static thread_local int t_lastFolds = 0;        // MgcgLastVcycleFolds: bit 0 first sweep folded, bit 1 prolongation folded (last V-cycle of this thread)
+
+static int log2_exact(long long v) { int l = 0; while ((1LL << l) < v) ++l; return ((1LL << l) == v) ? l : -1; }
+
+// coarse != nullptr (one rank, V(1,1), uniform diagonal, row-tile kernel on plain CSR, power-of-two nx and ny): the sweep runs on
+// x1 + P e without that iterate ever being stored -- x1 = omega (d0 b) and the parent's correction are formed per gather and for the
+// row itself (SpmvArgs::xScaled == 2); xin is not read.
+static bool mg_jacobi(MgcgMg* mg, MgLevel& L, const double* b, double* xin, double* xout, const int* done, bool withDot = false, const double* coarse = nullptr)
 {
     SpmvArgs a{};
     a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = xin; a.y = xout + L.offset;
     a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal;
     a.w = xin + L.offset; a.b = b; a.dinv = L.dinv; a.dinvUniform = L.dinvUniform ? 1 : 0; a.dinvScalar = L.dinvScalar; a.omega = mg->omega; a.doneFlag = done;
+    if (coarse != nullptr) {
+        const int lx = log2_exact(L.nx), ly = log2_exact(L.ny);
+        a.x = b; a.w = nullptr; a.xScaled = 2; a.xInner = L.dinvScalar; a.xOuter = mg->omega; a.xCoarse = coarse;
+        a.cMaskX = L.nx - 1; a.cMaskY = L.ny - 1; a.cLx = lx; a.cLxy = lx + ly;
+        a.cSy = L.ny > 1 ? 1 : 0; a.cSz = (L.z1 - L.z0) > 1 ? 1 : 0;
+        a.cLgNX = lx - 1; a.cLgNXY = (lx - 1) + (ly - a.cSy);
+    }
     // withDot marks the LAST sweep of the cycle on the finest level: r.z of the PCG loop rides on it (partial sums of b . xout), and
     // with several ranks it writes the rank's rows of the result where the caller wants them
     if (withDot && mg->multi && mg->finalOut != nullptr) { a.y = mg->finalOut; mg->finalWritten = true; }
@@ -219,6 +234,7 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
     // (worth two more launches only on a large level: 16 bytes per row saved against ~15 us of launches and a boundary pass of its own)
     const bool foldInterior = mayFold && mg->multi && (L.dcsr == nullptr || !L.dcsr->usable) && zoneLo <= zoneHi && 2 * (L.interior1 - L.interior0) >= L.n &&
                               (L.n >= 3000000 || tuning().overlap.load(std::memory_order_relaxed) == 2);
+    if (fold || foldInterior) t_lastFolds |= 1;
     if (fold) cur = x0;
     else if (foldInterior) {
         cur = x0;
@@ -253,6 +269,17 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
         if (mg->multi && !halo_exchange(mg->comm, C.transferHalo, e, mg->stream)) return false;
         launch_prolong_linear_add(mg->stream, L.nx, L.ny, L.nz, L.z0, L.z1, cur + L.offset, e, done);               // x += P e
     }
+    else if (fold && (L.dcsr == nullptr || !L.dcsr->usable) && L.nx >= 2 && log2_exact(L.nx) >= 1 && log2_exact(L.ny) >= 0 && L.nGlobal < 0x7fffffffLL &&
+             (tuning().foldUp.load(std::memory_order_relaxed) < 0 ? L.n <= kFoldUpMaxRows : tuning().foldUp.load(std::memory_order_relaxed) != 0)) {
+        // V(1,1) on plain CSR: the prolongation is folded into the one post-smoothing sweep as well -- x1 + P e is formed per gather there
+        // (no prolongation kernel, the iterate buffer `cur` is never written: 33 N bytes less on this level).  The second gather per entry
+        // costs the sweep more than the bytes save on the largest levels (tools/foldup_ab.py, profiles/r3/foldup_ab.log: 256^3 as the
+        // finest level -4.5 % per MGCG iteration, 512 x 512 x 256 -1.6 %, as level 1 of 512^3 -56 us; on the 512^3 level itself +0.13 ms): by level size.
+        if (!mg_jacobi(mg, L, b, cur, other, done, l == 0, e + C.offset)) return false;
+        t_lastFolds |= 2;
+        *result = other;
+        return true;
+    }
     else if (fold || foldInterior) launch_prolong_scaled(mg->stream, L.nx, L.ny, L.z1 - L.z0, cur + L.offset, b, L.dinvScalar, mg->omega, e + C.offset, done);
     else launch_prolong_add(mg->stream, L.nx, L.ny, L.z1 - L.z0, cur + L.offset, e + C.offset, done);   // x += P e (slab-local)
     return mg_smooth(mg, L, b, cur, other, mg->nu, false, done, result, l == 0);
@@ -265,6 +292,7 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
 static bool mg_apply(MgcgMg* mg, const double* r, double* z, const int* done, double* dotPartials = nullptr, int* nDot = nullptr)
 {
     mg->fuseDotPartials = dotPartials; mg->fusedDotCount = 0;
+    t_lastFolds = 0;
     struct Reset { MgcgMg* m; int* n; ~Reset() { if (n) *n = m->fusedDotCount; m->fuseDotPartials = nullptr; } } reset{ mg, nDot };
     MgLevel& L0 = mg->lv[0];
     double* res = nullptr;
@@ -678,6 +706,8 @@ int MgcgLastHalo(long long volume[2])
     if (volume) { volume[0] = v[1]; volume[1] = v[2]; }
     return (int)v[0];
 }
+
+int MgcgLastVcycleFolds(void) { return t_lastFolds; }
 
 int MgcgLastOverlap(long long interior[2])
 {

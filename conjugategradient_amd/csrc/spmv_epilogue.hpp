@@ -33,6 +33,13 @@ __device__ __forceinline__ double rows_epilogue_value(const SpmvArgs& a, double 
     }
 }
 
+// parent cell of fine cell c on a grid with power-of-two nx, ny (SpmvArgs::xScaled == 2)
+__device__ __forceinline__ int coarse_of(const SpmvArgs& a, int c)
+{
+    const int ix = c & a.cMaskX, iy = (c >> a.cLx) & a.cMaskY, iz = c >> a.cLxy;
+    return (ix >> 1) + ((iy >> a.cSy) << a.cLgNX) + ((iz >> a.cSz) << a.cLgNXY);
+}
+
 // ---- tile order (TileMap, common.hpp): trips of workgroup `wg` of `nWG`, and the tile of its t-th trip
 __host__ __device__ __forceinline__ int tile_map_trips(const TileMap& tm, int wg, int nWG, int nTiles)
 {

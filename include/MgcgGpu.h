@@ -416,6 +416,11 @@ int MgcgEstimateSpectrum(MgcgBlas* cublas, MgcgSparse* cusparse,
  * (rows outside it wait for the halo), or 0 when the exchange ran in line (single rank, MGCG_OVERLAP=0, or the
  * slice has too few rows that reference local columns only).  interior may be NULL. */
 int MgcgLastOverlap(long long interior[2]);
+/* Which folds the calling thread's LAST V-cycle took (Apply / SolveMg / SolveMgParallel): bit 0 = on some level the first sweep from
+ * zero was formed per gather of the residual pass instead of being stored, bit 1 = on some level the prolongation was formed per gather
+ * of the post-smoothing sweep as well (one rank, V(1,1), plain CSR, uniform diagonal, power-of-two nx and ny).  Schedules only: the
+ * results are bit-identical either way (MGCG_NO_FOLD=1 / MGCG_FOLD_UP=0 switch them off; MGCG_FOLD_UP=1 takes the second one on levels of any size, by default it is taken up to 100 M rows). */
+int MgcgLastVcycleFolds(void);
 /* The calling thread's last halo exchange: returns 1 if it moved per-peer index lists (unstructured slices: only the entries
  * of p the slice's column ids reference -- plan built once from them), 0 if contiguous ranges (banded / stencil slices,
  * the reference's [minJ, offset) and [offset + count, maxJ]: Mgcg.cu:83-84, ConjugateGradientParallelGpu.cs:397-398);

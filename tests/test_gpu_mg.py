@@ -133,3 +133,45 @@ def test_linear_transfer_fixture_16cubed():
     assert np.abs(cg.x - g["pcg_x"]).max() <= 1e-10 * np.abs(g["pcg_x"]).max()
     assert np.abs(cg.x - g["x_direct"]).max() <= 1e-8 * np.abs(g["x_direct"]).max()
     cg.Dispose()
+
+
+@pytest.mark.parametrize("dims", [(16, 16, 16), (32, 8, 4), (64, 4, 1), (8, 1, 8), (16, 16, 10), (4, 2, 2), (512, 2, 2)])
+def test_prolongation_folded_into_the_last_sweep_bit_exact_vs_oracle(oracle, dims):
+    """V(1,1) on plain CSR with power-of-two nx, ny: x1 + P e is formed per gather of the post-smoothing sweep (no prolongation
+    kernel, the iterate never stored).  Same bits as the oracle's stored cycle, with the fold and without it; the export says
+    which schedule ran."""
+    L = _lib.lib()
+    s = problems.poisson(*dims)
+    r = np.random.default_rng(21).standard_normal(s.Count)
+    for levels in (2, 3):
+        M = oracle.Multigrid(s, levels=levels, nu=1, nu_coarse=3)
+        cg = _mg(s, levels=levels, nu=1, nuc=3)
+        L.MgcgSetMatrixCompression(cg.cusparse, 0)
+        zref = M.apply(r)
+        try:
+            assert L.MgcgSetTuning(b"fold_up", 1) == 0
+            z = cg.Apply(r)
+            folds = L.MgcgLastVcycleFolds()
+            assert np.array_equal(z, zref), f"{dims} L{levels}"
+            if M.levels > 1 and s.Count >= 8:
+                assert folds & 1, (dims, levels, folds)             # first sweep folded into the residual pass
+                assert folds & 2, (dims, levels, folds)             # ... and the prolongation into the last sweep
+            assert L.MgcgSetTuning(b"fold_up", 0) == 0
+            assert np.array_equal(cg.Apply(r), zref)
+            assert (L.MgcgLastVcycleFolds() & 2) == 0
+        finally:
+            L.MgcgSetTuning(b"fold_up", -1)
+        ref = M.pcg(rule=oracle.RULE_CSHARP, max_iteration=300, trace=True)
+        cg.Solve(trace=True)                                        # the last sweep also carries r.z of the PCG loop
+        cg.Read()
+        assert cg.Iteration == ref["iteration"]
+        assert_trace_close(cg.trace, ref["trace"])
+        assert np.abs(cg.x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
+        cg.Dispose()
+    # a grid whose nx is not a power of two keeps the prolongation kernel
+    s = problems.poisson(24, 16, 4)
+    cg = _mg(s, levels=2, nu=1, nuc=3)
+    L.MgcgSetMatrixCompression(cg.cusparse, 0)
+    assert np.array_equal(cg.Apply(np.ones(s.Count)), oracle.Multigrid(s, levels=2, nu=1, nu_coarse=3).apply(np.ones(s.Count)))
+    assert (L.MgcgLastVcycleFolds() & 2) == 0
+    cg.Dispose()

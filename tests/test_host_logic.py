@@ -223,7 +223,14 @@ def test_required_bytes_of_the_vcycle():
     coarse = 16 * Nc + sweep(4)
     assert (v, s) == (fine + coarse, shell)
     vf, _ = bench.vcycle_required_bytes(n, 2, 1, 2, fold=True)
-    assert v - vf == 16 * N + 8 * N                      # the first sweep's store, and the residual's separate read of x
+    # the first sweep's store and the residual's separate read of x; on this small power-of-two level also the whole prolongation pass
+    # (16 N + 8 Nc) and the last sweep's read of the stored iterate (8 N), for the parent's correction read per gather (8 Nc)
+    assert v - vf == (16 * N + 8 * N) + (16 * N + 8 * Nc) + 8 * N - 8 * Nc
+    v6, _ = bench.vcycle_required_bytes(6, 2, 1, 2, fold=True)        # n = 6: not a power of two, the prolongation kernel stays
+    v6n, _ = bench.vcycle_required_bytes(6, 2, 1, 2, fold=False)
+    assert v6n - v6 == 24 * 216
+    big, bigshell = bench.vcycle_required_bytes(512, 3, 1, 4)         # 512^3: only the 256^3 level is under the row limit
+    assert bench.FOLD_UP_MAX_ROWS < 512**3 and big + bigshell == 60831694880 - 24 * 256**3      # (60.83 GB: the count before this fold)
     v2, _ = bench.vcycle_required_bytes(n, 2, 2, 2, fold=True)
     assert v2 == fine + coarse + 2 * sweep(n)            # V(2,2): nothing to fold, one more sweep either side
     va, sa = bench.vcycle_bytes(512, 3, 1, 4)
