@@ -266,9 +266,10 @@ struct SpmvArgs {
     double xInner, xOuter;   //   (a first Jacobi sweep from zero folded into the residual pass of the V-cycle)
     // xScaled == 2 (row-tile kernel, Jacobi epilogues): ... + xCoarse[parent(col)] on top -- the piecewise-constant prolongation of the coarse
     // correction folded into the last sweep of a V(1,1) cycle; the sweep's own iterate (w) is formed the same way from b.  The grid has
-    // power-of-two nx, ny: parent(c) = (ix >> 1) + ((iy >> cSy) << cLgNX) + ((iz >> cSz) << cLgNXY), ix = c & cMaskX, iy = (c >> cLx) & cMaskY, iz = c >> cLxy
+    // power-of-two nx, ny (lx, ly bits), y / z halved when sy / sz = 1: parent(c) = ((c >> 1) & cM0) | ((c >> cS1) & cM1) | ((c >> cS2) & cM2) with
+    // cM0 = nx/2 - 1, cS1 = 1 + sy, cM1 = ((ny >> sy) - 1) << (lx - 1), cS2 = 1 + sy + sz, cM2 = every bit from lx - 1 + ly - sy up
     const double* xCoarse;
-    int cMaskX, cMaskY, cLx, cLxy, cSy, cSz, cLgNX, cLgNXY;
+    int cM0, cM1, cM2, cS1, cS2;
     double* partials;        // EPI_DOT / EPI_RESIDUAL_DOT / EPI_JACOBI_DOT: one double per workgroup
     const int* doneFlag;     // optional: exit at once when *doneFlag != 0
     int ablate;              // lab builds only (-DMGCG_LAB, tools/spmv_sweep.py --ablate): bit0 skip the y store, bit1 gathers from L1; the product never reads it

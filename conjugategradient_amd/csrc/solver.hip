@@ -170,9 +170,9 @@ static bool mg_jacobi(MgcgMg* mg, MgLevel& L, const double* b, double* xin, doub
     if (coarse != nullptr) {
         const int lx = log2_exact(L.nx), ly = log2_exact(L.ny);
         a.x = b; a.w = nullptr; a.xScaled = 2; a.xInner = L.dinvScalar; a.xOuter = mg->omega; a.xCoarse = coarse;
-        a.cMaskX = L.nx - 1; a.cMaskY = L.ny - 1; a.cLx = lx; a.cLxy = lx + ly;
-        a.cSy = L.ny > 1 ? 1 : 0; a.cSz = (L.z1 - L.z0) > 1 ? 1 : 0;
-        a.cLgNX = lx - 1; a.cLgNXY = (lx - 1) + (ly - a.cSy);
+        const int sy = L.ny > 1 ? 1 : 0, sz = (L.z1 - L.z0) > 1 ? 1 : 0;
+        a.cM0 = L.nx / 2 - 1; a.cS1 = 1 + sy; a.cM1 = ((L.ny >> sy) - 1) << (lx - 1);
+        a.cS2 = 1 + sy + sz; a.cM2 = (int)(~0u << (lx - 1 + ly - sy));
     }
     // withDot marks the LAST sweep of the cycle on the finest level: r.z of the PCG loop rides on it (partial sums of b . xout), and
     // with several ranks it writes the rank's rows of the result where the caller wants them

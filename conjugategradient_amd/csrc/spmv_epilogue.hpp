@@ -34,10 +34,11 @@ __device__ __forceinline__ double rows_epilogue_value(const SpmvArgs& a, double 
 }
 
 // parent cell of fine cell c on a grid with power-of-two nx, ny (SpmvArgs::xScaled == 2)
+// (c = [iz | iy | ix] as bit fields; the parent drops the lowest bit of every coarsened field: three shifts, one and, two and-or)
 __device__ __forceinline__ int coarse_of(const SpmvArgs& a, int c)
 {
-    const int ix = c & a.cMaskX, iy = (c >> a.cLx) & a.cMaskY, iz = c >> a.cLxy;
-    return (ix >> 1) + ((iy >> a.cSy) << a.cLgNX) + ((iz >> a.cSz) << a.cLgNXY);
+    const unsigned u = (unsigned)c;
+    return (int)(((u >> 1) & (unsigned)a.cM0) | ((u >> a.cS1) & (unsigned)a.cM1) | ((u >> a.cS2) & (unsigned)a.cM2));
 }
 
 // ---- tile order (TileMap, common.hpp): trips of workgroup `wg` of `nWG`, and the tile of its t-th trip
