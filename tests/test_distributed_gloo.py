@@ -62,7 +62,7 @@ class OraclePhases:
         return self.x
 
 
-def _worker(rank, world, port, which, out_dir):
+def _worker(rank, world, port, which, out_dir, balance="rows"):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
 
@@ -74,7 +74,7 @@ def _worker(rank, world, port, which, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     system = problems.mgcg_main(1203, 160) if which == "banded" else problems.random_spd(900, mean_upper=6.0, seed=11)
-    part = RankPartition.of(system.Count, world, rank, system.RowOffsets)
+    part = RankPartition.of(system.Count, world, rank, system.RowOffsets, balance)
     backend = OraclePhases(system, part, O)
     solver = PhasedRankSolver(backend, part, 0, system.Count, 1e-8, dist=dist)
     solver.Solve()
@@ -84,24 +84,31 @@ def _worker(rank, world, port, which, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,which", [(2, "banded"), (3, "banded"), (2, "unstructured")])
-def test_phased_rank_solver_matches_the_parallel_oracle(tmp_path, world, which):
+@pytest.mark.parametrize("world,which,balance", [(2, "banded", "rows"), (3, "banded", "rows"), (2, "unstructured", "rows"),
+                                                 (3, "unstructured", "nnz")])      # row ranges of equal nonzero count: ranks of different sizes
+def test_phased_rank_solver_matches_the_parallel_oracle(tmp_path, world, which, balance):
     import torch.multiprocessing as mp
 
     from conjugategradient_amd import problems
     from oracle import oracle as O
 
-    port = 29500 + (os.getpid() % 2000) + world
-    mp.spawn(_worker, args=(world, port, which, str(tmp_path)), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 2000) + world + (7 if balance == "nnz" else 0)
+    mp.spawn(_worker, args=(world, port, which, str(tmp_path), balance), nprocs=world, join=True)
     system = problems.mgcg_main(1203, 160) if which == "banded" else problems.random_spd(900, mean_upper=6.0, seed=11)
-    ref = O.cg_parallel(system, world, allowable_residual=1e-8, min_iteration=0, max_iteration=system.Count)
+    offsets = problems.partition_offsets(system.Count, world, system.RowOffsets, balance)
+    if balance == "nnz":
+        assert offsets != problems.partition_offsets(system.Count, world)
+    ref = O.cg_parallel(system, world, allowable_residual=1e-8, min_iteration=0, max_iteration=system.Count, offsets=offsets)
     x = np.zeros(system.Count)
     for r in range(world):
         d = np.load(tmp_path / f"rank{r}.npz")
         x[int(d["offset"]): int(d["offset"]) + int(d["count"])] = d["x"]
+        assert (int(d["offset"]), int(d["count"])) == (offsets[r], offsets[r + 1] - offsets[r])
         assert int(d["iteration"]) == ref["iteration"]
         # gloo all-reduce adds the rank partials in an order of its own; everything else is bit-identical
-        assert abs(float(d["residual"]) - ref["residual"]) <= 1e-9 * ref["residual"]
+        # (the random system drops from 1e-8 to 6e-13 in its last step, five digits below where its iterates stop being reproducible to
+        #  1e-9 between two summation orders: looser for the three-rank case)
+        assert abs(float(d["residual"]) - ref["residual"]) <= (1e-3 if balance == "nnz" else 1e-9) * ref["residual"]
         lo, hi = O.minmax_column(system, int(d["offset"]), int(d["offset"]) + int(d["count"]))
         assert (int(d["minJ"]), int(d["maxJ"])) == (lo, hi)
     np.testing.assert_allclose(x, ref["x"], rtol=1e-10, atol=1e-12 * np.abs(ref["x"]).max())
