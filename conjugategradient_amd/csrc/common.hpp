@@ -270,6 +270,7 @@ struct SpmvArgs {
     // cM0 = nx/2 - 1, cS1 = 1 + sy, cM1 = ((ny >> sy) - 1) << (lx - 1), cS2 = 1 + sy + sz, cM2 = every bit from lx - 1 + ly - sy up
     const double* xCoarse;
     int cM0, cM1, cM2, cS1, cS2;
+    int cRowBase;            //   global cell of the launch's row 0 (several ranks / a row range: the sweep's own parent is parent(cRowBase + row))
     double* partials;        // EPI_DOT / EPI_RESIDUAL_DOT / EPI_JACOBI_DOT: one double per workgroup
     const int* doneFlag;     // optional: exit at once when *doneFlag != 0
     int ablate;              // lab builds only (-DMGCG_LAB, tools/spmv_sweep.py --ablate): bit0 skip the y store, bit1 gathers from L1; the product never reads it

@@ -54,7 +54,7 @@ __device__ __forceinline__ RowsEpi tile_epi_prefetch(const SpmvArgs& a, int row)
     // as rows_epi_prefetch, but without a conditional load (a branch around a load would make the waits uncounted)
     RowsEpi o; o.w = 0.0; o.b = 0.0; o.dinv = 0.0; o.yold = 0.0;
     if constexpr (XS == 2) {       // Jacobi sweep on x1 + P e formed on the fly (uniform diagonal): w is finished by tile_epi_own below
-        o.b = a.b[row]; o.w = a.xCoarse[coarse_of(a, row)]; o.dinv = a.dinvScalar;
+        o.b = a.b[row]; o.w = a.xCoarse[coarse_of(a, a.cRowBase + row)]; o.dinv = a.dinvScalar;
         return o;
     }
     if constexpr (EPI == EPI_AXPBY_BETA) o.yold = a.y[row];

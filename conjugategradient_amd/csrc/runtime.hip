@@ -300,6 +300,7 @@ int launch_spmv_range(hipStream_t s, int epilogue, const SpmvArgs& whole, const 
     if (r1 <= r0) return 0;
     SpmvArgs a = whole;
     a.rowOffsets += r0; a.y += r0; a.rowCount = (int)(r1 - r0); a.partials = partials;   // offsets stay absolute into elements / columnIndeces
+    a.cRowBase += (int)r0;
     if (a.w) a.w += r0;
     if (a.b) a.b += r0;
     if (a.dinv) a.dinv += r0;

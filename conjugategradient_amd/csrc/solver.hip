@@ -161,18 +161,29 @@ static int log2_exact(long long v) { int l = 0; while ((1LL << l) < v) ++l; retu
 // coarse != nullptr (one rank, V(1,1), uniform diagonal, row-tile kernel on plain CSR, power-of-two nx and ny): the sweep runs on
 // x1 + P e without that iterate ever being stored -- x1 = omega (d0 b) and the parent's correction are formed per gather and for the
 // row itself (SpmvArgs::xScaled == 2); xin is not read.
-static bool mg_jacobi(MgcgMg* mg, MgLevel& L, const double* b, double* xin, double* xout, const int* done, bool withDot = false, const double* coarse = nullptr)
+// Several ranks (coarse = the FULL-length coarse iterate, interiorOnly): only the interior rows form it on the fly (their columns are
+// local: (b - offset)[col]); the boundary rows multiply the stored iterate, which the caller has written within two planes of the
+// rank's boundaries and mg_spmv2 exchanges.
+static bool mg_jacobi(MgcgMg* mg, MgLevel& L, const double* b, double* xin, double* xout, const int* done, bool withDot = false, const double* coarse = nullptr,
+                      bool interiorOnly = false)
 {
     SpmvArgs a{};
     a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = xin; a.y = xout + L.offset;
     a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal;
     a.w = xin + L.offset; a.b = b; a.dinv = L.dinv; a.dinvUniform = L.dinvUniform ? 1 : 0; a.dinvScalar = L.dinvScalar; a.omega = mg->omega; a.doneFlag = done;
+    SpmvArgs stored = a;                            // (the sweep on a stored iterate: what the boundary rows of several ranks run)
     if (coarse != nullptr) {
         const int lx = log2_exact(L.nx), ly = log2_exact(L.ny);
-        a.x = b; a.w = nullptr; a.xScaled = 2; a.xInner = L.dinvScalar; a.xOuter = mg->omega; a.xCoarse = coarse;
-        const int sy = L.ny > 1 ? 1 : 0, sz = (L.z1 - L.z0) > 1 ? 1 : 0;
+        a.x = b - (interiorOnly ? L.offset : 0); a.w = nullptr; a.xScaled = 2; a.xInner = L.dinvScalar; a.xOuter = mg->omega; a.xCoarse = coarse;
+        const int sy = L.ny > 1 ? 1 : 0, sz = L.nz > 1 ? 1 : 0;
         a.cM0 = L.nx / 2 - 1; a.cS1 = 1 + sy; a.cM1 = ((L.ny >> sy) - 1) << (lx - 1);
         a.cS2 = 1 + sy + sz; a.cM2 = (int)(~0u << (lx - 1 + ly - sy));
+        a.cRowBase = interiorOnly ? (int)L.offset : 0;
+    }
+    if (interiorOnly) {
+        if (withDot && mg->finalOut != nullptr) { a.y = mg->finalOut; stored.y = mg->finalOut; mg->finalWritten = true; }
+        const bool dot = withDot && mg->fuseDotPartials != nullptr;
+        return mg_spmv2(mg, L, dot ? EPI_JACOBI_DOT : EPI_JACOBI, a, stored, xin, dot ? mg->fuseDotPartials : nullptr, dot ? &mg->fusedDotCount : nullptr, true);
     }
     // withDot marks the LAST sweep of the cycle on the finest level: r.z of the PCG loop rides on it (partial sums of b . xout), and
     // with several ranks it writes the rank's rows of the result where the caller wants them
@@ -276,6 +287,29 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
         // costs the sweep more than the bytes save on the largest levels (tools/foldup_ab.py, profiles/r3/foldup_ab.log: 256^3 as the
         // finest level -4.5 % per MGCG iteration, 512 x 512 x 256 -1.6 %, as level 1 of 512^3 -56 us; on the 512^3 level itself +0.13 ms): by level size.
         if (!mg_jacobi(mg, L, b, cur, other, done, l == 0, e + C.offset)) return false;
+        t_lastFolds |= 2;
+        *result = other;
+        return true;
+    }
+    else if (foldInterior && L.nx >= 2 && log2_exact(L.nx) >= 1 && log2_exact(L.ny) >= 0 && L.nGlobal < 0x7fffffffLL && L.nz > 1 && (L.z0 & 1) == 0 && ((L.z1 - L.z0) & 1) == 0 &&
+             (tuning().foldUp.load(std::memory_order_relaxed) < 0 ? L.n <= kFoldUpMaxRows : tuning().foldUp.load(std::memory_order_relaxed) != 0)) {
+        // several ranks: the same for the interior rows; x1 + P e is stored only where the boundary rows reach (the zones of the first fold, the
+        // upper one begun on an even plane so that its parents start on a whole coarse plane), and the halo planes arrive by the exchange
+        const long long planes = L.z1 - L.z0, coarsePlane = (long long)C.nx * C.ny;
+        const long long loPlanes = zoneLo / plane;
+        long long hiStart = zoneHi / plane;
+        if (hiStart & 1) --hiStart;
+        if (hiStart < loPlanes) {                                                   // the zones meet: the whole slab in one piece
+            launch_prolong_scaled(mg->stream, L.nx, L.ny, (int)planes, cur + L.offset, b, L.dinvScalar, mg->omega, e + C.offset, done);
+        } else {
+            if (loPlanes > 0) launch_prolong_scaled(mg->stream, L.nx, L.ny, (int)loPlanes, cur + L.offset, b, L.dinvScalar, mg->omega, e + C.offset, done);
+            if (zoneHi < L.n) {
+                const long long r0 = hiStart * plane;
+                launch_prolong_scaled(mg->stream, L.nx, L.ny, (int)(planes - hiStart), cur + L.offset + r0, b + r0, L.dinvScalar, mg->omega,
+                                      e + C.offset + (hiStart / 2) * coarsePlane, done);
+            }
+        }
+        if (!mg_jacobi(mg, L, b, cur, other, done, l == 0, e, true)) return false;
         t_lastFolds |= 2;
         *result = other;
         return true;

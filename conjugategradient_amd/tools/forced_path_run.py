@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--force", type=int, default=-1, help="entries of the artificial halo (default one plane; 0: the plain single-rank loop)")
     ap.add_argument("--solver", choices=["cg", "mgcg"], default="cg")
     ap.add_argument("--repeats", type=int, default=1)
+    ap.add_argument("--fold-up", type=int, default=-1, help="MGCG_FOLD_UP: -1 by level size, 0 never, 1 everywhere")
+    ap.add_argument("--ab-fold-up", action="store_true", help="mgcg: alternate fold_up = --fold-up and 0 inside this process (same placement), report both")
     a = ap.parse_args()
     from conjugategradient_amd import _lib
     from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu, ConjugateGradientRankGpu
@@ -38,6 +40,7 @@ def main():
     L.MgcgSetTuning(b"force_multirank", force)
     L.MgcgSetTuning(b"overlap", a.overlap)
     L.MgcgSetTuning(b"halo_stream", a.halo_stream)
+    L.MgcgSetTuning(b"fold_up", a.fold_up)
     dims = (a.nx, a.nx, a.planes)
     n = dims[0] * dims[1] * dims[2]
     import json
@@ -67,10 +70,23 @@ def main():
 
         def run():
             cg.Steps(a.steps, restart=False)
+    ab = None
+    if a.ab_fold_up and a.solver == "mgcg":
+        ab = {"fold_up": [], "prolongation_kernel": []}
+        folds = {}
+        for _ in range(max(a.repeats, 3)):
+            for key, v in (("fold_up", a.fold_up), ("prolongation_kernel", 0)):
+                L.MgcgSetTuning(b"fold_up", v)
+                run()
+                ab[key].append(timed(run))
+                folds[key] = L.MgcgLastVcycleFolds()
+        L.MgcgSetTuning(b"fold_up", a.fold_up)
+        ab = {k: sorted(v)[len(v) // 2] for k, v in ab.items()}
+        ab["folds_reported"] = folds
     ms = [timed(run) for _ in range(a.repeats)]
     active = cg.LastOverlap()[0] if a.solver == "cg" else None
     print(json.dumps({"solver": a.solver, "grid": list(dims), "force_multirank": force, "overlap": a.overlap, "halo_stream": a.halo_stream,
-                      "steps": a.steps, "ms_per_iteration": min(ms), "ms_per_iteration_all": ms, "halo_overlap_active": active}))
+                      "steps": a.steps, "ms_per_iteration": min(ms), "ms_per_iteration_all": ms, "halo_overlap_active": active, "fold_up_ab_ms_per_iteration": ab}))
     cg.Dispose()
 
 

@@ -412,15 +412,20 @@ def test_distributed_multigrid_over_loopback(oracle, mgcg_env, world, dims, leve
         assert cg.levels == M.levels
         off, cnt = cg.part.offset, cg.part.count
         z = cg.Apply(rvec[off: off + cnt])
+        folds = _lib.lib().MgcgLastVcycleFolds()
         cg.Solve(trace=True)
         cg.Read()
-        out = (off, cnt, z, cg.x[off: off + cnt].copy(), cg.Iteration, cg.trace)
+        out = (off, cnt, z, cg.x[off: off + cnt].copy(), cg.Iteration, cg.trace, folds)
         cg.Dispose()
         return out
 
     res = _run_ranks_in_threads(world, make_rank)
     x, z = np.zeros(s.Count), np.zeros(s.Count)
-    for off, cnt, zs, xs, it, tr in res:
+    if interpolation == 0 and dims[2] // world >= 8:
+        # slabs of eight planes, power-of-two nx and ny: on the finest level the interior rows form the first sweep AND x1 + P e per gather
+        # (bits 0 and 1); the boundary rows multiply what is stored within two planes of the rank's boundaries
+        assert all(r[6] == 3 for r in res), [r[6] for r in res]
+    for off, cnt, zs, xs, it, tr, _folds in res:
         z[off: off + cnt] = zs
         x[off: off + cnt] = xs
         assert it == ref["iteration"]
