@@ -421,7 +421,8 @@ def test_distributed_multigrid_over_loopback(oracle, mgcg_env, world, dims, leve
 
     res = _run_ranks_in_threads(world, make_rank)
     x, z = np.zeros(s.Count), np.zeros(s.Count)
-    if interpolation == 0 and dims[2] // world >= 8:
+    plain = os.environ.get("MGCG_COMPRESSION", "0") == "0" and "MGCG_NO_FOLD" not in os.environ and os.environ.get("MGCG_FOLD_UP", "-1") != "0"
+    if interpolation == 0 and dims[2] // world >= 8 and plain:       # (tools/pytest_env_modes.sh runs the suite with these switches too)
         # slabs of eight planes, power-of-two nx and ny: on the finest level the interior rows form the first sweep AND x1 + P e per gather
         # (bits 0 and 1); the boundary rows multiply what is stored within two planes of the rank's boundaries
         assert all(r[6] == 3 for r in res), [r[6] for r in res]
@@ -476,4 +477,31 @@ def test_unstructured_halo_moves_index_lists(oracle, mgcg_env, world, mean_upper
             assert contiguous > moved
         else:
             assert moved == contiguous
+    assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
+
+
+def test_ranks_without_rows(oracle, mgcg_env):
+    """floor(count / devices) leaves devices without rows when count < devices (ConjugateGradientParallelGpu.cs:271-277: the last
+    device takes everything): such ranks still take part in every collective of the loop."""
+    world = 4
+    mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    s = problems.mgcg_main(3, 160)                      # 3 rows over 4 ranks: offsets [0, 0, 0, 0, 3]
+    assert problems.partition_offsets(s.Count, world) == [0, 0, 0, 0, 3]
+    ref = oracle.cg_parallel(s, world, max_iteration=50, trace=True)
+
+    def make_rank(rank, comm):
+        cg = ConjugateGradientRankGpu(s.Count, 3, 0, 50, 1e-8, rank=rank, world=world, comm=comm, device=rank).load(s)
+        cg.Initialize()
+        cg.Solve(trace=True)
+        cg.Read()
+        out = (cg.part.offset, cg.part.count, cg.x[cg.part.offset: cg.part.offset + cg.part.count].copy(), cg.Iteration, cg.Residual)
+        cg.Dispose()
+        return out
+
+    res = _run_ranks_in_threads(world, make_rank)
+    x = np.zeros(s.Count)
+    for off, cnt, xs, it, resid in res:
+        x[off: off + cnt] = xs
+        assert it == ref["iteration"] and resid == res[0][4]
+    assert [r[1] for r in res] == [0, 0, 0, 3]
     assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
