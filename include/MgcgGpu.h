@@ -161,7 +161,9 @@ int         MgcgAbiVersion(void);
 /* Tuning knobs.  Every MGCG_* environment variable the library honours is read once, at first use; launches never read
  * the environment.  All knobs choose between schedules that give bit-identical results:
  *   overlap (MGCG_OVERLAP: 0 halo exchange in line, 1 hidden behind interior rows when it pays [default], 2 whenever an
- *   interior exists), no_fold, no_folded_finalize, check_every (iterations enqueued ahead of the stop flag, default 4),
+ *   interior exists), no_fold, fold_up (MGCG_FOLD_UP: -1 [default] the prolongation of a V(1,1) cycle is formed per gather of the
+ *   post-smoothing sweep on levels of up to 100 M rows, 0 never, 1 on every level), no_folded_finalize, check_every (iterations
+ *   enqueued ahead of the stop flag, default 4), vector_vals_nt, tile_pack, auto_tiles,
  *   no_uniform_diagonal, no_zsweep, rowtile_nt / vec_nt (-1 by size, 0 / 1 forced), vec_grid, r_grid, xp_grid,
  *   pattern_group, pattern_waves, no_indexed_halo, tile_nt, tile_shift, verbose, lazy_code_objects,
  *   virtual_devices (MGCG_VIRTUAL_DEVICES: one physical GPU shown as n devices, tests only),
