@@ -269,6 +269,13 @@ def mgcg_extra(L, n: int):
                         "achieved_gbps": ((rb_ + rshell_) / (ms * 1e-3) / 1e9) if mode == 0 else None,
                         "frac_of_peak": ((rb_ + rshell_) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if mode == 0 else None,
                         "frac_of_peak_on_survey_formula_bytes": ((vb_ + shell_) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if mode == 0 else None}
+            if key == "csr":                                # PMC bytes of a whole iteration (profiles/spmv_traffic.json: tools/pmc_iteration_traffic.py on separate --pmc passes)
+                try:
+                    pj = json.load(open(os.path.join(ROOT, "profiles", "spmv_traffic.json"))).get("mgcg_csr_iteration", {})
+                    if pj.get("grid") == n:
+                        out[key]["traffic_bytes_per_iteration"] = pj.get("hbm_bytes_per_iteration")
+                except Exception:       # noqa: BLE001 -- the file is evidence, not an input
+                    pass
             if key != "csr" and mode == 0:
                 out[key]["config"] = f"V({nu_},{nu_}), {lv_} levels, {nuc_} coarse sweeps" + (", cell-centred linear transfer" if interp else "")
                 out[key]["algorithmic_bytes_per_iteration"] = vb_ + shell_
