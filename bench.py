@@ -638,6 +638,15 @@ def main():
             "gflops": (2 * nnz_total + 10 * N) * (a.steps / dt) / 1e9 if a.solver == "cg" else None,
             "residual_after_steps": res,
         }
+        try:    # PMC bytes of one whole iteration (evidence file written by tools/pmc_iteration_traffic.py from separate --pmc passes; N = 1, plain CSR)
+            key = {"cg": "cg_csr_iteration", "mgcg": "mgcg_csr_iteration"}[a.solver]
+            pj = json.load(open(os.path.join(ROOT, "profiles", "spmv_traffic.json"))).get(key, {})
+            standard_cycle = a.solver == "cg" or (a.mg_levels, a.mg_nu, a.mg_nu_coarse, a.mg_interpolation) == (3, 1, 4, 0)
+            if world == 1 and fmt == "csr" and pj.get("grid") == n and standard_cycle:
+                out["iteration_traffic_bytes"] = pj.get("hbm_bytes_per_iteration")
+                out["iteration_algorithmic_bytes"] = iter_bytes
+        except Exception:       # noqa: BLE001 -- the file is evidence, not an input
+            pass
         if fmt == "csr":
             out["roofline"] = {"bound": "hbm",
                                "kernel": "spmv_rowtile_kernel<EPI_DOT> (CSR SpMV fused with p.Ap) on the plain CSR arrays (12 B/nnz), timed inside the CG loop",
