@@ -29,6 +29,8 @@ Output: ONE JSON line on rank 0 (contract in the task statement) with these extr
   mgcg           -- BASELINE config 3 (3-level V(1,1) Jacobi MGCG on the same matrix, plain CSR on every level):
                     iterations to 1e-8*||b||, ms per iteration, V-cycle algorithmic bytes and achieved fraction.
   lossless_forms -- the same CG loop on the row-pattern / per-nonzero-code forms (secondary, N=1 only).
+  parity_vs_single_rank -- N > 1 only, untimed: rank 0 replays the same iterations as ONE rank on its own GPU; both residuals and
+                    their relative difference (north star: 1e-10) travel in the line, so a scaling record checks itself.
 """
 from __future__ import annotations
 
@@ -484,13 +486,14 @@ def main():
     nnz_local = cg.part.elementCount
     rows_local = cg.part.count
 
-    def run_steps(k, restart):
+    def run_steps(k, restart, solver=None):
+        s_ = cg if solver is None else solver
         if a.solver == "mgcg":          # init (r = b - A x, z = M^-1 r) is inside: about one extra V-cycle per call
-            L.MgcgFill(cg.vectorX.Ptr, 0.0)
-            cg.MinIteration = k - 1
-            cg.Solve()
-            return cg.Residual
-        return cg.Steps(k, restart=restart)
+            L.MgcgFill(s_.vectorX.Ptr, 0.0)
+            s_.MinIteration = k - 1
+            s_.Solve()
+            return s_.Residual
+        return s_.Steps(k, restart=restart)
 
     if a.solver == "mgcg":
         cg.Setup()
@@ -512,6 +515,7 @@ def main():
     launches = C.c_int(0)
     spmv_ms_total = L.MgcgProfileSpmvMs(cg.cusparse, C.byref(launches))
     L.MgcgProfileSpmv(cg.cusparse, 0)
+
 
     # What this box streams ("% of attainable" next to "% of spec"): read-only = Dot over two vectors,
     # copy = the library's Copy export (device-to-device), on the same 1 GiB vectors; and the plain CsrMV export (beta = 0,
@@ -599,6 +603,39 @@ def main():
     if world > 1 and a.solver == "cg":
         ov = (C.c_longlong * 2)(0, 0)
         overlap = {"active": bool(L.MgcgLastOverlap(ov)), "interior_rows": [int(ov[0]), int(ov[1])], "local_rows": int(rows_local)}
+    # N > 1 (untimed): rank 0 replays the same iterations as ONE rank on its own GPU (the whole grid fits one card) and the line
+    # carries both residuals -- the partitioned run checks itself against the single-rank loop (north star: 1e-10 relative)
+    parity = None
+    if world > 1 and a.compression == 0:
+        if rank == 0:
+            single = None
+            try:
+                free_b, total_b = C.c_longlong(0), C.c_longlong(0)
+                L.MgcgMemGetInfo(C.byref(free_b), C.byref(total_b))
+                need = (12 * 7 + 8 * (14 if a.solver == "mgcg" else 6)) * N * 1.3
+                if free_b.value < need:
+                    parity = {"skipped": f"{free_b.value / 1e9:.0f} GB free on rank 0's device, the single-rank replay needs about {need / 1e9:.0f} GB"}
+                else:
+                    if a.solver == "mgcg":
+                        single = ConjugateGradientMgRankGpu(N, 7, 0, 10**9, 1e300, (n, n, n), rank=0, world=1, device=local_rank, rule=_lib.RULE_NATIVE,
+                                                            levels=a.mg_levels, nu=a.mg_nu, nuCoarse=a.mg_nu_coarse, interpolation=a.mg_interpolation)
+                    else:
+                        single = ConjugateGradientRankGpu(N, 7, 0, 10**9, 1e-8, rank=0, world=1, device=local_rank)
+                    L.MgcgSetMatrixCompression(single.cusparse, 0)
+                    single.InitializePoisson(n, n, n)
+                    if a.solver == "mgcg":
+                        single.Setup()
+                    run_steps(max(a.warmup, 1), True, single)
+                    r1 = run_steps(a.steps, False, single)
+                    rel = abs(res - r1) / abs(r1) if r1 else float("inf")
+                    parity = {"single_rank_residual_after_steps": r1, "partitioned_residual_after_steps": res, "relative_difference": rel, "within_1e-10": bool(rel <= 1e-10)}
+            except Exception as ex:     # noqa: BLE001 -- the check must never cost the line
+                parity = {"skipped": f"single-rank replay failed: {ex}"}
+                L.MgcgClearLastError()
+            finally:
+                if single is not None:
+                    single.Dispose()
+        barrier()
     if rank == 0:
         spmv_bytes = 12 * nnz_local + 4 * (rows_local + 1) + 16 * rows_local     # per launch, per GPU
         achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
@@ -638,6 +675,8 @@ def main():
             "gflops": (2 * nnz_total + 10 * N) * (a.steps / dt) / 1e9 if a.solver == "cg" else None,
             "residual_after_steps": res,
         }
+        if parity is not None:
+            out["parity_vs_single_rank"] = parity
         try:    # PMC bytes of one whole iteration (evidence file written by tools/pmc_iteration_traffic.py from separate --pmc passes; N = 1, plain CSR)
             key = {"cg": "cg_csr_iteration", "mgcg": "mgcg_csr_iteration"}[a.solver]
             pj = json.load(open(os.path.join(ROOT, "profiles", "spmv_traffic.json"))).get(key, {})

@@ -1,0 +1,45 @@
+"""bench.py as a program on the GPU box: the N = 1 line's contract fields, and the self-launched N = 2 run over the host-staged
+transport (two processes share the one GPU) with its self-check against a single-rank replay of the same iterations."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]                      # ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_fields():
+    rec = _run("--grid", "128", "--steps", "20", "--warmup", "5", "--no-extras", "--cpu-iters", "1")
+    assert rec["n_gpus"] == 1 and rec["steps"] == 20 and rec["warmup"] == 5 and rec["unit"] == "iterations/s" and rec["dtype"] == "f64"
+    assert rec["higher_is_better"] is True and rec["data"] == "synthetic" and rec["vs_baseline"] is None and "workload" in rec["config"]
+    assert abs(rec["value"] - 1e3 / rec["ms_per_step"]) <= 1e-6 * rec["value"]
+    rf = rec["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["launches_timed"] == 20 and rf["algorithmic_bytes_per_launch"] == 12 * rec["config"]["nnz"] + 4 * (rec["config"]["rows"] + 1) + 16 * rec["config"]["rows"]
+    cb = rec["cpu_baseline"]
+    assert cb["cores"] == 1 and cb["kind"] == "port" and cb["value"] > 0 and "sample" in cb
+
+
+@pytest.mark.parametrize("solver", ["cg", "mgcg"])
+def test_two_self_launched_ranks_check_themselves_against_one_rank(solver):
+    rec = _run("--gpus", "2", "--grid", "64", "--steps", "8", "--warmup", "2", "--allow-fallback", "--solver", solver)
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong"
+    if "rccl" not in rec["config"]["transport"].lower() or "fallback" in rec["config"]["transport"].lower():
+        assert "not a scaling result" in rec["config"]["transport"]             # one GPU: the host-staged transport, and the line says so
+    par = rec["parity_vs_single_rank"]
+    assert par["within_1e-10"] is True and par["relative_difference"] <= 1e-10, par
+    assert par["partitioned_residual_after_steps"] == rec["residual_after_steps"]
