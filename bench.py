@@ -587,10 +587,15 @@ def main():
     if dist is not None:
         import torch
 
-        t = torch.tensor([dt, spmv_ms_total / max(launches.value, 1)], dtype=torch.float64)
+        mine = torch.tensor([dt, spmv_ms_total / max(launches.value, 1)], dtype=torch.float64)
+        every = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(every, mine)                        # (per-rank figures travel in the line: a slow rank or link shows by itself)
+        per_rank = {"seconds_for_the_timed_steps": [float(v[0]) for v in every], "spmv_avg_launch_ms": [float(v[1]) for v in every]}
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, spmv_ms = float(t[0]), float(t[1])
     else:
+        per_rank = None
         spmv_ms = spmv_ms_total / max(launches.value, 1)
 
     # which form the analysis chose for the fine matrix (class 3 one byte per row, 2/1 per-nonzero codes, 0 plain CSR)
@@ -677,6 +682,8 @@ def main():
         }
         if parity is not None:
             out["parity_vs_single_rank"] = parity
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         try:    # PMC bytes of one whole iteration (evidence file written by tools/pmc_iteration_traffic.py from separate --pmc passes; N = 1, plain CSR)
             key = {"cg": "cg_csr_iteration", "mgcg": "mgcg_csr_iteration"}[a.solver]
             pj = json.load(open(os.path.join(ROOT, "profiles", "spmv_traffic.json"))).get(key, {})

@@ -43,3 +43,6 @@ def test_two_self_launched_ranks_check_themselves_against_one_rank(solver):
     par = rec["parity_vs_single_rank"]
     assert par["within_1e-10"] is True and par["relative_difference"] <= 1e-10, par
     assert par["partitioned_residual_after_steps"] == rec["residual_after_steps"]
+    pr = rec["per_rank"]
+    assert len(pr["seconds_for_the_timed_steps"]) == 2 and len(pr["spmv_avg_launch_ms"]) == 2
+    assert abs(max(pr["seconds_for_the_timed_steps"]) - rec["ms_per_step"] * rec["steps"] / 1e3) <= 1e-9       # the line reports the slowest rank
