@@ -322,9 +322,9 @@ def launch_ranks(n: int, argv: list[str], script: str | None = None, grace_s: fl
     reader = threading.Thread(target=lambda: lines.extend(l.decode(errors="replace") for l in children[0].stdout), daemon=True)
     reader.start()
     failed_at = None
-    # a run that has not finished after MGCG_BENCH_TIMEOUT seconds (default 1500; the bench takes about a minute) is ended the same way:
+    # a run that has not finished after MGCG_BENCH_TIMEOUT seconds (default 900; the bench takes about a minute, a cold import of torch on a fresh box two or three) is ended the same way:
     # ranks left in a collective that will never complete must not hold the node
-    deadline_all = time.monotonic() + float(os.environ.get("MGCG_BENCH_TIMEOUT", "1500"))
+    deadline_all = time.monotonic() + float(os.environ.get("MGCG_BENCH_TIMEOUT", "900"))
     while True:
         codes = [c.poll() for c in children]
         if all(c is not None for c in codes):
