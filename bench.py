@@ -287,6 +287,34 @@ def mgcg_extra(L, n: int):
     return out
 
 
+class _watchdog:
+    """N > 1: a collective that never returns would hold the whole job until the launcher's limit.  If the guarded step takes longer than
+    MGCG_BENCH_STEP_TIMEOUT seconds (default 240) the rank says where it is blocked and leaves with status 4; the launcher then ends the
+    other ranks.  (os._exit: the blocked call holds the GPU runtime's locks, a normal exit would wait for it.)"""
+
+    def __init__(self, what: str, enabled: bool = True):
+        self.what, self.enabled, self.timer = what, enabled, None
+
+    def _fire(self):
+        print(f"bench.py: {self.what} did not finish within {self.limit:.0f} s -- leaving with status 4", file=sys.stderr, flush=True)
+        os._exit(4)
+
+    def __enter__(self):
+        if self.enabled:
+            import threading
+
+            self.limit = float(os.environ.get("MGCG_BENCH_STEP_TIMEOUT", "240"))
+            self.timer = threading.Timer(self.limit, self._fire)
+            self.timer.daemon = True
+            self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.timer is not None:
+            self.timer.cancel()
+        return False
+
+
 def _free_port() -> int:
     import socket
 
@@ -434,8 +462,9 @@ def main():
                 ok, why = 0, pre_why or "another rank failed the RCCL precondition"
             else:
                 try:
-                    comm = create_comm(rank, world)
-                    probe = L.MgcgCommAllReduceSum(comm, 1.0)
+                    with _watchdog(f"rank {rank}: ncclCommInitRank / the first all-reduce over {world} ranks"):
+                        comm = create_comm(rank, world)
+                        probe = L.MgcgCommAllReduceSum(comm, 1.0)
                     if probe != float(world):
                         ok, why = 0, f"RCCL all-reduce probe returned {probe}"
                 except Exception as ex:     # noqa: BLE001 -- any failure of the RCCL bootstrap
@@ -498,7 +527,8 @@ def main():
     if a.solver == "mgcg":
         cg.Setup()
     # warm-up (also builds the RCCL communicator and the halo plans)
-    run_steps(max(a.warmup, 1), True)
+    with _watchdog(f"rank {rank}: the warm-up iterations (halo plan, first exchanges and all-reduces)", enabled=world > 1):
+        run_steps(max(a.warmup, 1), True)
 
     def barrier():
         if dist is not None:
@@ -507,11 +537,12 @@ def main():
     L.MgcgProfileSpmv(cg.cusparse, 1)
     barrier()
     L.MgcgDeviceSynchronize()
-    t0 = time.perf_counter()
-    res = run_steps(a.steps, False)             # synchronises the stream before returning
-    L.MgcgDeviceSynchronize()
-    barrier()
-    dt = time.perf_counter() - t0
+    with _watchdog(f"rank {rank}: the timed steps", enabled=world > 1):        # (a sleeping timer thread: nothing inside the timed region)
+        t0 = time.perf_counter()
+        res = run_steps(a.steps, False)             # synchronises the stream before returning
+        L.MgcgDeviceSynchronize()
+        barrier()
+        dt = time.perf_counter() - t0
     launches = C.c_int(0)
     spmv_ms_total = L.MgcgProfileSpmvMs(cg.cusparse, C.byref(launches))
     L.MgcgProfileSpmv(cg.cusparse, 0)

@@ -95,3 +95,27 @@ def test_a_run_that_never_finishes_is_ended(tmp_path, capfd, monkeypatch):
     s = _script(tmp_path, "import time; time.sleep(600)")
     assert bench.launch_ranks(2, [], script=s, grace_s=0.2) == 128 + 15
     assert "did not finish" in capfd.readouterr().err
+
+
+def test_a_blocked_step_of_a_rank_ends_that_rank_with_a_message(tmp_path):
+    """The per-step watchdog of the ranks (N > 1: RCCL bootstrap, warm-up, timed steps): a step that never returns ends the rank with
+    status 4 and says where it was, instead of holding the job until the launcher's limit."""
+    code = textwrap.dedent(f"""
+        import os, sys, time
+        sys.path.insert(0, {ROOT!r})
+        os.environ["MGCG_BENCH_STEP_TIMEOUT"] = "0.3"
+        import bench
+        with bench._watchdog("rank 3: ncclCommInitRank"):
+            pass                                            # a step that finishes: the timer is cancelled
+        time.sleep(0.6)
+        print("still here", flush=True)
+        with bench._watchdog("rank 3: the warm-up iterations", enabled=False):
+            time.sleep(0.6)                                 # N = 1: no watchdog
+        with bench._watchdog("rank 3: the timed steps"):
+            time.sleep(30)
+        print("not reached")
+    """)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 4
+    assert "still here" in out.stdout and "not reached" not in out.stdout
+    assert "rank 3: the timed steps did not finish" in out.stderr and "status 4" in out.stderr
