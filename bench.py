@@ -336,6 +336,7 @@ def launch_ranks(n: int, argv: list[str], script: str | None = None, grace_s: fl
     script = script or os.environ.get("MGCG_BENCH_RANK_SCRIPT") or os.path.abspath(__file__)     # (the variable: tests/test_bench_launcher.py)
     env0 = dict(os.environ)
     env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on this driver
+    env0.setdefault("NCCL_DEBUG", "WARN")                    # RCCL says why when a communicator does not form (stderr; silent otherwise)
     env0["MASTER_ADDR"] = "127.0.0.1"
     env0["MASTER_PORT"] = str(env0.get("MGCG_BENCH_MASTER_PORT") or _free_port())
     env0["WORLD_SIZE"] = env0["LOCAL_WORLD_SIZE"] = str(n)
