@@ -46,3 +46,18 @@ def test_two_self_launched_ranks_check_themselves_against_one_rank(solver):
     pr = rec["per_rank"]
     assert len(pr["seconds_for_the_timed_steps"]) == 2 and len(pr["spmv_avg_launch_ms"]) == 2
     assert abs(max(pr["seconds_for_the_timed_steps"]) - rec["ms_per_step"] * rec["steps"] / 1e3) <= 1e-9       # the line reports the slowest rank
+
+
+@pytest.mark.parametrize("solver", ["cg", "mgcg"])
+def test_two_ranks_over_rccl_when_the_box_has_two_devices(solver):
+    """The same self-launched run WITHOUT --allow-fallback: two ranks on two devices form a real RCCL communicator (the one step no
+    one-GPU box can take), and the line's self-check says whether the partitioned loop computed what one rank computes.  Skipped on a
+    box with one device."""
+    from conjugategradient_amd import _lib
+
+    if _lib.lib().GetDeviceCount() < 2 or os.environ.get("MGCG_VIRTUAL_DEVICES"):
+        pytest.skip("needs two physical devices")
+    rec = _run("--gpus", "2", "--grid", "128", "--steps", "10", "--warmup", "3", "--solver", solver)
+    assert rec["n_gpus"] == 2 and rec["config"]["transport"] == "rccl"
+    par = rec["parity_vs_single_rank"]
+    assert par["within_1e-10"] is True, par
