@@ -105,3 +105,23 @@ def test_command_line_driver(oracle):
     assert bad.returncode == 1 and "must divide nz" in bad.stderr
     bad = subprocess.run([exe, "--rule", "nonsense"], capture_output=True, text=True)
     assert bad.returncode == 1 and "unknown --rule" in bad.stderr
+
+
+def test_single_process_ranks_over_rccl_when_the_box_has_two_devices(oracle):
+    """MgcgCommInitAll's RCCL branch (ncclGroupStart / N x ncclCommInitRank / ncclGroupEnd from ONE process, one host thread per device):
+    runs wherever the box has two physical devices -- the shape of the reference's ConjugateGradientParallelGpu on a multi-GPU host.
+    Skipped on a one-GPU box."""
+    from conjugategradient_amd import _lib
+
+    if _lib.lib().GetDeviceCount() < 2 or os.environ.get("MGCG_VIRTUAL_DEVICES"):
+        pytest.skip("needs two physical devices")
+    exe = os.path.join(ROOT, "conjugategradient_amd", "host", "mgcg_solve")
+    s = problems.poisson(16, 16, 16)
+    env = {k: v for k, v in os.environ.items() if k != "MGCG_VIRTUAL_DEVICES"}
+    for flags, ref in ((("--rule", "csharp"), oracle.cg(s, rule=oracle.RULE_CSHARP, max_iteration=2000)),
+                       (("--mgcg", "--levels", "3"), oracle.Multigrid(s, levels=3).pcg(rule=oracle.RULE_CSHARP, max_iteration=400))):
+        out = subprocess.run([exe, "--ranks", "2", "--n", "16", "--compression", "0", *flags], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        rec = json.loads(out.stdout.splitlines()[-1])
+        assert rec["ranks"] == 2 and rec["transport"] == "rccl" and rec["iteration"] == ref["iteration"]
+        assert abs(rec["sum_x"] - ref["x"].sum()) <= 1e-9 * np.abs(ref["x"]).sum()
