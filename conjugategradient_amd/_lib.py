@@ -122,6 +122,7 @@ SIGNATURES = {
     "SolveParallel": (_i, [_vp] * 12 + [_i, _i, _i, _i, _i, _i, _d, _i, _i, _i, _pi, _pd, _vp, _i]),
     "CgSteps": (_d, [_vp] * 11 + [_i, _i, _i, _i, _i, _i, _i, _i]),
     "MgcgLastOverlap": (_i, [_vp]),
+    "MgcgLastOverlapTimes": (_i, [_vp]),
     "MgcgLastVcycleFolds": (_i, []),
     "MgcgLastHalo": (_i, [_vp]),
     "MgcgDebugTileOrder": (_i, [_ll, _i, _i, _i, _vp, _i]),

@@ -141,9 +141,9 @@ bool comm_allreduce_sum(MgcgComm* c, double* devPtr, int count, hipStream_t s)
         if (count > 8) { set_error("callback all-reduce: at most 8 values"); return false; }
         double vals[8];
         bool ok = MGCG_HIP(hipMemcpyAsync(vals, devPtr, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
-        if (!ok) return false;
+        if (!ok) for (int i = 0; i < count; ++i) vals[i] = NAN;     // the peers are inside the callback: join them, with a value that poisons the sum
         c->cbAllReduce(vals, count, c->cbUser);
-        return MGCG_HIP(hipMemcpyAsync(devPtr, vals, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s)) && MGCG_HIP(hipStreamSynchronize(s));
+        return MGCG_HIP(hipMemcpyAsync(devPtr, vals, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s)) && MGCG_HIP(hipStreamSynchronize(s)) && ok;
     }
     if (c->comm == nullptr) return true;             // single rank without a communicator: the local sum is the sum
     Rccl* r = rccl();
@@ -168,6 +168,9 @@ struct HaloPlan {
     // force_multirank on a one-rank communicator: selfCount entries of p travel rank 0 -> rank 0 into selfBuf (results are not used)
     long long selfBegin = 0, selfCount = 0;
     double* selfBuf = nullptr;
+    // the measured overlap rule (halo_overlap_pays): -1 not measured yet, 0 exchange in line, 1 hide it behind the interior rows
+    int overlapPays = -1;
+    double exchangeUs = 0.0, forkJoinUs = 0.0;
 };
 
 // flags has `count` bytes followed by one aligned int: set when a column id lies outside [0, count) (nothing is written for it)
@@ -246,9 +249,24 @@ static bool exchange_host(MgcgComm* c, const std::vector<std::vector<double>>& s
 static bool halo_plan_index(MgcgComm* c, HaloPlan* h, const std::vector<long long>& all, long long count, long long offset, long long countLocal,
                             const int* columnIndeces, long long nnz);
 
-HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long long countLocal, int minJ, int maxJ,
-                           const int* columnIndeces, long long nnz, bool reuse)
+// Agreement on a local precondition among the ranks of a communicator (one all-reduce of a flag): false on EVERY rank when any rank
+// says false, so that no rank walks into the collectives of a call that another rank has already left.
+bool comm_agree(MgcgComm* c, bool localOk, const char* who)
 {
+    if (!c || c->nranks <= 1) return localOk;
+    double failed = localOk ? 0.0 : 1.0;
+    bool ok = MGCG_HIP(hipMemcpyAsync(c->scratch, &failed, sizeof(double), hipMemcpyHostToDevice, c->stream)) && MGCG_HIP(hipStreamSynchronize(c->stream));
+    ok = comm_allreduce_sum(c, c->scratch, 1, c->stream) && ok;
+    ok = ok && MGCG_HIP(hipMemcpyAsync(&failed, c->scratch, sizeof(double), hipMemcpyDeviceToHost, c->stream)) && MGCG_HIP(hipStreamSynchronize(c->stream));
+    if (!ok) return false;
+    if (!(failed == 0.0)) { if (localOk) set_error("%s: another rank failed its preconditions", who); return false; }
+    return true;
+}
+
+HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long long countLocal, int minJ, int maxJ,
+                           const int* columnIndeces, long long nnz, bool reuse, bool localOk)
+{
+    if (!localOk && !(c && c->nranks > 1 && reuse)) return nullptr;      // nobody to tell
     HaloPlan* h = new HaloPlan();
     if (c && c->nranks == 1 && comm_multi(c) && countLocal > 0) {
         long long w = tuning().forceMultiRank.load(std::memory_order_relaxed);
@@ -263,11 +281,15 @@ HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long 
     if (reuse) {   // the same partition as last time on every rank?  (collective: one all-reduce of "mine changed")
         const long long key[5] = { count, offset, countLocal, (long long)minJ, (long long)maxJ };
         const bool same = c->cachedPlan != nullptr && memcmp(key, c->cachedKey, sizeof(key)) == 0;
-        double changed = same ? 0.0 : 1.0;
-        bool ok = MGCG_HIP(hipMemcpyAsync(c->scratch, &changed, sizeof(double), hipMemcpyHostToDevice, c->stream)) && MGCG_HIP(hipStreamSynchronize(c->stream));
-        ok = comm_allreduce_sum(c, c->scratch, 1, c->stream) && ok;
-        ok = ok && MGCG_HIP(hipMemcpyAsync(&changed, c->scratch, sizeof(double), hipMemcpyDeviceToHost, c->stream)) && MGCG_HIP(hipStreamSynchronize(c->stream));
+        // {my partition changed, my preconditions failed}: the second flag makes a rank whose arguments are unusable leave TOGETHER with
+        // its peers here, instead of returning early and leaving them blocked in the solve's first collective
+        double flags[2] = { same ? 0.0 : 1.0, localOk ? 0.0 : 1.0 };
+        bool ok = MGCG_HIP(hipMemcpyAsync(c->scratch, flags, sizeof(flags), hipMemcpyHostToDevice, c->stream)) && MGCG_HIP(hipStreamSynchronize(c->stream));
+        ok = comm_allreduce_sum(c, c->scratch, 2, c->stream) && ok;
+        ok = ok && MGCG_HIP(hipMemcpyAsync(flags, c->scratch, sizeof(flags), hipMemcpyDeviceToHost, c->stream)) && MGCG_HIP(hipStreamSynchronize(c->stream));
         if (!ok) { delete h; return nullptr; }
+        if (!(flags[1] == 0.0)) { if (localOk) set_error("another rank failed its preconditions: the solve was not started on any rank"); delete h; return nullptr; }
+        const double changed = flags[0];
         if (changed == 0.0) { delete h; return c->cachedPlan; }
         if (c->cachedPlan) { c->cachedPlan->cached = false; halo_plan_destroy(c->cachedPlan); c->cachedPlan = nullptr; }
         memcpy(c->cachedKey, key, sizeof(key));
@@ -475,8 +497,8 @@ static bool halo_exchange_ranges(MgcgComm* c, HaloPlan* h, const double* src, do
             if (h->sendCount[q] > 0) ok = ok && MGCG_HIP(hipMemcpyAsync(c->cbSend[(size_t)q].data(), p + h->sendBegin[q], sizeof(double) * (size_t)h->sendCount[q], hipMemcpyDeviceToHost, s));
         }
         ok = MGCG_HIP(hipStreamSynchronize(s)) && ok;
+        c->cbExchange(n, sp.data(), h->sendCount.data(), rp.data(), h->recvCount.data(), c->cbUser);     // (also after a local copy error: the peers are waiting in it)
         if (!ok) return false;
-        c->cbExchange(n, sp.data(), h->sendCount.data(), rp.data(), h->recvCount.data(), c->cbUser);
         for (int q = 0; q < n; ++q)
             if (h->recvCount[q] > 0) ok = ok && MGCG_HIP(hipMemcpyAsync(dst + h->recvBegin[q], c->cbRecv[(size_t)q].data(), sizeof(double) * (size_t)h->recvCount[q], hipMemcpyHostToDevice, s));
         return MGCG_HIP(hipStreamSynchronize(s)) && ok;
@@ -517,6 +539,67 @@ bool halo_overlap_join(MgcgComm* c, hipStream_t mainStream)
     return MGCG_HIP(hipEventRecord(c->evHalo, c->haloStream)) && MGCG_HIP(hipStreamWaitEvent(mainStream, c->evHalo, 0));
 }
 
+__global__ void overlap_probe_kernel(int* p) { if (p) *p = 0; }
+
+static thread_local double t_lastOverlapTimes[3] = { 0.0, 0.0, 0.0 };   // measured?, exchange in line (us), fork + launch + join (us)
+void halo_overlap_last_times(double out[3]) { out[0] = t_lastOverlapTimes[0]; out[1] = t_lastOverlapTimes[1]; out[2] = t_lastOverlapTimes[2]; }
+
+// Does hiding THIS plan's exchange behind the interior rows pay on THIS communicator?  Measured once per plan, on the stream the loop
+// runs on: kReps exchanges of `vec` in line (idempotent: every halo entry is overwritten with its owner's value) against kReps
+// fork / empty launch / join round trips of the overlap schedule, both with HIP events; the overlap schedule also splits the boundary
+// rows off as a launch of their own (kBoundaryLaunchUs, profiles/r3/forced_path_timeline_*.log).  The two times are averaged over the
+// ranks by one all-reduce, so every rank takes the same decision from the same bits (a collective: all ranks call together, as they
+// do for the plan itself).  A local failure travels in the all-reduce as NaN and every rank answers "in line".
+constexpr double kBoundaryLaunchUs = 13.0;
+bool halo_overlap_pays(MgcgComm* c, HaloPlan* h, double* vec, hipStream_t s, bool* pays)
+{
+    *pays = false;
+    t_lastOverlapTimes[0] = 0.0; t_lastOverlapTimes[1] = 0.0; t_lastOverlapTimes[2] = 0.0;
+    if (!c || !h || !vec) return true;
+    if (h->overlapPays < 0) {
+        constexpr int kReps = 5;
+        hipEvent_t e[4] = { nullptr, nullptr, nullptr, nullptr };
+        bool ok = halo_overlap_available(c);
+        for (int i = 0; i < 4; ++i) ok = MGCG_HIP(hipEventCreate(&e[i])) && ok;
+        // every rank walks through the same exchanges whatever happened locally (a rank that left early would block its peers);
+        // ex says whether they all went out, ok whether the local timing can be trusted
+        bool ex = true;
+        for (int i = 0; i < 2; ++i) ex = halo_exchange(c, h, vec, s) && ex;                  // warm-up: RCCL builds its channels at the first use
+        ok = ok && MGCG_HIP(hipEventRecord(e[0], s));
+        for (int i = 0; i < kReps; ++i) ex = halo_exchange(c, h, vec, s) && ex;
+        ok = ok && MGCG_HIP(hipEventRecord(e[1], s));
+        for (int i = 0; ok && i < kReps + 1; ++i) {                                          // local only: fork / empty launch / join
+            if (i == 1) ok = MGCG_HIP(hipEventRecord(e[2], s));                              // (the first round trip is the warm-up)
+            hipStream_t side = ok ? halo_overlap_fork(c, s) : nullptr;
+            ok = ok && side != nullptr;
+            if (ok) hipLaunchKernelGGL(overlap_probe_kernel, dim3(1), dim3(1), 0, side, (int*)nullptr);
+            ok = ok && halo_overlap_join(c, s);
+        }
+        ok = ok && MGCG_HIP(hipEventRecord(e[3], s)) && MGCG_HIP(hipEventSynchronize(e[3]));
+        double us[2] = { NAN, NAN };
+        float msEx = 0.0f, msFj = 0.0f;
+        if (ok && ex && MGCG_HIP(hipEventElapsedTime(&msEx, e[0], e[1])) && MGCG_HIP(hipEventElapsedTime(&msFj, e[2], e[3]))) {
+            us[0] = 1e3 * (double)msEx / kReps; us[1] = 1e3 * (double)msFj / kReps;
+        }
+        (void)hipStreamSynchronize(s);
+        for (int i = 0; i < 4; ++i) if (e[i]) (void)hipEventDestroy(e[i]);
+        bool g = MGCG_HIP(hipMemcpyAsync(c->scratch, us, sizeof(us), hipMemcpyHostToDevice, s)) && MGCG_HIP(hipStreamSynchronize(s));
+        g = comm_allreduce_sum(c, c->scratch, 2, s) && g;
+        g = g && MGCG_HIP(hipMemcpyAsync(us, c->scratch, sizeof(us), hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
+        if (!g) return false;
+        const int n = c->nranks > 0 ? c->nranks : 1;
+        h->exchangeUs = us[0] / n; h->forkJoinUs = us[1] / n;
+        // (a NaN -- some rank could not measure -- compares false: in line)
+        h->overlapPays = (h->exchangeUs > h->forkJoinUs + kBoundaryLaunchUs) ? 1 : 0;
+        if (tuning().verbose.load(std::memory_order_relaxed) >= 1)
+            fprintf(stderr, "[MgcgGpu] halo of %lld entries: exchange in line %.1f us, fork + launch + join %.1f us (+ %.0f us for the boundary rows' own launch) -> %s\n",
+                    h->indexed ? h->recvTotal : (h->selfCount > 0 ? h->selfCount : h->contiguousRecv), h->exchangeUs, h->forkJoinUs, kBoundaryLaunchUs, h->overlapPays ? "overlap" : "in line");
+    }
+    *pays = h->overlapPays == 1;
+    t_lastOverlapTimes[0] = 1.0; t_lastOverlapTimes[1] = h->exchangeUs; t_lastOverlapTimes[2] = h->forkJoinUs;
+    return true;
+}
+
 void preload_comm() { preload_code_object(reinterpret_cast<const void*>(&halo_pack_kernel)); }
 
 } // namespace mgcg
@@ -540,6 +623,7 @@ int MgcgCommGetUniqueId(void* id128)
 MgcgComm* MgcgCommInitRank(const void* id128, int nranks, int rank)
 {
     if (nranks < 1 || rank < 0 || rank >= nranks) { set_error("MgcgCommInitRank: bad rank %d of %d", rank, nranks); return nullptr; }
+    if (tuning().failCommInit.load(std::memory_order_relaxed)) { set_error("MgcgCommInitRank: MGCG_FAIL_COMM_INIT is set (test hook)"); return nullptr; }
     // ncclCommInitRank comes first: before this rank creates its stream or allocates anything (only the device is selected)
     if (!select_device_only()) return nullptr;
     MgcgComm* c = new MgcgComm();
@@ -564,6 +648,7 @@ int MgcgCommInitAll(MgcgComm* comms[], int ndev)
 {
     if (!comms || ndev < 1 || ndev > kMaxDevices) { set_error("MgcgCommInitAll: bad argument"); return -1; }
     for (int d = 0; d < ndev; ++d) comms[d] = nullptr;            // (the caller's array has ndev entries: that is the contract)
+    if (tuning().failCommInit.load(std::memory_order_relaxed)) { set_error("MgcgCommInitAll: MGCG_FAIL_COMM_INIT is set (test hook)"); return -1; }
     int phys = 0;
     if (hipGetDeviceCount(&phys) != hipSuccess || phys <= 0) { set_error("no HIP device available (hipGetDeviceCount = %d): the HIP path cannot run", phys); return -1; }
     if (ndev > GetDeviceCount()) { set_error("MgcgCommInitAll: %d communicators asked for, %d device(s)", ndev, GetDeviceCount()); return -1; }
@@ -620,13 +705,13 @@ __global__ void probe_empty_kernel(int* p) { if (p) *p = 0; }
 double MgcgCommProbe(MgcgComm* c, int what, int count, int reps)
 {
     DeviceState* d = device_state();
-    if (!d || !c || reps < 1 || count < 0 || what < 0 || what > 3) { if (d) set_error("MgcgCommProbe: bad argument"); return NAN; }
+    if (!d || !c || reps < 1 || count < 0 || what < 0 || what > 4) { if (d) set_error("MgcgCommProbe: bad argument"); return NAN; }
     hipStream_t s = c->stream ? c->stream : d->stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     double* buf = nullptr;
     const size_t n = (size_t)(count > 8 ? count : 8);
-    bool ok = MGCG_HIP(hipEventCreate(&e0)) && MGCG_HIP(hipEventCreate(&e1)) && MGCG_HIP(hipMalloc((void**)&buf, sizeof(double) * 2 * n)) &&
-              MGCG_HIP(hipMemsetAsync(buf, 0, sizeof(double) * 2 * n, s));
+    bool ok = MGCG_HIP(hipEventCreate(&e0)) && MGCG_HIP(hipEventCreate(&e1)) && MGCG_HIP(hipMalloc((void**)&buf, sizeof(double) * 4 * n)) &&
+              MGCG_HIP(hipMemsetAsync(buf, 0, sizeof(double) * 4 * n, s));
     Rccl* r = (c->comm != nullptr) ? rccl() : nullptr;
     auto once = [&]() -> bool {
         switch (what) {
@@ -638,6 +723,17 @@ double MgcgCommProbe(MgcgComm* c, int what, int count, int reps)
                 if (q == c->rank && c->nranks > 1) continue;
                 g = g && nccl_ok(r->Send(buf, (size_t)count, NCCL_DOUBLE, q, c->comm, s), "ncclSend");
                 g = g && nccl_ok(r->Recv(buf + n, (size_t)count, NCCL_DOUBLE, q, c->comm, s), "ncclRecv");
+            }
+            return nccl_ok(r->GroupEnd(), "ncclGroupEnd") && g;
+        }
+        case 4: {                                                  // the stencil's exchange: `count` doubles to and from ranks rank - 1 and rank + 1 only
+            if (!r) return true;
+            bool g = nccl_ok(r->GroupStart(), "ncclGroupStart");
+            for (int dq = -1; g && dq <= 1; dq += 2) {
+                const int q = c->nranks > 1 ? c->rank + dq : 0;
+                if (q < 0 || q >= c->nranks || (c->nranks == 1 && dq > 0)) continue;
+                g = g && nccl_ok(r->Send(buf + (dq > 0 ? count : 0), (size_t)count, NCCL_DOUBLE, q, c->comm, s), "ncclSend");
+                g = g && nccl_ok(r->Recv(buf + 2 * n + (dq > 0 ? count : 0), (size_t)count, NCCL_DOUBLE, q, c->comm, s), "ncclRecv");
             }
             return nccl_ok(r->GroupEnd(), "ncclGroupEnd") && g;
         }

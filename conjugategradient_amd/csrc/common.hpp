@@ -42,7 +42,7 @@ bool hip_ok(hipError_t e, const char* what, const char* file, int line);
 // MgcgReloadEnvironment() reads the environment again.  Nothing here changes results: every knob picks between bit-identical
 // schedules (include/MgcgGpu.h lists them).
 struct Tuning {
-    std::atomic<int> overlap{1};             // MGCG_OVERLAP            0 off, 1 when it pays, 2 whenever an interior exists
+    std::atomic<int> overlap{1};             // MGCG_OVERLAP            0 off, 1 where the measured exchange costs more than the hops that hide it, 2 whenever an interior exists
     std::atomic<int> noFold{0};              // MGCG_NO_FOLD            V(1,*): store the first sweep instead of forming it per gather
     std::atomic<int> foldUp{-1};             // MGCG_FOLD_UP            V(1,1): x1 + P e formed per gather of the last sweep instead of a prolongation kernel + stored iterate:
                                              //                         -1 by level size (it pays up to a few ten million rows), 0 never, 1 wherever possible
@@ -66,6 +66,7 @@ struct Tuning {
                                              //                         1 the halo exchange on the side stream, all rows on the main stream (measured faster on one GPU, solver.hip;
                                              //                         opt-in until RCCL on two streams of one communicator has run on real multi-GPU hardware)
     std::atomic<int> forceMultiRank{0};      // MGCG_FORCE_MULTIRANK    a one-rank communicator takes the several-ranks code path (measurement)
+    std::atomic<int> failCommInit{0};        // MGCG_FAIL_COMM_INIT     tests only: MgcgCommInitAll / MgcgCommInitRank report failure (what a host without a working RCCL does)
 };
 Tuning& tuning();
 void tuning_reload();
@@ -425,7 +426,10 @@ struct HaloPlan;  // per-peer contiguous send/recv ranges of p
 // reuse: the plan of a solve's own vector p -- kept on the communicator and handed out again while every rank calls with the same partition
 // (one 8-byte all-reduce decides); such a plan is not freed by halo_plan_destroy.  Plans of multigrid levels are never shared.
 HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long long countLocal, int minJ, int maxJ,
-                           const int* columnIndeces = nullptr, long long nnz = 0, bool reuse = false);
+                           const int* columnIndeces = nullptr, long long nnz = 0, bool reuse = false, bool localOk = true);
+// localOk (reuse plans only, several ranks): this rank's verdict on its own arguments, folded into the plan's one all-reduce -- when any
+// rank says false, every rank gets nullptr and nobody enters the solve's collectives.
+bool comm_agree(MgcgComm* c, bool localOk, const char* who);   // the same agreement as a call of its own (set-up paths)
 void halo_last(long long out[3]);   // calling thread's last exchange: {index lists used, entries received, entries the contiguous plan receives}
 void halo_plan_destroy(HaloPlan* h);
 bool halo_exchange(MgcgComm* c, HaloPlan* h, double* p, hipStream_t s);
@@ -433,5 +437,8 @@ bool halo_exchange(MgcgComm* c, HaloPlan* h, double* p, hipStream_t s);
 bool halo_overlap_available(MgcgComm* c);
 hipStream_t halo_overlap_fork(MgcgComm* c, hipStream_t mainStream);   // side stream, ordered after everything enqueued on mainStream so far
 bool halo_overlap_join(MgcgComm* c, hipStream_t mainStream);          // mainStream waits for the side stream
+// the measured overlap rule (collective; once per plan): *pays = this plan's exchange in line costs more than the hops that would hide it
+bool halo_overlap_pays(MgcgComm* c, HaloPlan* h, double* vec, hipStream_t s, bool* pays);
+void halo_overlap_last_times(double out[3]);   // calling thread's last decision: {measured?, exchange in line (us), fork + launch + join (us)}
 
 } // namespace mgcg

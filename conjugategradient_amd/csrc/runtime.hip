@@ -47,6 +47,7 @@ const Knob kKnobs[] = {
     { "MGCG_VIRTUAL_DEVICES", "virtual_devices", &Tuning::virtualDevices, 0, false },
     { "MGCG_HALO_STREAM", "halo_stream", &Tuning::haloStream, 0, false },
     { "MGCG_FORCE_MULTIRANK", "force_multirank", &Tuning::forceMultiRank, 0, false },
+    { "MGCG_FAIL_COMM_INIT", "fail_comm_init", &Tuning::failCommInit, 0, false },
 };
 Tuning g_tuning;
 std::once_flag g_tuningOnce;

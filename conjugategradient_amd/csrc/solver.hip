@@ -69,17 +69,27 @@ static SpmvConfig cfg_of(const MgcgSparse* h)
 
 // The interior rows of a row slice -- rows [*i0, *i1) reference local columns only -- and whether its halo exchange should hide behind them
 // (*active).  The range is found for every slice of several ranks (the multigrid's folded residual pass uses it with or without overlap);
-// MGCG_OVERLAP decides *active: 0 never, 1 (default) when it pays, 2 whenever an interior exists (tests).
+// MGCG_OVERLAP decides *active: 0 never; 2 whenever an interior exists (tests); 1 (default) BY MEASUREMENT -- on slices of at least
+// kOverlapMinRows rows per rank on average the plan's own exchange is timed in line against the fork / launch / join round trip of the
+// overlap schedule on this communicator (halo_overlap_pays, comm.hip: once per plan, the same answer on every rank), and the exchange is
+// hidden only where it costs more than the hops that hide it.  (Round 3 decided by size alone, >= 3 M rows: on the one-rank RCCL
+// communicator of a one-GPU box that rule picked the slowest schedule measured, profiles/r3/slab_latency_box_e_final_code.json.)
+// halo / vec: the plan of the slice and the full-length vector it exchanges.  nGlobal: rows of all ranks (the same number everywhere,
+// so all ranks enter the measurement's collective together or not at all).
 // d2: two device ints of the caller's workspace (Workspace::devInts + 6)
+constexpr long long kOverlapMinRows = 1000000;
 static bool plan_overlap(hipStream_t s, MgcgComm* comm, bool multi, const int* rowOffsets, const int* columnIndeces,
-                         long long n, long long offset, bool* active, long long* i0, long long* i1, int* d2)
+                         long long n, long long offset, bool* active, long long* i0, long long* i1, int* d2,
+                         HaloPlan* halo, double* vec, long long nGlobal)
 {
     *active = false; *i0 = 0; *i1 = 0;
-    if (!multi || n <= 0) return true;
+    if (!multi) return true;
     const int mode = tuning().overlap.load(std::memory_order_relaxed);
-    // mode 1: only where the rows between fork and join outlast the two cross-stream hops (10 us each, measured) and the exchange --
-    // a row-tile SpMV streams ~55 k rows per us, so below ~3 M rows the exchange in line is the cheaper schedule (profiles/r3/slab_latency.json)
-    const bool wanted = mode == 2 || (mode == 1 && n >= 3000000);
+    bool wanted = mode == 2;
+    if (mode == 1 && nGlobal >= kOverlapMinRows * (long long)MgcgCommSize(comm)) {
+        if (!halo_overlap_pays(comm, halo, vec, s, &wanted)) return false;       // collective
+    }
+    if (n <= 0) return true;
     if (MgcgCommSize(comm) == 1) {
         // one rank forced onto the several-ranks path (measurement): an artificial split -- the first and last force_multirank rows
         // (rounded to SpMV tiles) play the boundary
@@ -377,7 +387,7 @@ static thread_local long long t_lastOverlap[3] = { 0, 0, 0 };
 static bool cg_plan_overlap(CgRun& R)
 {
     t_lastOverlap[0] = 0; t_lastOverlap[1] = 0; t_lastOverlap[2] = 0;
-    if (!plan_overlap(R.ws->stream, R.comm, R.multi, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.overlap, &R.interior0, &R.interior1, R.ws->devInts + 6)) return false;
+    if (!plan_overlap(R.ws->stream, R.comm, R.multi, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.overlap, &R.interior0, &R.interior1, R.ws->devInts + 6, R.halo, R.p, R.count)) return false;
     if (R.overlap) { t_lastOverlap[0] = 1; t_lastOverlap[1] = R.interior0; t_lastOverlap[2] = R.interior1; }
     return true;
 }
@@ -671,10 +681,17 @@ int SolveParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMa
 {
     (void)matDescr;
     if (!device_state()) return MGCG_ERROR;
-    if (!cublas || !cusparse) { set_error("SolveParallel: null handle"); return MGCG_ERROR; }
-    if (!check_vectors("SolveParallel", elementsVector, rowOffsetsVector, columnIndecesVector, xVector, bVector, ApVector, pVector, rVector,
-                       elementsCountForDevice, countForDevice, count)) return MGCG_ERROR;
-    if (offsetForDevice < 0 || (long long)offsetForDevice + countForDevice > count) { set_error("SolveParallel: bad partition"); return MGCG_ERROR; }
+    // A rank whose own arguments are unusable must not simply return: its peers would block in the solve's first collective.  The verdict
+    // travels in the halo plan's one all-reduce (halo_plan_create, localOk) and every rank leaves with MGCG_ERROR.
+    bool pre = true;
+    if (!cublas || !cusparse) { set_error("SolveParallel: null handle"); pre = false; }
+    pre = pre && check_vectors("SolveParallel", elementsVector, rowOffsetsVector, columnIndecesVector, xVector, bVector, ApVector, pVector, rVector,
+                               elementsCountForDevice, countForDevice, count);
+    if (pre && (offsetForDevice < 0 || (long long)offsetForDevice + countForDevice > count)) { set_error("SolveParallel: bad partition"); pre = false; }
+    if (!pre) {
+        if (MgcgCommSize(comm) > 1) (void)halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, nullptr, 0, true, false);
+        return MGCG_ERROR;
+    }
     CgRun R;
     R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse; R.comm = comm; R.nranks = MgcgCommSize(comm); R.multi = comm_multi(comm);
     R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCountForDevice;
@@ -698,9 +715,15 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
                int minJ, int maxJ, int steps, int restart)
 {
     if (!device_state()) return NAN;
-    if (!cublas || !cusparse) { set_error("CgSteps: null handle"); return NAN; }
-    if (!check_vectors("CgSteps", elementsVector, rowOffsetsVector, columnIndecesVector, xVector, bVector, ApVector, pVector, rVector,
-                       elementsCountForDevice, countForDevice, count)) return NAN;
+    bool pre = true;
+    if (!cublas || !cusparse) { set_error("CgSteps: null handle"); pre = false; }
+    pre = pre && check_vectors("CgSteps", elementsVector, rowOffsetsVector, columnIndecesVector, xVector, bVector, ApVector, pVector, rVector,
+                               elementsCountForDevice, countForDevice, count);
+    if (pre && (offsetForDevice < 0 || (long long)offsetForDevice + countForDevice > count)) { set_error("CgSteps: bad partition"); pre = false; }
+    if (!pre) {       // leave together with the peers (see SolveParallel)
+        if (MgcgCommSize(comm) > 1) (void)halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, nullptr, 0, true, false);
+        return NAN;
+    }
     CgRun R;
     R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse; R.comm = comm; R.nranks = MgcgCommSize(comm); R.multi = comm_multi(comm);
     R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCountForDevice;
@@ -743,6 +766,13 @@ int MgcgLastHalo(long long volume[2])
 
 int MgcgLastVcycleFolds(void) { return t_lastFolds; }
 
+int MgcgLastOverlapTimes(double microseconds[2])
+{
+    double t[3]; halo_overlap_last_times(t);
+    if (microseconds) { microseconds[0] = t[1]; microseconds[1] = t[2]; }
+    return (int)t[0];
+}
+
 int MgcgLastOverlap(long long interior[2])
 {
     if (interior) { interior[0] = t_lastOverlap[1]; interior[1] = t_lastOverlap[2]; }
@@ -781,15 +811,17 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
 {
     DeviceState* d = device_state();
     if (!d) return nullptr;
-    if (!cublas || !cusparse || !elementsVector || !rowOffsetsVector || !columnIndecesVector) { set_error("MgSetup: null argument"); return nullptr; }
     const long long nGlobal0 = (long long)nx * ny * nz;
     const int nranks = MgcgCommSize(comm);
-    if (nx < 1 || ny < 1 || nz < 1 || levels < 1 || nu < 1 || nuCoarse < 1 || nGlobal0 > 0x7fffffffLL || zBegin < 0 || zEnd > nz || zBegin >= zEnd) { set_error("MgSetup: bad parameters"); return nullptr; }
     const long long nLocal0 = (long long)nx * ny * (zEnd - zBegin);
-    if (rowOffsetsVector->size < nLocal0 + 1 || elementsVector->size < elementsCount || columnIndecesVector->size < elementsCount) { set_error("MgSetup: matrix vectors too small"); return nullptr; }
-    if (nranks > 1 && (nz % nranks != 0 || (zEnd - zBegin) != nz / nranks || zBegin != MgcgCommRank(comm) * (nz / nranks))) {
-        set_error("MgSetup: with several ranks the grid must be split into equal z-slabs in rank order"); return nullptr;
+    bool pre = true;
+    if (!cublas || !cusparse || !elementsVector || !rowOffsetsVector || !columnIndecesVector) { set_error("MgSetup: null argument"); pre = false; }
+    if (pre && (nx < 1 || ny < 1 || nz < 1 || levels < 1 || nu < 1 || nuCoarse < 1 || nGlobal0 > 0x7fffffffLL || zBegin < 0 || zEnd > nz || zBegin >= zEnd)) { set_error("MgSetup: bad parameters"); pre = false; }
+    if (pre && (rowOffsetsVector->size < nLocal0 + 1 || elementsVector->size < elementsCount || columnIndecesVector->size < elementsCount)) { set_error("MgSetup: matrix vectors too small"); pre = false; }
+    if (pre && nranks > 1 && (nz % nranks != 0 || (zEnd - zBegin) != nz / nranks || zBegin != MgcgCommRank(comm) * (nz / nranks))) {
+        set_error("MgSetup: with several ranks the grid must be split into equal z-slabs in rank order"); pre = false;
     }
+    if (!comm_agree(comm, pre, "MgSetup")) return nullptr;       // collective: a rank with unusable arguments leaves together with its peers
     hipStream_t s = d->stream;
     MgcgMg* mg = new MgcgMg();
     mg->omega = omega; mg->nu = nu; mg->nuCoarse = nuCoarse; mg->sigma = sigma; mg->stream = s; mg->cfg = cfg_of(cusparse);
@@ -874,7 +906,7 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
             ok = ok && MGCG_HIP(hipStreamSynchronize(s));
             L.minJ = out[0]; L.maxJ = out[1];
             if (ok) { L.halo = halo_plan_create(comm, L.nGlobal, L.offset, L.n, L.minJ, L.maxJ); ok = L.halo != nullptr; }
-            ok = ok && plan_overlap(s, comm, mg->multi, L.rowOffsets, L.columnIndeces, L.n, L.offset, &L.overlap, &L.interior0, &L.interior1, cublas->ws.devInts + 6);
+            ok = ok && plan_overlap(s, comm, mg->multi, L.rowOffsets, L.columnIndeces, L.n, L.offset, &L.overlap, &L.interior0, &L.interior1, cublas->ws.devInts + 6, L.halo, L.xa, L.nGlobal);
         }
         mg->lv.push_back(L);
         mg->levels = (int)mg->lv.size();
@@ -973,14 +1005,19 @@ int SolveMgParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, Mgcg
 {
     (void)matDescr;
     if (!device_state()) return MGCG_ERROR;
-    if (!cublas || !cusparse || !mg || !zVector) { set_error("SolveMg: null handle"); return MGCG_ERROR; }
-    if (!check_vectors("SolveMg", elementsVector, rowOffsetsVector, columnIndecesVector, xVector, bVector, ApVector, pVector, rVector,
-                       elementsCountForDevice, countForDevice, count)) return MGCG_ERROR;
-    if (zVector->size < countForDevice || mg->lv[0].n != countForDevice || mg->lv[0].nGlobal != count || mg->lv[0].offset != offsetForDevice) {
-        set_error("SolveMg: z vector or hierarchy does not match the problem"); return MGCG_ERROR;
+    bool pre = true;
+    if (!cublas || !cusparse || !mg || !zVector) { set_error("SolveMg: null handle"); pre = false; }
+    pre = pre && check_vectors("SolveMg", elementsVector, rowOffsetsVector, columnIndecesVector, xVector, bVector, ApVector, pVector, rVector,
+                               elementsCountForDevice, countForDevice, count);
+    if (pre && (zVector->size < countForDevice || mg->lv[0].n != countForDevice || mg->lv[0].nGlobal != count || mg->lv[0].offset != offsetForDevice)) {
+        set_error("SolveMg: z vector or hierarchy does not match the problem"); pre = false;
     }
-    if (mg->nranks != MgcgCommSize(comm) || mg->multi != comm_multi(comm)) { set_error("SolveMg: the hierarchy was built for %d rank(s)%s", mg->nranks, mg->multi ? " on the several-ranks path" : ""); return MGCG_ERROR; }
-    if (rule == MGCG_RULE_HANDMADECL || rule == MGCG_RULE_VIENNACL) { set_error("SolveMg supports the 2-norm absolute rules only"); return MGCG_ERROR; }
+    if (pre && (mg->nranks != MgcgCommSize(comm) || mg->multi != comm_multi(comm))) { set_error("SolveMg: the hierarchy was built for %d rank(s)%s", mg->nranks, mg->multi ? " on the several-ranks path" : ""); pre = false; }
+    if (pre && (rule == MGCG_RULE_HANDMADECL || rule == MGCG_RULE_VIENNACL)) { set_error("SolveMg supports the 2-norm absolute rules only"); pre = false; }
+    if (!pre) {       // leave together with the peers (see SolveParallel)
+        if (MgcgCommSize(comm) > 1) (void)halo_plan_create(comm, count, offsetForDevice, countForDevice, minJ, maxJ, nullptr, 0, true, false);
+        return MGCG_ERROR;
+    }
     CgRun R;
     R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse; R.mg = mg; R.comm = comm; R.nranks = MgcgCommSize(comm); R.multi = comm_multi(comm);
     R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCountForDevice;

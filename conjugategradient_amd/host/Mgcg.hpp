@@ -228,6 +228,7 @@ public:
     bool BalanceNonzeros = false;        // not in the reference: row ranges of equal NONZERO count instead of floor(count / devices) rows, chosen at
                                          // Initialize() from A's row offsets (a matrix with uneven rows: the slowest device sets the iteration time)
     std::string LastPath = "none";       // "native loop (SolveParallel over <transport>)" or "host-driven phases (Solve0..3)"
+    std::string CommFailure;             // why the communicators of the native loop could not be formed ("" when they were); UsePhases is then true
 private:
     int deviceCount;
     std::vector<MgcgComm*> comms;
@@ -262,7 +263,16 @@ public:
         if (deviceCount < 1) throw MgcgError("no GPU");
         const size_t n = (size_t)deviceCount;
         comms.assign(n, nullptr);
-        if (MgcgCommInitAll(comms.data(), deviceCount) != 0) { Check("MgcgCommInitAll"); throw MgcgError("MgcgCommInitAll failed"); }   // before any handle or vector exists
+        // The communicators of the native loop come first (before any handle or vector exists).  If they cannot be formed -- RCCL missing or
+        // refusing on this host -- the class still works: it keeps the reference's own host-driven phases, which need no communicator, and
+        // CommFailure / LastPath say why.
+        if (MgcgCommInitAll(comms.data(), deviceCount) != 0) {
+            const char* e = MgcgGetLastError();
+            CommFailure = (e && *e) ? e : "MgcgCommInitAll failed";
+            MgcgClearLastError();
+            comms.assign(n, nullptr);
+            UsePhases = true;
+        }
         offsetsForDevice.assign(n + 1, 0);
         for (int i = 1; i < deviceCount; i++) offsetsForDevice[(size_t)i] = offsetsForDevice[(size_t)i - 1] + (int)std::floor((double)Count() / deviceCount);
         offsetsForDevice[n] = Count();
@@ -270,23 +280,33 @@ public:
         cublas.assign(n, nullptr); cusparse.assign(n, nullptr); matDescr.assign(n, nullptr);
         vectorElements.assign(n, nullptr); vectorX.assign(n, nullptr); vectorB.assign(n, nullptr); vectorAp.assign(n, nullptr); vectorP.assign(n, nullptr); vectorR.assign(n, nullptr);
         vectorColumnIndeces.assign(n, nullptr); vectorRowOffsets.assign(n, nullptr);
-        ParallelFor([&](int d) {
-            const size_t i = (size_t)d; const int c = CountForDevice(d);
-            cublas[i] = CreateBlas(); cusparse[i] = CreateSparse(); matDescr[i] = CreateMatDescr();
-            vectorElements[i] = new VectorDouble(c * maxNonZeroCount); vectorColumnIndeces[i] = new VectorInt(c * maxNonZeroCount); vectorRowOffsets[i] = new VectorInt(c + 1);
-            vectorX[i] = new VectorDouble(c); vectorB[i] = new VectorDouble(c); vectorAp[i] = new VectorDouble(c); vectorP[i] = new VectorDouble(count); vectorR[i] = new VectorDouble(c);
-        });
+        try {
+            ParallelFor([&](int d) {
+                const size_t i = (size_t)d; const int c = CountForDevice(d);
+                cublas[i] = CreateBlas(); cusparse[i] = CreateSparse(); matDescr[i] = CreateMatDescr();
+                vectorElements[i] = new VectorDouble(c * maxNonZeroCount); vectorColumnIndeces[i] = new VectorInt(c * maxNonZeroCount); vectorRowOffsets[i] = new VectorInt(c + 1);
+                vectorX[i] = new VectorDouble(c); vectorB[i] = new VectorDouble(c); vectorAp[i] = new VectorDouble(c); vectorP[i] = new VectorDouble(count); vectorR[i] = new VectorDouble(c);
+            });
+        } catch (...) { Release(); throw; }      // (a constructor that throws runs no destructor: nothing may be left on the devices)
     }
-    ~ConjugateGradientParallelGpu() override
+private:
+    void Release()
     {
         for (int d = 0; d < deviceCount; d++) {
             const size_t i = (size_t)d; SetDevice(d);
             delete vectorElements[i]; delete vectorColumnIndeces[i]; delete vectorRowOffsets[i];
             delete vectorX[i]; delete vectorB[i]; delete vectorAp[i]; delete vectorP[i]; delete vectorR[i];
-            DestroyBlas(cublas[i]); DestroySparse(cusparse[i]); DestroyMatDescr(matDescr[i]);
-            MgcgCommDestroy(comms[i]);
+            vectorElements[i] = vectorX[i] = vectorB[i] = vectorAp[i] = vectorP[i] = vectorR[i] = nullptr; vectorColumnIndeces[i] = vectorRowOffsets[i] = nullptr;
+            if (cublas[i]) DestroyBlas(cublas[i]);
+            if (cusparse[i]) DestroySparse(cusparse[i]);
+            if (matDescr[i]) DestroyMatDescr(matDescr[i]);
+            cublas[i] = nullptr; cusparse[i] = nullptr; matDescr[i] = nullptr;
+            if (comms[i]) MgcgCommDestroy(comms[i]);
+            comms[i] = nullptr;
         }
     }
+public:
+    ~ConjugateGradientParallelGpu() override { Release(); }
     int DeviceCount() const { return deviceCount; }
     int OffsetForDevice(int d) const { return offsetsForDevice[(size_t)d]; }
     void Initialize() override
@@ -321,7 +341,10 @@ public:
     }
     void Solve() override
     {
-        if (UsePhases) { LastPath = "host-driven phases (Solve0..3)"; SolvePhases(); return; }
+        if (UsePhases || !comms[0]) {
+            LastPath = std::string("host-driven phases (Solve0..3)") + (CommFailure.empty() ? "" : " -- no communicators: " + CommFailure);
+            SolvePhases(); return;
+        }
         LastPath = std::string("native loop (SolveParallel over ") + MgcgCommTransport(comms[0]) + ")";
         std::vector<int> iteration((size_t)deviceCount, 0), status((size_t)deviceCount, MGCG_ERROR);
         std::vector<double> residual((size_t)deviceCount, 0.0);

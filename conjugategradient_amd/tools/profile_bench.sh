@@ -6,6 +6,9 @@
 set -u
 OUT=$1; shift
 ARGS="$*"
+# one rank only: bench.py --gpus N > 1 starts its ranks from a parent that must be GPU-free, and under rocprofv3 the parent is not
+# (profile a single rank of the several-ranks path with tools/forced_path_run.py instead)
+case " $ARGS " in *" --gpus "[2-9]*|*" --gpus="[2-9]*|*" --gpus "1[0-9]*) echo "profile_bench.sh: --gpus > 1 is refused under the profiler (use tools/forced_path_run.py)" >&2; exit 2;; esac
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 export PYTHONPATH=$GRAFT_REPO_ROOT

@@ -160,7 +160,9 @@ void        MgcgClearLastError(void);
 int         MgcgAbiVersion(void);
 /* Tuning knobs.  Every MGCG_* environment variable the library honours is read once, at first use; launches never read
  * the environment.  All knobs choose between schedules that give bit-identical results:
- *   overlap (MGCG_OVERLAP: 0 halo exchange in line, 1 hidden behind interior rows when it pays [default], 2 whenever an
+ *   overlap (MGCG_OVERLAP: 0 halo exchange in line; 1 [default] hidden behind the interior rows where that pays BY MEASUREMENT -- for
+ *   slices of >= 1 M rows per rank the plan's own exchange is timed in line against the fork / launch / join round trip of the overlap
+ *   schedule on the live communicator, once per plan, and every rank takes the same decision from the all-reduced times; 2 whenever an
  *   interior exists), no_fold, fold_up (MGCG_FOLD_UP: -1 [default] the prolongation of a V(1,1) cycle is formed per gather of the
  *   post-smoothing sweep on levels of up to 100 M rows, 0 never, 1 on every level), no_folded_finalize, check_every (iterations
  *   enqueued ahead of the stop flag, default 4), vector_vals_nt, tile_pack, auto_tiles,
@@ -171,7 +173,9 @@ int         MgcgAbiVersion(void);
  *   main stream; 1 the halo exchange runs on the side stream and all rows on the main stream -- 19 us less per iteration on one
  *   rank's slab, opt-in until RCCL on two streams of one communicator has been run on real multi-GPU hardware),
  *   force_multirank (MGCG_FORCE_MULTIRANK = w > 0: a one-rank RCCL communicator takes the several-ranks code path with an
- *   artificial halo of w entries, for measuring that path's device-side cost on a one-GPU box).
+ *   artificial halo of w entries, for measuring that path's device-side cost on a one-GPU box),
+ *   fail_comm_init (MGCG_FAIL_COMM_INIT, tests only: MgcgCommInitAll / MgcgCommInitRank report failure, as on a host whose RCCL
+ *   cannot form a communicator -- callers must then fall back or fail loudly).
  * MgcgSetTuning / MgcgGetTuning take the knob's name or its environment variable; they return 0, or -1 for an unknown
  * name (MgcgGetLastError).  MgcgReloadEnvironment reads all variables again.  Change knobs only while no solve is running. */
 int         MgcgSetTuning(const char* name, int value);
@@ -343,6 +347,7 @@ const char* MgcgCommTransport(const MgcgComm* comm);
  *   what = 1  halo exchanges: one grouped send/recv of `count` doubles with every other rank (with itself on one rank),
  *   what = 2  fork / join pairs of the overlap schedule (event record + stream wait on the side stream and back),
  *   what = 3  empty single-workgroup kernel launches (the price of a kernel boundary on this stream),
+ *   what = 4  the stencil's halo exchange: one grouped send/recv of `count` doubles with ranks rank - 1 and rank + 1 only,
  * timed with HIP events around the batch; returns microseconds per repetition (NaN on error).  Collective: every rank
  * of the communicator must make the same call. */
 double    MgcgCommProbe(MgcgComm* comm, int what, int count, int reps);
@@ -418,6 +423,10 @@ int MgcgEstimateSpectrum(MgcgBlas* cublas, MgcgSparse* cusparse,
  * (rows outside it wait for the halo), or 0 when the exchange ran in line (single rank, MGCG_OVERLAP=0, or the
  * slice has too few rows that reference local columns only).  interior may be NULL. */
 int MgcgLastOverlap(long long interior[2]);
+/* The measurement behind that choice (overlap = 1): returns 1 and microseconds[0] = one halo exchange in line, microseconds[1] = one
+ * fork / empty launch / join round trip, both averaged over the ranks, if the calling thread's last plan was decided by measurement;
+ * 0 if it was decided by the knob or the slice's size alone.  microseconds may be NULL. */
+int MgcgLastOverlapTimes(double microseconds[2]);
 /* Which folds the calling thread's LAST V-cycle took (Apply / SolveMg / SolveMgParallel): bit 0 = on some level the first sweep from
  * zero was formed per gather of the residual pass instead of being stored, bit 1 = on some level the prolongation was formed per gather
  * of the post-smoothing sweep as well (one rank, V(1,1), plain CSR, uniform diagonal, power-of-two nx and ny).  Schedules only: the

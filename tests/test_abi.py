@@ -112,3 +112,33 @@ def test_tuning_knobs_are_read_once_and_settable(hiplib, monkeypatch):
     assert L.MgcgGetTuning(b"overlap", C.byref(v)) == 0 and v.value == 1
     # the timing ablations that produce wrong results are not in the product library
     assert b"MGCG_SPMV_ABLATE" not in open(_lib.LIB_PATH, "rb").read()
+
+
+def test_comm_init_all_writes_exactly_the_entries_it_was_given(hiplib):
+    """Regression test for the host SIGSEGVs of round 3 (gpurun_out/r3/pytest_gpu_2.log, pytest_gdb.log: a Python-internal crash inside,
+    or some fifty tests after, test_comm_init_all_single_process -- heap corruption, not one bad call).  The call
+    that was new in that working tree and writes into caller memory is MgcgCommInitAll(comms, ndev): it clears comms[0 .. ndev) before
+    anything else, so an ndev larger than the ctypes array handed in overruns a Python-owned buffer.  The contract since: ndev outside
+    [1, 64] is refused before any write, otherwise exactly ndev entries are written -- checked here with sentinels either side of the
+    array (works with or without a GPU: every call below fails, or succeeds, after the same clearing step)."""
+    L = hiplib
+    sentinel = 0x5A5A5A5A5A5A5A5A
+    guard = 16
+    for ndev in (-1, 0, 1, 3, 64, 65, 1 << 20):
+        room = max(0, min(ndev, 64))
+        buf = (C.c_uint64 * (guard + room + guard))(*([sentinel] * (guard + room + guard)))
+        base = C.addressof(buf) + 8 * guard
+        rc = L.MgcgCommInitAll(C.c_void_p(base), ndev)
+        made = [buf[guard + d] for d in range(room)]
+        if rc == 0:                                          # (a GPU box with enough devices: real communicators -- give them back)
+            for ptr in made:
+                assert ptr not in (0, sentinel)
+                L.MgcgCommDestroy(C.c_void_p(ptr))
+        else:
+            assert rc == -1 and hiplib.MgcgGetLastError()
+            if 1 <= ndev <= 64:
+                assert made == [0] * room                    # every entry the caller was promised is NULL after a failure
+        L.MgcgClearLastError()
+        assert list(buf[:guard]) == [sentinel] * guard and list(buf[guard + room:]) == [sentinel] * guard, ndev
+    assert L.MgcgCommInitAll(None, 2) == -1
+    L.MgcgClearLastError()

@@ -119,3 +119,32 @@ def test_a_blocked_step_of_a_rank_ends_that_rank_with_a_message(tmp_path):
     assert out.returncode == 4
     assert "still here" in out.stdout and "not reached" not in out.stdout
     assert "rank 3: the timed steps did not finish" in out.stderr and "status 4" in out.stderr
+
+
+def test_the_launcher_refuses_to_start_ranks_under_a_profiler(tmp_path, capfd, monkeypatch):
+    """Under rocprofv3 the profiler's preloaded library has initialised the GPU in the parent: starting rank processes from it is the
+    exec-after-GPU-init hop this pool forbids.  launch_ranks says so and starts nothing."""
+    s = _script(tmp_path, "import pathlib, os; pathlib.Path(os.environ['MARK']).write_text('started')")
+    mark = tmp_path / "mark"
+    monkeypatch.setenv("MARK", str(mark))
+    monkeypatch.setenv("ROCPROFILER_LIBRARY_CTOR", "1")
+    assert bench.launch_ranks(2, [], script=s) == 5
+    assert "refuses to start its ranks under a profiler" in capfd.readouterr().err and not mark.exists()
+    monkeypatch.delenv("ROCPROFILER_LIBRARY_CTOR")
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    assert bench.launch_ranks(2, [], script=s) == 5 and not mark.exists()
+
+
+def test_byte_counts_of_the_line():
+    """The closed-form byte counts bench.py quotes: SURVEY.md section 8d's figures for 512^3, and the relation between the SURVEY-formula
+    count and the count the library's schedule must move."""
+    n, N = 512, 512**3
+    nnz = 7 * N - 6 * n * n
+    assert 12 * nnz + 4 * (N + 1) + 16 * N == 13_939_769_348                  # SpMV, SURVEY 8d
+    v, shell = bench.vcycle_bytes(n, 3, 1, 4)
+    assert shell == 13_939_769_348 + 72 * N                                    # 23.60 GB per CG iteration
+    rv, rshell = bench.vcycle_required_bytes(n, 3, 1, 4)
+    assert rshell == shell and rv < v                                          # no D^-1 array, folded first sweep and prolongation
+    rv_nofold, _ = bench.vcycle_required_bytes(n, 3, 1, 4, fold=False)
+    assert rv < rv_nofold
+    assert abs((rv + rshell) - 60.43e9) < 0.01e9                               # DESIGN section 5

@@ -32,6 +32,9 @@ def test_single_gpu_line_has_the_contract_fields():
     assert rf["launches_timed"] == 20 and rf["algorithmic_bytes_per_launch"] == 12 * rec["config"]["nnz"] + 4 * (rec["config"]["rows"] + 1) + 16 * rec["config"]["rows"]
     cb = rec["cpu_baseline"]
     assert cb["cores"] == 1 and cb["kind"] == "port" and cb["value"] > 0 and "sample" in cb
+    # the HIP loop against the oracle on the same iterations of the same full-size system, in the line itself (north star: 1e-10)
+    assert cb["gpu_vs_oracle_within_1e-10"] is True and cb["gpu_vs_oracle_relative_difference"] <= 1e-10, cb
+    assert rf["traffic"] is None or "RECORDED" in rf["traffic_source"]
 
 
 @pytest.mark.parametrize("solver", ["cg", "mgcg"])
@@ -46,6 +49,32 @@ def test_two_self_launched_ranks_check_themselves_against_one_rank(solver):
     pr = rec["per_rank"]
     assert len(pr["seconds_for_the_timed_steps"]) == 2 and len(pr["spmv_avg_launch_ms"]) == 2
     assert abs(max(pr["seconds_for_the_timed_steps"]) - rec["ms_per_step"] * rec["steps"] / 1e3) <= 1e-9       # the line reports the slowest rank
+    assert par["single_rank_ms_per_step"] > 0 and par["speedup_vs_single_rank"] > 0
+    if solver == "cg":
+        _check_multirank_extras(rec, 2)
+
+
+def _check_multirank_extras(rec, world):
+    """The N > 1 line of the driver's command explains itself: config 4 (row-partitioned MGCG) with its own self-check and 1-GPU leg,
+    the communicator's prices, the three halo schedules next to the library's choice (Mgcg/cuBlas/Mgcg/MgcgMain.cs:143-167 times the
+    1-GPU and N-GPU legs in one run; ConjugateGradientParallelGpu.cs:384-419,463,499,525 are the steps priced)."""
+    assert "extras_aborted" not in rec, rec.get("extras_aborted")
+    cp = rec["comm_probe"]
+    for k in ("allreduce_8B_us", "allreduce_16B_us", "neighbour_exchange_one_plane_us", "neighbour_exchange_8B_us", "fork_join_us", "kernel_boundary_us"):
+        assert cp[k] is not None and cp[k] >= 0, (k, cp)
+    assert cp["fork_join_us"] > 0 and cp["kernel_boundary_us"] > 0 and cp["plane_bytes"] == 8 * round(rec["config"]["rows"] ** (1 / 3)) ** 2
+    sc = rec["schedules"]
+    for k in ("exchange_in_line", "interior_rows_on_side_stream", "exchange_on_side_stream", "library_default"):
+        assert sc[k]["ms_per_iteration"] > 0, (k, sc)
+    assert sc["exchange_in_line"]["overlap_active_rank0"] is False and sc["interior_rows_on_side_stream"]["overlap_active_rank0"] is True
+    mg = rec["mgcg"]
+    assert mg["ms_per_iteration"] > 0 and mg["iterations_to_1e-8"] > 0 and mg["solve_s"] > 0
+    par = mg["parity_vs_single_rank"]
+    assert par["within_1e-10"] is True and par["same_iterations_to_1e-8"] is True, par
+    assert mg["single_rank"]["iterations_to_1e-8"] == mg["iterations_to_1e-8"]
+    assert mg["speedup_vs_single_rank"]["solver_time"] > 0 and mg["speedup_vs_single_rank"]["per_iteration"] > 0
+    for k in ("exchange_in_line", "interior_rows_on_side_stream", "exchange_on_side_stream", "library_default"):
+        assert mg["schedules"][k]["ms_per_iteration"] > 0, (k, mg["schedules"])
 
 
 @pytest.mark.parametrize("solver", ["cg", "mgcg"])
@@ -61,3 +90,6 @@ def test_two_ranks_over_rccl_when_the_box_has_two_devices(solver):
     assert rec["n_gpus"] == 2 and rec["config"]["transport"] == "rccl"
     par = rec["parity_vs_single_rank"]
     assert par["within_1e-10"] is True, par
+    if solver == "cg":
+        _check_multirank_extras(rec, 2)
+        assert rec["comm_probe"]["transport"] == "rccl" and rec["comm_probe"]["allreduce_8B_us"] > 0 and rec["comm_probe"]["neighbour_exchange_one_plane_us"] > 0

@@ -109,10 +109,44 @@ def test_config5_like_irregular_rows(oracle):
     np.testing.assert_allclose(cg.x, np.ones(s.Count), rtol=1e-7)             # b = A.1
 
 
-def test_config3_mgcg_at_full_size():
+def test_config3_first_iterations_against_the_oracle_at_full_size(oracle):
+    """BASELINE config 3 AT its size against the ORACLE (oracle/mg_oracle.c: hierarchy, V(1,1) Jacobi cycle and PCG shell restated on the
+    CPU): the first three MGCG iterations on the 7-point 512^3 system, plain CSR on every level -- the residual of every iteration to the
+    north star's 1e-10 relative, the iterate to 1e-10 of its largest entry.  (The whole 157-iteration solve is beyond a CPU loop that
+    takes about ten seconds per V-cycle at this size; the first iterations exercise every kernel of the cycle on every level at full
+    size: Galerkin set-up, folded first sweep and residual, restriction, coarse sweeps, prolongation, last sweep fused with r.z, the PCG
+    updates.)  About a minute and a half of host time."""
+    import conjugategradient_amd.problems as problems
+    from conjugategradient_amd.multigrid import ConjugateGradientMgGpu
+
+    n, its = 512, 3
+    N = n**3
+    L = _lib.lib()
+    e, c, r = oracle.poisson_csr(n, n, n)
+    s = problems.LinearSystem(e, c, r, np.zeros(N), np.ones(N), f"poisson{n}", grid=(n, n, n))
+    M = oracle.Multigrid(s, levels=3)
+    ref = M.pcg(rule=oracle.RULE_NATIVE, allowable_residual=1e300, min_iteration=its - 1, max_iteration=its + 2, trace=True)
+    assert ref["iteration"] == its - 1 and len(ref["trace"]) == its
+    del M
+    mg = ConjugateGradientMgGpu(N, 7, its - 1, 1000, 1e300, (n, n, n), levels=3, rule=_lib.RULE_NATIVE)
+    L.MgcgSetMatrixCompression(mg.cusparse, 0)
+    mg.InitializePoisson()
+    mg.Solve(trace=True)
+    assert mg.Iteration == its - 1
+    assert L.MgcgLastVcycleFolds() == 3                   # the schedule of record: first sweep and (on the 256^3 level) prolongation folded
+    np.testing.assert_allclose(mg.trace, ref["trace"], rtol=1e-10)
+    x = np.empty(N)
+    mg.vectorX.CopyTo(x, N)
+    assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
+    mg.Dispose()
+
+
+@pytest.mark.parametrize("compression", [0, 1])
+def test_config3_mgcg_at_full_size(compression):
     """BASELINE config 3 (7-point 512^3, 3-level V(1,1) Jacobi) through size-independent properties: the iteration count
-    is the grid-independent one (157 here; 53 at 128^3, 157 +- a few at 512^3 because the coarsest grid is only smoothed),
-    the residual the solver reports equals ||b - A x|| recomputed from x, and the lossless matrix analysis is in use."""
+    is the grid-independent one (157 here; 53 at 128^3, 157 +- a few at 512^3 because the coarsest grid is only smoothed) and
+    the residual the solver reports equals ||b - A x|| recomputed from x.  compression 0: the form of record -- plain CSR on
+    every level, what bench.py times; 1: the opt-in lossless analysis (row patterns, class 3)."""
     from conjugategradient_amd.multigrid import ConjugateGradientMgGpu
 
     n = 512
@@ -120,12 +154,12 @@ def test_config3_mgcg_at_full_size():
     L = _lib.lib()
     tol = 1e-8 * np.sqrt(N)                      # 1e-8 * ||b||_2 for b = 1
     mg = ConjugateGradientMgGpu(N, 7, 0, 1000, tol, (n, n, n), levels=3, rule=_lib.RULE_CSHARP)
-    L.MgcgSetMatrixCompression(mg.cusparse, 1)
+    L.MgcgSetMatrixCompression(mg.cusparse, compression)
     mg.InitializePoisson()
     mg.Solve()
     assert 150 <= mg.Iteration + 1 <= 165, mg.Iteration
     assert mg.Residual < tol
-    assert L.MgcgAnalysisInfo(mg.cusparse, 0, None, None, None, None) == 3
+    assert L.MgcgAnalysisInfo(mg.cusparse, 0, None, None, None, None) == (3 if compression else -1)
     y = VectorDouble(N)
     nnz = 7 * N - 6 * n * n
     L.CsrMV(mg.cusparse, mg.matDescr, y.ToRawPtr(), mg.vectorA.ToRawPtr(), mg.vectorRowOffsets.ToRawPtr(), mg.vectorColumnIndeces.ToRawPtr(),

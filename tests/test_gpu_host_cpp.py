@@ -39,6 +39,25 @@ def test_mgcg_main_driver(oracle, devices, balance):
     assert abs(rec["x0"] - ref["x"][0]) <= 1e-10 * abs(ref["x"][0]) and abs(rec["xlast"] - ref["x"][-1]) <= 1e-10 * abs(ref["x"][-1])
 
 
+def test_class_keeps_working_on_the_phases_when_no_communicator_forms(oracle):
+    """A host whose RCCL cannot form a communicator (MGCG_FAIL_COMM_INIT: the test hook that makes MgcgCommInitAll report failure):
+    ConjugateGradientParallelGpu must still construct and solve -- on the reference's own host-driven phases
+    (ConjugateGradientParallelGpu.cs:424-565), which need no communicator -- and say so."""
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(EXE)])
+    count, min_it = 6007, 30
+    env = dict(os.environ, MGCG_VIRTUAL_DEVICES="3", MGCG_FAIL_COMM_INIT="1")
+    out = subprocess.run([EXE, str(count), str(min_it)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["parallel_path"].startswith("host-driven phases (Solve0..3) -- no communicators:") and "MGCG_FAIL_COMM_INIT" in rec["parallel_path"]
+    s = problems.mgcg_main(count, 160)
+    ref = oracle.cg(s, rule=oracle.RULE_NATIVE, min_iteration=min_it, max_iteration=count, hard_cap=count + 5)
+    assert rec["iteration_single"] == rec["iteration_parallel"] == ref["iteration"] == min_it and rec["mismatches"] == 0
+    w = (np.arange(count) % 7) + 1.0
+    assert abs(rec["checksum"] - float(np.dot(ref["x"], w))) <= 1e-9 * abs(rec["checksum"])
+
+
 def test_other_two_driver_families_in_cpp(oracle):
     """host/MgcgFrontends.hpp + MgcgCLMain: the HandmadeCL ELL builder with the max-norm rule and the ViennaCL dictionary
     builder with the relative rule, filled by the reference drivers' loops in C++, against the oracle's same rules."""

@@ -84,7 +84,7 @@ def test_mg_variable_coefficients(oracle):
     cg.Solve()
     cg.Read()
     assert cg.Iteration == ref["iteration"]
-    assert np.abs(cg.x - ref["x"]).max() <= 1e-9 * np.abs(ref["x"]).max()
+    assert np.abs(cg.x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
 
 
 @pytest.mark.parametrize("dims", [(16, 16, 16), (8, 12, 4), (24, 16, 1), (4, 2, 2), (6, 1, 10), (1, 8, 12), (520, 4, 2)])

@@ -314,14 +314,14 @@ def test_native_multirank_loop_over_loopback(oracle, mgcg_env, world, which, ove
     assert ref["iteration"] >= 5
     maxnz = int(np.diff(s.RowOffsets).max())
 
-    def make_rank(rank, comm):
-        cg = ConjugateGradientRankGpu(s.Count, maxnz, 0, s.Count, 1e-8, rank=rank, world=world, comm=comm, device=rank).load(s)
+    def make_rank(rank, comm, min_iteration=0, tolerance=1e-8):
+        cg = ConjugateGradientRankGpu(s.Count, maxnz, min_iteration, s.Count, tolerance, rank=rank, world=world, comm=comm, device=rank).load(s)
         cg.Initialize()
         lo, hi = oracle.minmax_column(s, cg.part.offset, cg.part.offset + cg.part.count)
         assert (cg.part.minJ, cg.part.maxJ) == (lo, hi)
         cg.Solve(trace=True)
         active, i0, i1 = cg.LastOverlap()
-        if which == "unstructured" or overlap == "0" or overlap is None:     # (the library's own choice overlaps from 3 M rows per rank up)
+        if which == "unstructured" or overlap == "0" or overlap is None:     # (the library's own choice measures only from 1 M rows per rank up)
             assert not active
         else:
             assert active and 0 <= i0 < i1 <= cg.part.count
@@ -333,20 +333,46 @@ def test_native_multirank_loop_over_loopback(oracle, mgcg_env, world, which, ove
         cg.Dispose()
         return out
 
+    def gathered(res):
+        x = np.zeros(s.Count)
+        for off, cnt, xs, *_ in res:
+            x[off: off + cnt] = xs
+        return x
+
+    from tests.gpu_util import assert_trace_close
+
     res = _run_ranks_in_threads(world, make_rank)
-    x = np.zeros(s.Count)
+    x = gathered(res)
     for off, cnt, xs, it, resid, tr in res:
-        x[off: off + cnt] = xs
         assert it == ref["iteration"]
         assert resid == res[0][4]                       # every rank holds the same all-reduced bits
-        from tests.gpu_util import assert_trace_close
         # below 1e-6 * r0 this well-conditioned random system is chaotic even between the serial and the
         # partitioned ORACLE (relative differences grow 10x per iteration there), so only the magnitude is checked
         assert_trace_close(tr, ref["trace"], loose=1.0)
-    # (the random system over 8 ranks: eight partial sums per dot product instead of two or four -- its chaotic tail below 1e-6 r0, see above,
-    #  leaves the iterate at the stopping index 1.2e-10 from the oracle's; every other case meets the 1e-10 of the north star)
-    xtol = 5e-10 if (which == "unstructured" and world == 8) else 1e-10
-    assert np.abs(x - ref["x"]).max() <= xtol * np.abs(ref["x"]).max()
+    scale = np.abs(ref["x"]).max()
+    distance = np.abs(x - ref["x"]).max() / scale
+    if which != "unstructured":
+        assert distance <= 1e-10                        # the north star's tolerance at the stopping index
+        return
+    # The random system.  (1) While the residual is above round-off -- the last index k* with residual >= 1e-6 r0, where the trace is held to
+    # 1e-10 -- the iterate meets the north star's 1e-10: both loops are stopped exactly there (rule: index >= MinIteration and residual below an
+    # infinite tolerance) and compared.
+    hi = np.nonzero(ref["trace"] >= 1e-6 * ref["trace"][0])[0]
+    k_star = int(hi[-1])
+    assert 5 <= k_star < ref["iteration"]
+    ref_k = oracle.cg_parallel(s, world, allowable_residual=1e300, min_iteration=k_star, max_iteration=s.Count)
+    assert ref_k["iteration"] == k_star
+    res_k = _run_ranks_in_threads(world, lambda rank, comm: make_rank(rank, comm, k_star, 1e300))
+    assert all(r[3] == k_star for r in res_k)
+    assert np.abs(gathered(res_k) - ref_k["x"]).max() <= 1e-10 * np.abs(ref_k["x"]).max()
+    # (2) At the stopping index, 19 iterations into the round-off-dominated tail, the ORACLE itself moves by more than 1e-10 when only the
+    # number of partial sums per dot product changes (ConjugateGradientParallelGpu.cs:463,499,525: resultsDot.Sum() over 1 .. 8 devices;
+    # measured on this system: up to 1.2e-10 between the 4- and 8-device oracles, 7e-11 against the serial loop).  The HIP loop, whose dot
+    # products are summed in yet another order, must lie within that spread of the oracle it is compared with -- asserted, not assumed.
+    spread = max(np.abs(oracle.cg_parallel(s, w, max_iteration=s.Count)["x"] - ref["x"]).max() for w in range(1, 9) if w != world) / scale
+    assert distance <= max(1e-10, 1.5 * spread), (distance, spread)
+    if world == 8:
+        assert spread > 1e-10                           # the evidence for not demanding 1e-10 here: the oracles do not meet it among themselves
 
 
 @pytest.mark.parametrize("world", [3, 8])
@@ -380,9 +406,10 @@ def test_partition_of_equal_nonzero_counts_over_loopback(oracle, mgcg_env, world
         assert it == ref["iteration"] and resid == res[0][4]
         assert_trace_close(tr, ref["trace"], loose=1.0)
         assert abs(nnz - s.nnz / world) <= maxnz
-    # (this random system's iterates are chaotic below 1e-6 r0 even between two ORACLE partitions, see test_native_multirank_loop_over_loopback:
-    #  1.2e-10 at the stopping index here; the systems with structure meet the 1e-10 of the north star)
-    assert np.abs(x - ref["x"]).max() <= 5e-10 * np.abs(ref["x"]).max()
+    # this random system's iterates are chaotic below 1e-6 r0 even between two ORACLE partitions (test_native_multirank_loop_over_loopback): the
+    # HIP loop must lie within the spread of the oracle over other device counts -- computed and asserted inside assert_iterate_close
+    from tests.gpu_util import assert_iterate_close
+    assert_iterate_close(x, ref["x"], spread_refs=[oracle.cg_parallel(s, w, max_iteration=s.Count)["x"] for w in range(1, 9)])
 
 
 @pytest.mark.parametrize("world,dims,levels,interpolation", [(2, (8, 8, 16), 3, 0), (4, (16, 8, 16), 2, 0), (2, (12, 12, 8), 3, 0),

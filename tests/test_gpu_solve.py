@@ -14,7 +14,7 @@ from conjugategradient_amd import _lib, problems
 from conjugategradient_amd.solver import (ApplicationException, ConjugateGradientParallelGpu,
                                           ConjugateGradientSingleGpu)
 from tests.conftest import golden
-from tests.gpu_util import assert_trace_close
+from tests.gpu_util import assert_iterate_close, assert_trace_close
 
 pytestmark = pytest.mark.gpu
 
@@ -85,7 +85,8 @@ def test_min_iteration_runs_past_convergence(oracle):
     above = ref["trace"] > 1e-6 * ref["trace"][0]
     np.testing.assert_allclose(cg.trace[above], ref["trace"][above], rtol=RTOL_TRACE)
     assert cg.trace[-1] < 1e-8 and ref["trace"][-1] < 1e-8      # both sit at round-off level
-    assert np.abs(cg.x - ref["x"]).max() <= 1e-9 * np.abs(ref["x"]).max()
+    # 60 forced iterations end deep in the round-off tail: 1e-10, or within the oracle's own spread over device counts (asserted inside)
+    assert_iterate_close(cg.x, ref["x"], spread_refs=[oracle.cg_parallel(s, w, min_iteration=60, max_iteration=1200)["x"] for w in (2, 3, 4)])
 
 
 def test_max_iteration_raises_like_the_csharp_rule(oracle):
@@ -205,7 +206,9 @@ def test_other_front_ends(oracle):
     cl.Read()
     assert cl.Iteration == ref["iteration"] == 50
     assert abs(cl.Residual - ref["residual"]) <= 1e-3 * ref["residual"] + 1e-12      # round-off level max-norm after 50 forced iterations
-    assert np.abs(cl.x - ref["x"]).max() <= 1e-9 * np.abs(ref["x"]).max()
+    # (the iterate after exactly 50 iterations does not depend on the norm of the stop rule: the 2-norm oracle over 2 .. 4 devices, stopped at the
+    #  same index, gives the oracle's own spread there)
+    assert_iterate_close(cl.x, ref["x"], spread_refs=[oracle.cg_parallel(s, w, allowable_residual=1e300, min_iteration=50, max_iteration=1800)["x"] for w in (2, 3, 4)])
     cl.Dispose()
 
 
@@ -233,8 +236,8 @@ def test_front_ends_driven_from_their_own_builders(oracle):
     cl.Initialize()
     cl.Solve()
     cl.Read()
-    assert cl.Iteration == ref["iteration"]
-    assert np.abs(cl.x - ref["x"]).max() <= 1e-9 * np.abs(ref["x"]).max()
+    assert cl.Iteration == ref["iteration"] == 50
+    assert_iterate_close(cl.x, ref["x"], spread_refs=[oracle.cg_parallel(s, w, allowable_residual=1e300, min_iteration=50, max_iteration=n)["x"] for w in (2, 3, 4)])
     cl.Dispose()
 
     A = CompressedMatrix()
