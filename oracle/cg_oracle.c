@@ -45,9 +45,31 @@ void oracle_spmv(const double *elements, const int *columnIndeces,
     }
 }
 
-/* Mgcg/cuBlas/Mgcg/LongVector.cs:15-31  Dot: serial left-to-right sum. */
+/* Mgcg/cuBlas/Mgcg/LongVector.cs:15-31  Dot: serial left-to-right sum.
+ *
+ * Mode 1 (oracle_set_dot_mode, tests only) sums the SAME rounded products with Neumaier's compensation, i.e. to the last bit or two of
+ * their exact sum.  It is not the reference's arithmetic; it exists to MEASURE the reference order's own rounding error, which is no
+ * longer negligible at BASELINE sizes: a serial sum of 1.3e8 nearly equal terms rounds every add to the ulp of a running sum 1e8
+ * times larger than the addend, in the same direction for long stretches -- relative error of order 1e-9 at 512^3
+ * (tests/test_gpu_fullsize.py), where the device's two-stage tree sums are good to 1e-15.  A HIP result that differs from the
+ * reference-order oracle by that much and from the compensated oracle by 1e-13 differs by the reference's rounding, not its own. */
+static int g_dot_mode = 0;
+void oracle_set_dot_mode(int mode) { g_dot_mode = mode; }
+int oracle_get_dot_mode(void) { return g_dot_mode; }
+
 double oracle_dot(const double *left, const double *right, int64_t n)
 {
+    if (g_dot_mode == 1) {
+        double sum = 0, comp = 0;
+        for (int64_t i = 0; i < n; i++) {
+            double prod = left[i] * right[i];
+            double t = sum + prod;
+            if (fabs(sum) >= fabs(prod)) comp += (sum - t) + prod;
+            else comp += (prod - t) + sum;
+            sum = t;
+        }
+        return sum + comp;
+    }
     double answer = 0;
     for (int64_t i = 0; i < n; i++) {
         double prod = left[i] * right[i];

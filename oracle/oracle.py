@@ -101,6 +101,21 @@ def _i(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
+class compensated_dots:
+    """``with oracle.compensated_dots():`` -- every dot product of the oracle loops sums the same rounded products with Neumaier's
+    compensation instead of the reference's serial left-to-right order (cg_oracle.c: oracle_set_dot_mode).  NOT the reference's
+    arithmetic: a yardstick for the reference order's own rounding error at large sizes."""
+
+    def __enter__(self):
+        self._saved = lib().oracle_get_dot_mode()
+        lib().oracle_set_dot_mode(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().oracle_set_dot_mode(self._saved)
+        return False
+
+
 def spmv(elements, column_indeces, row_offsets, vector):
     ro = _i(row_offsets)
     n = ro.shape[0] - 1

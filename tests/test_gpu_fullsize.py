@@ -111,22 +111,31 @@ def test_config5_like_irregular_rows(oracle):
 
 def test_config3_first_iterations_against_the_oracle_at_full_size(oracle):
     """BASELINE config 3 AT its size against the ORACLE (oracle/mg_oracle.c: hierarchy, V(1,1) Jacobi cycle and PCG shell restated on the
-    CPU): the first three MGCG iterations on the 7-point 512^3 system, plain CSR on every level -- the residual of every iteration to the
-    north star's 1e-10 relative, the iterate to 1e-10 of its largest entry.  (The whole 157-iteration solve is beyond a CPU loop that
-    takes about ten seconds per V-cycle at this size; the first iterations exercise every kernel of the cycle on every level at full
-    size: Galerkin set-up, folded first sweep and residual, restriction, coarse sweeps, prolongation, last sweep fused with r.z, the PCG
-    updates.)  About a minute and a half of host time."""
+    CPU): the first two MGCG iterations on the 7-point 512^3 system, plain CSR on every level.  They exercise every kernel of the cycle on
+    every level at full size (Galerkin set-up, folded first sweep and residual, restriction, coarse sweeps, prolongation, last sweep fused
+    with r.z, the PCG updates); the whole 157-iteration solve is beyond a CPU loop that takes ten seconds per V-cycle here.
+
+    What can be demanded at this size: the V-cycle is bit-identical to the oracle's, so the loops differ only in their dot products --
+    and at 1.3e8 terms the reference's serial left-to-right sums (LongVector.cs:15-31) carry a rounding error of their own of order 1e-9
+    (a running sum 1e8 times the addend, rounded the same way for long stretches), where the device's tree sums are good to 1e-15.  So:
+      (1) against the oracle with the SAME products summed exactly (compensated_dots): residual trace and iterate to the north star's 1e-10;
+      (2) against the reference-order oracle: within twice that oracle's own distance from the exactly summed one -- asserted, with the
+          distance itself required to be what the argument says (above 1e-10), so the bound cannot quietly become vacuous or unnecessary.
+    About two minutes of host time."""
     import conjugategradient_amd.problems as problems
     from conjugategradient_amd.multigrid import ConjugateGradientMgGpu
 
-    n, its = 512, 3
+    n, its = 512, 2
     N = n**3
     L = _lib.lib()
     e, c, r = oracle.poisson_csr(n, n, n)
     s = problems.LinearSystem(e, c, r, np.zeros(N), np.ones(N), f"poisson{n}", grid=(n, n, n))
     M = oracle.Multigrid(s, levels=3)
-    ref = M.pcg(rule=oracle.RULE_NATIVE, allowable_residual=1e300, min_iteration=its - 1, max_iteration=its + 2, trace=True)
-    assert ref["iteration"] == its - 1 and len(ref["trace"]) == its
+    kw = dict(rule=oracle.RULE_NATIVE, allowable_residual=1e300, min_iteration=its - 1, max_iteration=its + 2, trace=True)
+    ref = M.pcg(**kw)
+    with oracle.compensated_dots():
+        exact = M.pcg(**kw)
+    assert ref["iteration"] == exact["iteration"] == its - 1 and len(ref["trace"]) == len(exact["trace"]) == its
     del M
     mg = ConjugateGradientMgGpu(N, 7, its - 1, 1000, 1e300, (n, n, n), levels=3, rule=_lib.RULE_NATIVE)
     L.MgcgSetMatrixCompression(mg.cusparse, 0)
@@ -134,11 +143,19 @@ def test_config3_first_iterations_against_the_oracle_at_full_size(oracle):
     mg.Solve(trace=True)
     assert mg.Iteration == its - 1
     assert L.MgcgLastVcycleFolds() == 3                   # the schedule of record: first sweep and (on the 256^3 level) prolongation folded
-    np.testing.assert_allclose(mg.trace, ref["trace"], rtol=1e-10)
     x = np.empty(N)
     mg.vectorX.CopyTo(x, N)
-    assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
     mg.Dispose()
+    # (1) the same algorithm with exactly summed dot products
+    np.testing.assert_allclose(mg.trace, exact["trace"], rtol=1e-10)
+    scale = np.abs(exact["x"]).max()
+    assert np.abs(x - exact["x"]).max() <= 1e-10 * scale
+    # (2) the reference's summation order
+    own_trace = np.abs(ref["trace"] - exact["trace"]) / exact["trace"]
+    own_x = np.abs(ref["x"] - exact["x"]).max() / scale
+    assert own_trace.max() > 1e-10, own_trace               # the reference order's own rounding at this size is what stands between the two
+    assert np.all(np.abs(mg.trace - ref["trace"]) / ref["trace"] <= 2.0 * own_trace + 1e-10), (mg.trace, ref["trace"], own_trace)
+    assert np.abs(x - ref["x"]).max() / scale <= 2.0 * own_x + 1e-10
 
 
 @pytest.mark.parametrize("compression", [0, 1])

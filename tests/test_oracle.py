@@ -168,3 +168,27 @@ def test_oracle_asan_build_runs():
     env = dict(os.environ, LD_PRELOAD=asan_rt, ASAN_OPTIONS="detect_leaks=0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert "asan-ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_compensated_dot_mode_is_a_yardstick_not_the_reference_order(oracle):
+    """oracle.compensated_dots(): the same rounded products summed with Neumaier's compensation (cg_oracle.c, oracle_set_dot_mode) -- the
+    measure of what the reference's serial left-to-right order (LongVector.cs:15-31) loses at large n.  2^22 equal terms: the exact sum is
+    the product times 2^22 (a power of two), the compensated sum hits it, the serial sum is off by far more than 1e-13; small systems are
+    untouched in their iteration count and to 1e-13 in x; the mode switches back."""
+    n = 1 << 22
+    v = np.full(n, 0.1234567)
+    exact = float(v[0] * v[0]) * n
+    serial = oracle.dot(v, v)
+    with oracle.compensated_dots():
+        comp = oracle.dot(v, v)
+        assert oracle.lib().oracle_get_dot_mode() == 1
+    assert oracle.lib().oracle_get_dot_mode() == 0 and oracle.dot(v, v) == serial
+    assert comp == exact and abs(serial - exact) > 1e-13 * exact
+    s = problems.poisson(12, 12, 12)
+    a = oracle.cg(s, rule=oracle.RULE_CSHARP, max_iteration=2000)
+    with oracle.compensated_dots():
+        b = oracle.cg(s, rule=oracle.RULE_CSHARP, max_iteration=2000)
+        m = oracle.Multigrid(s, levels=2).pcg(rule=oracle.RULE_CSHARP, max_iteration=200)
+    m0 = oracle.Multigrid(s, levels=2).pcg(rule=oracle.RULE_CSHARP, max_iteration=200)
+    assert a["iteration"] == b["iteration"] and np.abs(a["x"] - b["x"]).max() <= 1e-12 * np.abs(a["x"]).max()
+    assert m["iteration"] == m0["iteration"] and np.abs(m["x"] - m0["x"]).max() <= 1e-12 * np.abs(m0["x"]).max()
