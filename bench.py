@@ -769,6 +769,13 @@ def main():
     with _watchdog(f"rank {rank}: the warm-up iterations (halo plan, first exchanges and all-reduces)", enabled=world > 1):
         run_steps(max(a.warmup, 1), True)
 
+    # the library's placement draw for p (first solve on a p beyond the Infinity Cache: the loop's SpMV timed on extra allocations, the fastest kept)
+    pl_ms = (C.c_double * 16)()
+    pl_chosen = C.c_int(-1)
+    pl_n = L.MgcgLastPlacement(pl_ms, 16, C.byref(pl_chosen))
+    placement = ({"candidates_spmv_ms": [pl_ms[i] for i in range(min(pl_n, 16))], "chosen": pl_chosen.value,
+                  "note": "one-off, inside the warm-up: candidate 0 is the allocation p came with (MGCG_PLACEMENT=0 switches the draw off)"} if pl_n > 0 else None)
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -959,6 +966,8 @@ def main():
             "gflops": (2 * nnz_total + 10 * N) * (a.steps / dt) / 1e9 if a.solver == "cg" else None,
             "residual_after_steps": res,
         }
+        if placement is not None:
+            out["placement_draw_rank0"] = placement
         if parity is not None:
             out["parity_vs_single_rank"] = parity
         if per_rank is not None:

@@ -66,6 +66,7 @@ struct Tuning {
                                              //                         1 the halo exchange on the side stream, all rows on the main stream (measured faster on one GPU, solver.hip;
                                              //                         opt-in until RCCL on two streams of one communicator has run on real multi-GPU hardware)
     std::atomic<int> forceMultiRank{0};      // MGCG_FORCE_MULTIRANK    a one-rank communicator takes the several-ranks code path (measurement)
+    std::atomic<int> placement{3};           // MGCG_PLACEMENT          Solve-family calls on >= 32 M-entry p: time the SpMV on this many EXTRA allocations of p and keep the fastest (0: off)
     std::atomic<int> failCommInit{0};        // MGCG_FAIL_COMM_INIT     tests only: MgcgCommInitAll / MgcgCommInitRank report failure (what a host without a working RCCL does)
 };
 Tuning& tuning();
@@ -224,7 +225,9 @@ struct MgcgSparse {
     std::vector<PeriodEntry> periods;
 };
 struct MgcgMatDescr { int type = 0; int base = 0; };
-struct Vector    { double* data = nullptr; long long size = 0; int device = -1; };
+struct Vector    { double* data = nullptr; long long size = 0; int device = -1;
+                   bool rawExported = false;   // ToRawPtr_Double handed the address out: the library must not move the data any more
+                   bool placed = false; };     // the placement draw (solver.hip) has looked at this vector
 struct VectorInt { int* data = nullptr;    long long size = 0; int device = -1; };
 
 namespace mgcg {

@@ -48,6 +48,7 @@ const Knob kKnobs[] = {
     { "MGCG_HALO_STREAM", "halo_stream", &Tuning::haloStream, 0, false },
     { "MGCG_FORCE_MULTIRANK", "force_multirank", &Tuning::forceMultiRank, 0, false },
     { "MGCG_FAIL_COMM_INIT", "fail_comm_init", &Tuning::failCommInit, 0, false },
+    { "MGCG_PLACEMENT", "placement", &Tuning::placement, 3, false },
 };
 Tuning g_tuning;
 std::once_flag g_tuningOnce;
@@ -583,7 +584,7 @@ void Delete_Int(VectorInt* v)
     if (v->data) { analysis_note_write(v->data, sizeof(int) * (size_t)v->size); DeviceState* d = device_state(); if (d) (void)hipStreamSynchronize(d->stream); (void)hipFree(v->data); }
     delete v;
 }
-double* ToRawPtr_Double(Vector* v) { return v ? v->data : nullptr; }
+double* ToRawPtr_Double(Vector* v) { if (v) v->rawExported = true; return v ? v->data : nullptr; }
 int* ToRawPtr_Int(VectorInt* v) { return v ? v->data : nullptr; }
 
 void CopyFromDevice_Double(const double* source, double* destination, int count, int sourceOffset, int destinationOffset)

@@ -380,6 +380,7 @@ struct CgRun {
     long long interior0 = 0, interior1 = 0;
     bool noFoldedFinalize = false;         // tuning knobs, resolved once per solve (every iteration of every rank takes the same path)
     bool haloOnSide = false;
+    Vector* pVec = nullptr;                // the handle behind p (the placement draw may move its data)
 };
 
 static thread_local long long t_lastOverlap[3] = { 0, 0, 0 };
@@ -417,6 +418,72 @@ __global__ void snapshot_kernel(const CgScalars* sc, HostMirror* m, volatile int
 
 __global__ void clear_done_kernel(CgScalars* sc) { sc->done = 0; sc->status = 0; }
 
+// ---------------------------------------------------------------- placement draw for p
+// The same SpMV binary on the same matrix runs +-5 % apart depending on WHERE the runtime placed the gathered vector (identical HBM
+// traffic and L2 hit rates: the timing of the same requests -- the channel / bank hash of the physical pages; profiles/r2/
+// spmv_placement_*.log).  A kernel cannot steer that, but the library owns every vector (Create_Double): at the
+// first solve on a p of at least kPlacementMinEntries entries (256 MB: beyond the Infinity Cache) it allocates `placement` more buffers of
+// p's size, times the loop's own SpMV (fused with p.Ap) on each, keeps the fastest and frees the rest -- one draw becomes the best of k.
+// One-off cost at 512^3: 4 candidates x 4 launches x 2.5 ms + 3 GiB of copies ~ 45 ms, inside the first solve (the role cuSPARSE's csrmv
+// analysis plays in the reference's stack).  Nothing numerical changes: the same doubles at another address.  A vector whose address
+// the caller has seen (ToRawPtr_Double) is never moved.
+constexpr long long kPlacementMinEntries = 32LL << 20;
+static thread_local double t_placementMs[16];
+static thread_local int t_placementInfo[2] = { 0, -1 };     // candidates timed, chosen
+
+static void placement_draw(CgRun& R)
+{
+    Vector* v = R.pVec;
+    const int extra = tuning().placement.load(std::memory_order_relaxed);
+    if (!v || v->placed || v->rawExported || extra <= 0 || v->size < kPlacementMinEntries || v->data != R.p || R.nLocal < 4096 || R.elementsCount < 8) return;
+    v->placed = true;                              // one draw per vector, whatever comes of it
+    t_placementInfo[0] = 0; t_placementInfo[1] = -1;
+    hipStream_t s = R.ws->stream;
+    const size_t bytes = sizeof(double) * (size_t)v->size;
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { (void)hipGetLastError(); return; }
+    double* cand[16];
+    int n = 1;
+    cand[0] = v->data;
+    const int want = extra > 15 ? 15 : extra;
+    for (int i = 0; i < want && freeB > (size_t)(i + 1) * bytes + (2ULL << 30); ++i) {
+        double* q = nullptr;
+        if (hipMalloc((void**)&q, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        cand[n++] = q;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = n > 1 && MGCG_HIP(hipEventCreate(&e0)) && MGCG_HIP(hipEventCreate(&e1));
+    for (int i = 1; ok && i < n; ++i) ok = MGCG_HIP(hipMemcpyAsync(cand[i], v->data, bytes, hipMemcpyDeviceToDevice, s));   // the same contents everywhere
+    int best = 0;
+    constexpr int kReps = 6;
+    for (int i = 0; ok && i < n; ++i) {
+        SpmvArgs a{};
+        a.elements = R.elements; a.rowOffsets = R.rowOffsets; a.columnIndeces = R.columnIndeces; a.x = cand[i]; a.y = R.Ap;
+        a.elementsCount = R.elementsCount; a.rowCount = (int)R.nLocal; a.columnCount = (int)R.count;
+        a.w = cand[i] + R.offset; a.partials = R.ws->partials; a.doneFlag = nullptr;
+        (void)launch_spmv_auto(s, EPI_DOT, a, R.cfg, R.dcsr);                              // warm-up (Ap and the partial sums are rewritten by the solve)
+        ok = MGCG_HIP(hipEventRecord(e0, s));
+        for (int k = 0; k < kReps; ++k) (void)launch_spmv_auto(s, EPI_DOT, a, R.cfg, R.dcsr);
+        ok = ok && MGCG_HIP(hipEventRecord(e1, s)) && MGCG_HIP(hipEventSynchronize(e1));
+        float ms = 0.0f;
+        ok = ok && MGCG_HIP(hipEventElapsedTime(&ms, e0, e1));
+        t_placementMs[i] = (double)ms / kReps;
+        if (ok && t_placementMs[i] < t_placementMs[best]) best = i;
+    }
+    (void)hipStreamSynchronize(s);
+    if (!ok) { best = 0; (void)hipGetLastError(); }
+    for (int i = 0; i < n; ++i) if (i != best) { analysis_note_write(cand[i], bytes); (void)hipFree(cand[i]); }   // (freed addresses may be handed out again)
+    if (best != 0) { v->data = cand[best]; R.p = v->data; }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (ok) { t_placementInfo[0] = n; t_placementInfo[1] = best; }
+    if (ok && tuning().verbose.load(std::memory_order_relaxed) >= 1) {
+        fprintf(stderr, "[MgcgGpu] placement draw for p (%lld entries): SpMV", v->size);
+        for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f", t_placementMs[i]);
+        fprintf(stderr, " ms -> candidate %d\n", best);
+    }
+}
+
 static bool cg_enqueue_init(CgRun& R)
 {
     hipStream_t s = R.ws->stream;
@@ -425,6 +492,7 @@ static bool cg_enqueue_init(CgRun& R)
     if (R.cusparse) R.dcsr = dcsr_lookup(R.cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset, R.count, R.mg ? -1 : meanDistance);
     if (meanDistance >= (1LL << 19) && R.count >= (8LL << 19)) R.cfg.flags |= 16;      // gathers without locality: the stream form among the CSR kernels
     if (!R.mg) R.cfg.flags |= 8;                 // plain CG loop: the row-tile kernel may read the matrix with the non-temporal hint (kernels_rowtile.hip)
+    placement_draw(R);                           // (before p is touched: may move p's data once per vector)
     CgScalars* sc = R.ws->scalars;
     double* pLoc = R.p + R.offset;
     if (R.rule == MGCG_RULE_SIMPLE) launch_fill(s, R.x, 0.0, R.nLocal);             // SimpleConjugateGradient.cu:53
@@ -649,7 +717,7 @@ int SolveEx(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr,
     CgRun R;
     R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse;
     R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCount;
-    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data;
+    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data; R.pVec = pVector;
     R.count = count; R.nLocal = count; R.offset = 0;
     R.tol = allowableResidual; R.minIt = minIteration; R.maxIt = maxIteration; R.rule = rule;
     return cg_solve(R, iteration, residual, residualTrace, traceCapacity);
@@ -695,7 +763,7 @@ int SolveParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMa
     CgRun R;
     R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse; R.comm = comm; R.nranks = MgcgCommSize(comm); R.multi = comm_multi(comm);
     R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCountForDevice;
-    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data;
+    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data; R.pVec = pVector;
     R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice;
     R.tol = allowableResidual; R.minIt = minIteration; R.maxIt = maxIteration; R.rule = rule;
     if (R.multi) {
@@ -727,7 +795,7 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     CgRun R;
     R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse; R.comm = comm; R.nranks = MgcgCommSize(comm); R.multi = comm_multi(comm);
     R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCountForDevice;
-    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data;
+    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data; R.pVec = pVector;
     R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice; R.rule = MGCG_RULE_NATIVE;
     double* savedTrace = R.ws->trace; const int savedCap = R.ws->traceCap;
     R.ws->trace = nullptr; R.ws->traceCap = 0;
@@ -765,6 +833,14 @@ int MgcgLastHalo(long long volume[2])
 }
 
 int MgcgLastVcycleFolds(void) { return t_lastFolds; }
+
+int MgcgLastPlacement(double milliseconds[], int capacity, int* chosen)
+{
+    const int n = t_placementInfo[0];
+    for (int i = 0; milliseconds && i < n && i < capacity; ++i) milliseconds[i] = t_placementMs[i];
+    if (chosen) *chosen = t_placementInfo[1];
+    return n;
+}
 
 int MgcgLastOverlapTimes(double microseconds[2])
 {
@@ -1021,7 +1097,7 @@ int SolveMgParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, Mgcg
     CgRun R;
     R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse; R.mg = mg; R.comm = comm; R.nranks = MgcgCommSize(comm); R.multi = comm_multi(comm);
     R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCountForDevice;
-    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data; R.z = zVector->data;
+    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data; R.z = zVector->data; R.pVec = pVector;
     R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice;
     R.tol = allowableResidual; R.minIt = minIteration; R.maxIt = maxIteration; R.rule = rule;
     if (R.multi) {

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Best-of-k placement of p against the plain draw: the default bench command in fresh processes, alternating MGCG_PLACEMENT = 0 / 3 / 7
+# (run on the GPU box from the repo root).  Usage: bash conjugategradient_amd/tools/placement_ab.sh OUT.log [rounds]
+OUT=${1:-gpurun_out/placement_ab.log}
+ROUNDS=${2:-4}
+: > "$OUT"
+for i in $(seq 1 "$ROUNDS"); do
+  for k in ${KS:-0 3}; do
+    MGCG_PLACEMENT=$k python3 bench.py --no-extras --no-cpu-baseline --steps 60 --warmup 5 2>/dev/null | python3 -c "
+import json, sys
+d = json.loads(sys.stdin.readline())
+p = d.get('placement_draw_rank0') or {}
+print(json.dumps({'placement': $k, 'round': $i, 'it_per_s': round(d['value'], 2), 'spmv_in_loop_ms': round(d['roofline']['avg_launch_ms'], 4), 'frac': round(d['roofline']['frac'], 4),
+                  'export_frac': round(d['roofline_csr_spmv']['frac'], 4), 'candidates_ms': [round(v, 4) for v in p.get('candidates_spmv_ms', [])], 'chosen': p.get('chosen')}))" >> "$OUT"
+    tail -1 "$OUT"
+  done
+done

@@ -2,7 +2,8 @@
 // config 5's shape (10 M rows, ~31 entries per row, columns uniform over the whole range): which part of the 3.3 ms per product is the
 // gathers, which the y read-modify-write, which the streams -- and what a 12-byte entry (value + one packed word) buys.  Measurement
 // tool, not part of the library.  Every variant is checked bit for bit against the production-shaped pass (V0) and V0 against the host.
-//   tile_lab [rows=10000000] [tiles=20] [tileShift=19] [meanPerCell=1.55]
+//   tile_lab [rows=10000000] [tiles=20] [tileShift=19] [meanPerCell=1.55] [tileWidth=2^tileShift columns; any width <= 2^tileShift]
+//   TILE_LAB_QUICK=1: only the 12-byte production pass (for PMC runs)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -270,8 +271,11 @@ int main(int argc, char** argv)
     const int T = argc > 2 ? atoi(argv[2]) : 20;
     const int shift = argc > 3 ? atoi(argv[3]) : 19;
     const double mean = argc > 4 ? atof(argv[4]) : 1.55;
-    const long long cols = (long long)T << shift;
-    printf("tile_lab: %lld rows, %d tiles of 2^%d columns (x = %.1f MB), mean %.2f entries per (row, tile)\n", rows, T, shift, cols * 8 / 1048576.0, mean);
+    const int width = argc > 5 ? atoi(argv[5]) : (1 << shift);          // columns per tile (<= 2^shift: the packed word keeps `shift` bits for the offset)
+    if (width < 1 || width > (1 << shift)) { printf("tileWidth must be in [1, 2^tileShift]\n"); return 1; }
+    const bool quick = getenv("TILE_LAB_QUICK") != nullptr;
+    const long long cols = (long long)T * width;
+    printf("tile_lab: %lld rows, %d tiles of %d columns = %.2f MiB of x each (x = %.1f MB), mean %.2f entries per (row, tile)\n", rows, T, width, width * 8 / 1048576.0, cols * 8 / 1048576.0, mean);
     // ---- host generation, tile-major, row-major inside a tile, ascending columns inside a (row, tile) segment
     std::vector<double> hv; std::vector<int> hc, hr; std::vector<int> tileStart((size_t)T + 1, 0);
     hv.reserve((size_t)(rows * T * mean * 1.05)); hc.reserve(hv.capacity()); hr.reserve(hv.capacity());
@@ -284,12 +288,12 @@ int main(int argc, char** argv)
             int cnt = 0;
             while (u > cum && cnt < 12) { ++cnt; p *= mean / cnt; cum += p; }   // Poisson(mean)
             int cs[12];
-            for (int q = 0; q < cnt; ++q) { h = mix(h + 0x632BE59BD9B4E019ull); cs[q] = (int)(h & ((1u << shift) - 1)); }
+            for (int q = 0; q < cnt; ++q) { h = mix(h + 0x632BE59BD9B4E019ull); cs[q] = (int)(h % (unsigned long long)width); }
             std::sort(cs, cs + cnt);
             for (int q = 0; q < cnt; ++q) {
                 if (q > 0 && cs[q] == cs[q - 1]) continue;
                 h = mix(h + 1);
-                hv.push_back(-((double)(h >> 11) * (1.0 / 9007199254740992.0))); hc.push_back((t << shift) + cs[q]); hr.push_back((int)i);
+                hv.push_back(-((double)(h >> 11) * (1.0 / 9007199254740992.0))); hc.push_back(t * width + cs[q]); hr.push_back((int)i);
             }
         }
     }
@@ -305,12 +309,13 @@ int main(int argc, char** argv)
         hdrBase[(size_t)t] = (int)hh.size();
         for (int kb = tileStart[(size_t)t]; kb < tileStart[(size_t)t + 1]; kb += kEnt) {
             const int ke = std::min(kb + kEnt, tileStart[(size_t)t + 1]);
+            const int tileCol0 = t * width;
             int2 h; h.x = hr[(size_t)kb]; h.y = kb > tileStart[(size_t)t] ? hr[(size_t)kb - 1] : -1;
             hh.push_back(h);
             for (int k = kb; k < ke; ++k) {
                 const int lr = hr[(size_t)k] - h.x;
                 if (lr >= (1 << (32 - shift))) ++overflow;
-                hp[(size_t)k] = ((unsigned)lr << shift) | (unsigned)(hc[(size_t)k] & ((1 << shift) - 1));
+                hp[(size_t)k] = ((unsigned)lr << shift) | (unsigned)(hc[(size_t)k] - tileCol0);
             }
         }
     }
@@ -335,10 +340,14 @@ int main(int argc, char** argv)
 #define PASSES(...) [&] { hipLaunchKernelGGL(zero_kernel, dim3(2048), dim3(256), 0, 0, dy, rows); \
         for (int t = 0; t < T; ++t) { const int kb = tileStart[(size_t)t], ke = tileStart[(size_t)t + 1]; if (ke <= kb) continue; const dim3 g((ke - kb + kEnt - 1) / kEnt); __VA_ARGS__; } }
 #define V0(ABL) PASSES(pass_v0<ABL><<<g, dim3(kBlock), 0, 0>>>(dx, dy, dv, dc, dr, kb, ke))
-#define V1(YE) PASSES(pass_v1<YE><<<g, dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t << shift, shift))
+#define V1(YE) PASSES(pass_v1<YE><<<g, dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t * width, shift))
     struct Row { const char* name; double ms; };
     std::vector<Row> res;
     auto run = [&](const char* name, auto f, bool exact) { const double ms = time_ms(f); res.push_back({ name, ms }); printf("%-48s %7.3f ms per product\n", name, ms); check(name, exact); fflush(stdout); };
+    if (quick) {
+        run("V1b production ordering (12 B entries)", PASSES(pass_v1b<<<g, dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t * width, shift, (const int*)nullptr)), true);
+        return 0;
+    }
     run("V0 production pass (16 B entries)", V0(0), true);
     run("V0 without the y read-modify-write", V0(1), false);
     run("V0 gathers from an 8 KB window (L1)", V0(2), false);
@@ -348,21 +357,21 @@ int main(int argc, char** argv)
     run("V1 12 B entries, y requested before the gathers", V1(1), true);
 #define V2(E, G) [&] { hipLaunchKernelGGL(zero_kernel, dim3(2048), dim3(256), 0, 0, dy, rows); \
         for (int t = 0; t < T; ++t) { const int kb = tileStart[(size_t)t], ke = tileStart[(size_t)t + 1]; if (ke <= kb) continue; const int nb = (ke - kb + kBlock * E - 1) / (kBlock * E); \
-            pass_v2<E><<<dim3(nb < (G) ? nb : (G)), dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t << shift, shift, nb); } }
+            pass_v2<E><<<dim3(nb < (G) ? nb : (G)), dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t * width, shift, nb); } }
     run("V1 12 B entries, y requested behind the gathers", V1(2), true);
-    run("V1b production ordering (one barrier)", PASSES(pass_v1b<<<g, dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t << shift, shift, (const int*)nullptr)), true);
+    run("V1b production ordering (one barrier)", PASSES(pass_v1b<<<g, dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t * width, shift, (const int*)nullptr)), true);
     {   // the same with 8 GB of other allocations alive (the product holds the CSR arrays next to the tiled copy)
         void* extra = nullptr; CK(hipMalloc(&extra, 8ull << 30)); CK(hipMemset(extra, 1, 8ull << 30));
-        run("V1b with 8 GB of other allocations alive", PASSES(pass_v1b<<<g, dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t << shift, shift, (const int*)nullptr)), true);
+        run("V1b with 8 GB of other allocations alive", PASSES(pass_v1b<<<g, dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t * width, shift, (const int*)nullptr)), true);
         CK(hipFree(extra));
     }
     run("V2 persistent, next block prefetched, 2048 wgs", V2(4, 2048), true);
 #define V1E(E, NT) [&] { hipLaunchKernelGGL(zero_kernel, dim3(2048), dim3(256), 0, 0, dy, rows); \
         for (int t = 0; t < T; ++t) { const int kb = tileStart[(size_t)t], ke = tileStart[(size_t)t + 1]; if (ke <= kb) continue; const dim3 g((ke - kb + kBlock * E - 1) / (kBlock * E)); \
-            pass_v1<0, E, NT><<<g, dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t << shift, shift); } }
+            pass_v1<0, E, NT><<<g, dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t * width, shift); } }
 #define V1Y(YM) [&] { hipLaunchKernelGGL(zero_kernel, dim3(2048), dim3(256), 0, 0, dy, rows); \
         for (int t = 0; t < T; ++t) { const int kb = tileStart[(size_t)t], ke = tileStart[(size_t)t + 1]; if (ke <= kb) continue; const dim3 g((ke - kb + kEnt - 1) / kEnt); \
-            pass_v1<0, 4, true, YM><<<g, dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t << shift, shift); } }
+            pass_v1<0, 4, true, YM><<<g, dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t * width, shift); } }
     run("V1 12 B, y stored non-temporally", V1Y(1), true);
     run("V1 12 B, y loaded non-temporally", V1Y(2), true);
     run("V1 12 B, y loaded and stored non-temporally", V1Y(3), true);
