@@ -221,7 +221,8 @@ struct MgcgSparse {
     std::vector<mgcg::DcsrMatrix*> analysed;
     // far-band distance found per matrix (the tile order of the row-tile kernel; any value gives the same results, so a stale
     // entry can only cost locality): keyed by the array pointers and the row count
-    struct PeriodEntry { const int* rowOffsets; const int* columnIndeces; long long rows, rowBase; int period; int maxRow; long long meanDistance; };
+    struct PeriodEntry { const int* rowOffsets; const int* columnIndeces; long long rows, rowBase; int period; int maxRow; long long meanDistance;
+                         int products = 0, threshold = 8; };   // per-op calls on this matrix since the column tiles were last (re)built / products before the next build
     std::vector<PeriodEntry> periods;
 };
 struct MgcgMatDescr { int type = 0; int base = 0; };
@@ -335,7 +336,17 @@ int launch_spmv_tiled(hipStream_t s, int epilogue, const SpmvArgs& a, const Dcsr
 // Cached analysis of a matrix on a handle (nullptr: compression off, not applicable, or the build failed).
 const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* rowOffsets, const int* columnIndeces,
                               long long rows, long long nnz, long long rowBase, long long columns = 0,    // columns: length of x (0: unknown, no column tiling)
-                              long long autoMeanDistance = -1);   // >= 0: a Solve-family call; with compression off the library may still build column tiles for a matrix whose entries lie this far (on average) from the diagonal
+                              long long autoMeanDistance = -1,    // >= 0: a Solve-family call; with compression off the library may still build column tiles for a matrix whose entries lie this far (on average) from the diagonal
+                              bool trustRegistry = false);        // the three arrays are library-owned vectors: every write the library can see marks the form stale, so no per-call checksum
+// Per-op calls (CsrMV, CsrMVDot, Solve0, Solve1: the reference's own phase driver multiplies through these, Mgcg.cu:10-19,116-163): the form
+// the caller asked for (MgcgSetMatrixCompression), or -- compression off -- the library's own column tiles for a matrix without locality
+// once it has been multiplied a few times through this handle, provided the three arrays are library-owned vectors (Create_*): writes
+// through any export mark the form stale (analysis_note_write), so it is trusted without the per-solve checksum.  Writes by the caller's
+// own kernels through ToRawPtr_* pointers are outside the library's view (MgcgAnalysisClear / MGCG_AUTO_TILES=0 are for those).
+const DcsrMatrix* dcsr_lookup_op(MgcgSparse* h, const SpmvArgs& a, long long rowBase);
+bool vector_owned(const void* p, size_t bytes);   // [p, p + bytes) lies inside a device vector the library allocated
+void vector_registry_add(const void* p, size_t bytes);
+void vector_registry_remove(const void* p);
 unsigned long long csr_checksum(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces, long long rows, long long nnz, unsigned long long* scratch);
 // Every export that writes device memory (or frees it) names the range here: analyses made from arrays it overlaps go stale
 // and are rebuilt at their next use (the reference re-uploads A into the same vectors on every Initialize():

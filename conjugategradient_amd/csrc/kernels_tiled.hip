@@ -356,9 +356,15 @@ static bool exclusive_scan(hipStream_t s, int* data, long long n)
 bool tiled_build(hipStream_t s, const double* elements, const int* rowOffsets, const int* columnIndeces,
                  long long rows, long long nnz, long long rowBase, long long columns, DcsrMatrix* out)
 {
-    int tileShift = 19;                                            // 2^19 columns = 4 MiB of x per tile (one XCD's L2)
-    { const int v = tuning().tileShift.load(std::memory_order_relaxed); if (v >= 8 && v <= 26) tileShift = v; }
-    const long long tileCols = 1LL << tileShift;
+    // Width of a tile's x window.  Round 3 used 2^19 columns = 4 MiB, the whole of an XCD's 4 MiB L2: the y lines and the entry streams of a
+    // pass then push window lines out again and every XCD fetches its window about nine times per pass (PMC, tools/tile_width_sweep.sh,
+    // profiles/r4/tile_width_pmc.json: 0.55 GB of L2-miss reads per pass where entries + y + window need 0.27; 12.6 GB per product = 1.8 x the
+    // form's own bytes).  At 2.85 MiB the re-fetches all but vanish (9.7 GB per product = 1.2 x its own bytes, 27 passes instead of 20 on the
+    // 10 M-column matrix) for the same time per product (2.68 against 2.66 ms: each pass costs its y sweep, ~21 us, whatever its width); below
+    // that the additional passes cost more than the misses (2.77 / 2.95 / 3.36 ms at 2.4 / 1.9 / 1.4 MiB).  MGCG_TILE_SHIFT = s asks for 2^s columns.
+    int tileShift = 19;                                            // bits of the packed word that hold the column offset inside a tile
+    long long tileCols = 365LL * 1024;                             // 2.85 MiB of x
+    { const int v = tuning().tileShift.load(std::memory_order_relaxed); if (v >= 8 && v <= 26) { tileShift = v; tileCols = 1LL << v; } }
     const int nTiles = (int)((columns + tileCols - 1) / tileCols);
     // equal-width tiles (not the last one narrow): tile t = columns [t * tileWidth, (t + 1) * tileWidth), tileWidth <= 2^tileShift -- every tile
     // then has the same share of a uniformly spread matrix, and the packed entries (below) fit in all of them

@@ -58,9 +58,10 @@ void CsrMV(MgcgSparse* cusparse, MgcgMatDescr* matDescr, double* y,
 #ifdef MGCG_LAB
     if (const char* ab = getenv("MGCG_SPMV_ABLATE")) a.ablate = atoi(ab);     // lab builds only: timing ablations with WRONG results
 #endif
-    const DcsrMatrix* dc = dcsr_lookup(cusparse, elements, rowOffsets, columnIndeces, rowCount, elementsCount, 0, columnCount);
+    const SpmvConfig cfg = cfg_for(cusparse, a, 0);
+    const DcsrMatrix* dc = dcsr_lookup_op(cusparse, a, 0);
     analysis_note_write(y, sizeof(double) * (size_t)rowCount);
-    launch_spmv_auto(cusparse->ws.stream, EPI_AXPBY, a, cfg_for(cusparse, a, 0), dc);
+    launch_spmv_auto(cusparse->ws.stream, EPI_AXPBY, a, cfg, dc);
     (void)MGCG_HIP(hipGetLastError());
 }
 
@@ -77,8 +78,9 @@ double CsrMVDot(MgcgBlas* cublas, MgcgSparse* cusparse, double* y,
 #endif
     a.elements = elements; a.rowOffsets = rowOffsets; a.columnIndeces = columnIndeces; a.x = x; a.y = y;
     a.elementsCount = elementsCount; a.rowCount = rowCount; a.columnCount = columnCount; a.w = w; a.partials = cublas->ws.partials;
-    const DcsrMatrix* dc = dcsr_lookup(cusparse, elements, rowOffsets, columnIndeces, rowCount, elementsCount, 0, columnCount);
-    const int n = launch_spmv_auto(cublas->ws.stream, EPI_DOT, a, cfg_for(cusparse, a, 0), dc);
+    const SpmvConfig cfg = cfg_for(cusparse, a, 0);
+    const DcsrMatrix* dc = dcsr_lookup_op(cusparse, a, 0);
+    const int n = launch_spmv_auto(cublas->ws.stream, EPI_DOT, a, cfg, dc);
     return finish_reduction(cublas->ws, n, 0);
 }
 
@@ -246,7 +248,10 @@ double Solve0(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr,
     a.elements = elementsVector->data; a.rowOffsets = rowOffsetsVector->data; a.columnIndeces = columnIndecesVector->data;
     a.x = pVector->data; a.y = ApVector->data; a.elementsCount = elementsCountForDevice; a.rowCount = countForDevice; a.columnCount = count;
     a.alpha = 1.0; a.beta = 0.0;
-    launch_spmv(s, EPI_AXPBY, a, cfg_for(cusparse, a, offsetForDevice));              // Ap = A p            (:138)
+    {
+        const SpmvConfig cfg = cfg_for(cusparse, a, offsetForDevice);
+        launch_spmv_auto(s, EPI_AXPBY, a, cfg, dcsr_lookup_op(cusparse, a, offsetForDevice));   // Ap = A p            (:138)
+    }
     launch_copy(s, rVector->data, bVector->data, countForDevice);                     // r = b               (:139)
     launch_axpy(s, rVector->data, ApVector->data, countForDevice, -1.0);              // r -= Ap
     launch_copy(s, pVector->data + offsetForDevice, rVector->data, countForDevice);   // p[offset..] = r     (:140)
@@ -268,7 +273,8 @@ double Solve1(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr,
     a.elements = elementsVector->data; a.rowOffsets = rowOffsetsVector->data; a.columnIndeces = columnIndecesVector->data;
     a.x = pVector->data; a.y = ApVector->data; a.elementsCount = elementsCountForDevice; a.rowCount = countForDevice; a.columnCount = count;
     a.w = pVector->data + offsetForDevice; a.partials = cublas->ws.partials;
-    const int n = launch_spmv(cublas->ws.stream, EPI_DOT, a, cfg_for(cusparse, a, offsetForDevice));   // Ap = A p ; p_loc.Ap  (:161-162) in one pass
+    const SpmvConfig cfg = cfg_for(cusparse, a, offsetForDevice);
+    const int n = launch_spmv_auto(cublas->ws.stream, EPI_DOT, a, cfg, dcsr_lookup_op(cusparse, a, offsetForDevice));   // Ap = A p ; p_loc.Ap  (:161-162) in one pass
     return finish_reduction(cublas->ws, n, 0);
 }
 

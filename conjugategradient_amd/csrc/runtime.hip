@@ -1,6 +1,7 @@
 // Runtime half of the C ABI: devices, handles, device vectors, errors.
 // Replaces Mgcg/cuBlas/MgcgGpu/Runtime.cu, Vector_Double.cu and Vector_Int.cu.
 #include "common.hpp"
+#include <map>
 
 namespace mgcg {
 
@@ -191,8 +192,48 @@ void analysis_note_write(const void* p, size_t bytes)
             m->stale.store(true, std::memory_order_release);
 }
 
+// ---------------------------------------------------------------- device vectors the library allocated
+static std::mutex g_allocMutex;
+static std::map<uintptr_t, size_t> g_allocs;
+void vector_registry_add(const void* p, size_t bytes) { if (p && bytes) { std::lock_guard<std::mutex> lock(g_allocMutex); g_allocs[(uintptr_t)p] = bytes; } }
+void vector_registry_remove(const void* p) { if (p) { std::lock_guard<std::mutex> lock(g_allocMutex); g_allocs.erase((uintptr_t)p); } }
+bool vector_owned(const void* p, size_t bytes)
+{
+    if (!p) return false;
+    std::lock_guard<std::mutex> lock(g_allocMutex);
+    auto it = g_allocs.upper_bound((uintptr_t)p);
+    if (it == g_allocs.begin()) return false;
+    --it;
+    return (uintptr_t)p + bytes <= it->first + it->second;
+}
+
+const DcsrMatrix* dcsr_lookup_op(MgcgSparse* h, const SpmvArgs& a, long long rowBase)
+{
+    if (!h) return nullptr;
+    if (h->compression != 0) return dcsr_lookup(h, a.elements, a.rowOffsets, a.columnIndeces, a.rowCount, a.elementsCount, rowBase, a.columnCount);
+    if (a.elementsCount < (4 << 20) || tuning().autoTiles.load(std::memory_order_relaxed) == 0) return nullptr;
+    MgcgSparse::PeriodEntry* pe = nullptr;             // (filled by spmv_period, which every per-op call makes first: cfg_for)
+    for (auto& e : h->periods)
+        if (e.rowOffsets == a.rowOffsets && e.columnIndeces == a.columnIndeces && e.rows == a.rowCount && e.rowBase == rowBase) { pe = &e; break; }
+    if (!pe || pe->meanDistance < (1LL << 19)) return nullptr;
+    // a form that exists and has seen no write since: use it
+    for (DcsrMatrix* q : h->analysed)
+        if (q->automatic && q->elements == a.elements && q->rowOffsets == a.rowOffsets && q->columnIndeces == a.columnIndeces && q->rows == a.rowCount &&
+            q->nnz == a.elementsCount && q->rowBase == rowBase && !q->stale.load(std::memory_order_acquire))
+            return q->usable ? q : nullptr;
+    // none, or written to since: the CSR kernels serve the next `threshold` products, then the tiles are (re)built -- a matrix that is rewritten
+    // between its products pays for ever fewer builds (the threshold doubles with every rebuild)
+    if (++pe->products < pe->threshold) return nullptr;
+    if (!vector_owned(a.elements, sizeof(double) * (size_t)a.elementsCount) || !vector_owned(a.columnIndeces, sizeof(int) * (size_t)a.elementsCount) ||
+        !vector_owned(a.rowOffsets, sizeof(int) * ((size_t)a.rowCount + 1))) { pe->products = 0; pe->threshold = 1 << 30; return nullptr; }   // not ours: never
+    const DcsrMatrix* m = dcsr_lookup(h, a.elements, a.rowOffsets, a.columnIndeces, a.rowCount, a.elementsCount, rowBase, a.columnCount, pe->meanDistance, true);
+    for (auto& e : h->periods)                         // (dcsr_lookup does not touch h->periods, but stay safe against reallocation)
+        if (e.rowOffsets == a.rowOffsets && e.columnIndeces == a.columnIndeces && e.rows == a.rowCount && e.rowBase == rowBase) { e.products = 0; if (e.threshold < (1 << 20)) e.threshold *= 2; break; }
+    return m;
+}
+
 const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* rowOffsets, const int* columnIndeces,
-                              long long rows, long long nnz, long long rowBase, long long columns, long long autoMeanDistance)
+                              long long rows, long long nnz, long long rowBase, long long columns, long long autoMeanDistance, bool trustRegistry)
 {
     if (!h) return nullptr;
     // The library's own choice (compression off, a Solve-family call): column tiles for a large matrix whose gathers have no locality --
@@ -216,6 +257,7 @@ const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* 
             if (!q->stale.load(std::memory_order_acquire)) {
                 if (!q->automatic) return q->usable ? q : nullptr;
                 if (!q->usable) return nullptr;
+                if (trustRegistry) return q;
                 if (csr_checksum(h->ws.stream, elements, rowOffsets, columnIndeces, rows, nnz, (unsigned long long*)(h->ws.devInts + 4)) == q->checksum) return q;
             }
             m = q;                                          // written to since: same slot, new analysis
@@ -374,6 +416,7 @@ static V* create_vec(long long size)
         if (!MGCG_HIP(hipMalloc((void**)&v->data, sizeof(T) * (size_t)size))) { delete v; return nullptr; }
         // thrust::device_vector<T>(size) value-initialises (Vector_Double.cu:9)
         if (!MGCG_HIP(hipMemsetAsync(v->data, 0, sizeof(T) * (size_t)size, d->stream))) { (void)hipFree(v->data); delete v; return nullptr; }
+        mgcg::vector_registry_add(v->data, sizeof(T) * (size_t)size);
     }
     return v;
 }
@@ -575,13 +618,13 @@ void CopyFromArray_Int(VectorInt* d, int s[], int count, int so, int dofs) { cop
 void Delete_Double(Vector* v)
 {
     if (!v) return;
-    if (v->data) { analysis_note_write(v->data, sizeof(double) * (size_t)v->size); DeviceState* d = device_state(); if (d) (void)hipStreamSynchronize(d->stream); (void)hipFree(v->data); }
+    if (v->data) { analysis_note_write(v->data, sizeof(double) * (size_t)v->size); vector_registry_remove(v->data); DeviceState* d = device_state(); if (d) (void)hipStreamSynchronize(d->stream); (void)hipFree(v->data); }
     delete v;
 }
 void Delete_Int(VectorInt* v)
 {
     if (!v) return;
-    if (v->data) { analysis_note_write(v->data, sizeof(int) * (size_t)v->size); DeviceState* d = device_state(); if (d) (void)hipStreamSynchronize(d->stream); (void)hipFree(v->data); }
+    if (v->data) { analysis_note_write(v->data, sizeof(int) * (size_t)v->size); vector_registry_remove(v->data); DeviceState* d = device_state(); if (d) (void)hipStreamSynchronize(d->stream); (void)hipFree(v->data); }
     delete v;
 }
 double* ToRawPtr_Double(Vector* v) { if (v) v->rawExported = true; return v ? v->data : nullptr; }

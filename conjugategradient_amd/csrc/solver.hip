@@ -473,7 +473,7 @@ static void placement_draw(CgRun& R)
     (void)hipStreamSynchronize(s);
     if (!ok) { best = 0; (void)hipGetLastError(); }
     for (int i = 0; i < n; ++i) if (i != best) { analysis_note_write(cand[i], bytes); (void)hipFree(cand[i]); }   // (freed addresses may be handed out again)
-    if (best != 0) { v->data = cand[best]; R.p = v->data; }
+    if (best != 0) { vector_registry_remove(v->data); v->data = cand[best]; R.p = v->data; vector_registry_add(v->data, bytes); }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (ok) { t_placementInfo[0] = n; t_placementInfo[1] = best; }

@@ -13,8 +13,14 @@
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-constexpr int kBlock = 256;
-constexpr int kTileE = 4;
+#ifndef KBLOCK
+#define KBLOCK 256
+#endif
+#ifndef KTILEE
+#define KTILEE 4
+#endif
+constexpr int kBlock = KBLOCK;
+constexpr int kTileE = KTILEE;
 constexpr int kEnt = kBlock * kTileE;      // entries per workgroup
 
 static inline unsigned long long mix(unsigned long long h) { h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 27; h *= 0x94D049BB133111EBull; h ^= h >> 31; return h; }

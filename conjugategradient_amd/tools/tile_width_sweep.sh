@@ -8,13 +8,13 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 LAB=$GRAFT_REPO_ROOT/conjugategradient_amd/tools/tile_lab
 ROWS=10000000
-for T in 20 24 27 32 40 54; do
+for T in ${TIME_TS:-20 24 27 32 40 54}; do
   W=$(( (ROWS + T - 1) / T ))
   MEAN=$(python3 -c "print(31.0/$T)")
   echo "== T=$T width=$W" | tee -a "$OUT/times.log"
   TILE_LAB_QUICK=1 $LAB $ROWS $T 19 $MEAN $W >> "$OUT/times.log" 2>&1
 done
-for T in 20 32 40; do
+for T in ${PMC_TS:-20 32 40}; do
   W=$(( (ROWS + T - 1) / T ))
   MEAN=$(python3 -c "print(31.0/$T)")
   (cd /tmp && TILE_LAB_QUICK=1 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/pmc_rd_T$T" -- $LAB $ROWS $T 19 $MEAN $W) > "$OUT/pmc_rd_T$T.log" 2>&1

@@ -4,6 +4,7 @@ the CPU oracle's product, timing, and the whole solve against a manufactured sol
 Host generation needs ~25 GB of RAM and a few minutes; --rows scales it down."""
 # Lives under tests/ (not in the package) because it checks the GPU products against the CPU oracle: the oracle is test infrastructure.
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -50,6 +51,7 @@ def main():
     algo = 12 * s.nnz + 4 * (s.Count + 1) + 16 * s.Count
     ev0, ev1 = L.MgcgEventCreate(), L.MgcgEventCreate()
     out["kernels"] = {}
+    L.MgcgSetTuning(b"auto_tiles", 0)            # the CSR kernels themselves (per-op calls would switch to the library's column tiles after a few products)
     for name, k in (("auto", 0), ("row-block (stream form)", 1), ("rows (lane = row)", 9), ("8 lanes/row", 5), ("16 lanes/row", 6), ("32 lanes/row", 7)):
         L.MgcgSetSpmvKernel(cg.cusparse, k)
         args = (cg.cusparse, cg.matDescr, dy.ToRawPtr(), cg.vectorA.ToRawPtr(), cg.vectorRowOffsets.ToRawPtr(), cg.vectorColumnIndeces.ToRawPtr(), dx.ToRawPtr(), s.nnz, s.Count, s.Count, 1.0, 0.0)
@@ -64,8 +66,41 @@ def main():
         ms = L.MgcgEventElapsedMs(ev0, ev1) / a.reps
         out["kernels"][name] = {"ms": ms, "algorithmic_gbps": algo / ms / 1e6, "bit_identical_to_oracle": bool(np.array_equal(got, ref)), "max_rel_err": err}
     L.MgcgSetSpmvKernel(cg.cusparse, 0)
+    L.MgcgSetTuning(b"auto_tiles", 1)
+    # per-op calls with everything at its default (compression off): CsrMV on library-owned vectors moves to the library's own column tiles after
+    # 8 products of the same matrix (write registry instead of a checksum per call), Solve1 -- the product of the reference's phase driver -- with it
+    L.MgcgAnalysisClear(cg.cusparse)
+    for _ in range(12):
+        L.CsrMV(*args)
+    got = dy.to_numpy()
+    L.MgcgEventRecord(ev0)
+    for _ in range(a.reps):
+        L.CsrMV(*args)
+    L.MgcgEventRecord(ev1)
+    ms = L.MgcgEventElapsedMs(ev0, ev1) / a.reps
+    out["kernels"]["per-op CsrMV, defaults (library's own column tiles from the 8th product)"] = {
+        "ms": ms, "algorithmic_gbps": algo / ms / 1e6, "bit_identical_to_oracle": bool(np.array_equal(got, ref)), "max_rel_err": float(np.abs(got - ref).max() / np.abs(ref).max())}
+    L.Solve1(cg.cublas, cg.cusparse, cg.matDescr, cg.vectorA.Ptr, cg.vectorRowOffsets.Ptr, cg.vectorColumnIndeces.Ptr, dy.Ptr, dx.Ptr, s.Count, s.Count, 0, s.nnz)
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        pap = L.Solve1(cg.cublas, cg.cusparse, cg.matDescr, cg.vectorA.Ptr, cg.vectorRowOffsets.Ptr, cg.vectorColumnIndeces.Ptr, dy.Ptr, dx.Ptr, s.Count, s.Count, 0, s.nnz)
+    ms = (time.perf_counter() - t0) / a.reps * 1e3
+    out["kernels"]["Solve1 (Ap = A p, p.Ap returned to the host), defaults"] = {
+        "ms": ms, "bit_identical_to_oracle": bool(np.array_equal(dy.to_numpy(), ref)), "p_dot_Ap_rel_err": abs(pap - float(np.dot(x, ref))) / abs(float(np.dot(x, ref)))}
+    L.MgcgAnalysisClear(cg.cusparse)
     # the column-tiled copy (class 4): opt-in for single products (MgcgSetMatrixCompression), the library's own choice inside solves;
     # 12-byte entries by default, the 16-byte form (round 2) for comparison
+    def tiles_n():
+        d = C.c_int(0)
+        i = 0
+        while True:
+            c = L.MgcgAnalysisInfo(cg.cusparse, i, C.byref(d), None, None, None)
+            if c == 4:
+                return d.value
+            if c < 0:
+                return 0
+            i += 1
+
     def tiled(label, pack):
         L.MgcgSetTuning(b"tile_pack", pack)
         L.MgcgAnalysisClear(cg.cusparse)
@@ -81,7 +116,7 @@ def main():
             L.CsrMV(*args)
         L.MgcgEventRecord(ev1)
         ms = L.MgcgEventElapsedMs(ev0, ev1) / a.reps
-        out["kernels"]["column tiles, %s (tile shift %s)" % (label, os.environ.get("MGCG_TILE_SHIFT", "19"))] = {
+        out["kernels"]["column tiles, %s (%s)" % (label, ("2^%s columns per tile" % os.environ["MGCG_TILE_SHIFT"]) if os.environ.get("MGCG_TILE_SHIFT") else "%d tiles" % tiles_n())] = {
             "ms": ms, "algorithmic_gbps": algo / ms / 1e6, "bit_identical_to_oracle": bool(np.array_equal(got, ref)),
             "max_rel_err": float(np.abs(got - ref).max() / np.abs(ref).max())}
     tiled("16-byte entries", 0)

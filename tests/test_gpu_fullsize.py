@@ -329,6 +329,45 @@ def test_config5_at_full_size(oracle):
     r = cg.b - dy.to_numpy()
     true_res = float(np.sqrt(np.dot(r, r)))
     assert abs(true_res - cg.Residual) <= 0.05 * cg.Residual + 1e-10, (true_res, cg.Residual)
+    # The per-op API (what the reference's own phase driver multiplies through: CsrMV Mgcg.cu:10-19, Solve1 :145-163) gets the tiles too, under
+    # the write registry instead of a checksum per call: compression off, library-owned vectors -- the first products of a matrix run on the
+    # CSR kernels (sums in tree order: 1e-13), from the 8th on the library's column tiles serve them (stored order: bit-identical to the oracle);
+    # a write through any export (Scal on the values) sends the next products back to the CSR kernels until the form is rebuilt.
+    L.MgcgAnalysisClear(cg.cusparse)
+    dx.CopyFrom(xs, N)
+
+    def automatic_form():
+        i = 0
+        while True:
+            c = L.MgcgAnalysisInfo(cg.cusparse, i, None, None, None, None)
+            if c < 0:
+                return None
+            if c == 4:
+                return i
+            i += 1
+
+    assert automatic_form() is None
+    built_at = None
+    for k in range(10):                                                    # (the handle has multiplied this matrix a few times already: the 8th product overall builds)
+        L.CsrMV(*args(dx))
+        got = dy.to_numpy()
+        if automatic_form() is None:
+            assert built_at is None and k < 8
+            np.testing.assert_allclose(got, ref, rtol=1e-13, atol=1e-13 * np.abs(ref).max())
+        else:
+            built_at = k if built_at is None else built_at
+            assert np.array_equal(got, ref), k
+    assert built_at is not None and built_at >= 1
+    pap = L.Solve1(cg.cublas, cg.cusparse, cg.matDescr, cg.vectorA.Ptr, cg.vectorRowOffsets.Ptr, cg.vectorColumnIndeces.Ptr, dy.Ptr, dx.Ptr, N, N, 0, nnz)
+    _lib.check("Solve1")
+    assert np.array_equal(dy.to_numpy(), ref) and abs(pap - float(np.dot(xs, ref))) <= 1e-12 * abs(pap)      # Ap = A p on the tiles ; p.Ap
+    L.Scal(cg.cublas, cg.vectorA.ToRawPtr(), 2.0, nnz)                     # a write the library sees: the form is stale at once
+    L.CsrMV(*args(dx))
+    np.testing.assert_allclose(dy.to_numpy(), 2.0 * ref, rtol=1e-13, atol=1e-13 * np.abs(ref).max())
+    L.Scal(cg.cublas, cg.vectorA.ToRawPtr(), 0.5, nnz)
+    for k in range(16):                                                    # (the threshold doubles with every rebuild: 16 products this time)
+        L.CsrMV(*args(dx))
+    assert np.array_equal(dy.to_numpy(), ref)
     for v in (dx, dy):
         v.Dispose()
     cg.Dispose()
