@@ -85,7 +85,10 @@ def main():
         ab["folds_reported"] = folds
     ms = [timed(run) for _ in range(a.repeats)]
     active = cg.LastOverlap()[0] if a.solver == "cg" else None
-    print(json.dumps({"solver": a.solver, "grid": list(dims), "force_multirank": force, "overlap": a.overlap, "halo_stream": a.halo_stream,
+    us = (C.c_double * 2)(0.0, 0.0)
+    measured = bool(L.MgcgLastOverlapTimes(us))       # overlap = 1: the library's measured rule (last plan of this thread: the CG loop's own halo)
+    print(json.dumps({"overlap_decided_by_measurement": measured, "measured_exchange_in_line_us": us[0] if measured else None, "measured_fork_launch_join_us": us[1] if measured else None,
+                      "solver": a.solver, "grid": list(dims), "force_multirank": force, "overlap": a.overlap, "halo_stream": a.halo_stream,
                       "steps": a.steps, "ms_per_iteration": min(ms), "ms_per_iteration_all": ms, "halo_overlap_active": active, "fold_up_ab_ms_per_iteration": ab}))
     cg.Dispose()
 

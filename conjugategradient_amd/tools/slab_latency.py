@@ -148,9 +148,10 @@ def main():
             rows = []
             for overlap, halo_stream in ((0, 0), (2, 0), (2, 1), (1, 0), (1, 1)):      # overlap 1 + halo_stream 0 = the library's defaults
                 r = fresh("--overlap", str(overlap), "--halo-stream", str(halo_stream))
-                rows.append({"overlap": overlap, "schedule": "exchange in line" if overlap == 0 else (("overlap where a level has >= 3 M rows (the default rule): " if overlap == 1 else "overlap on every level: ") + (
+                rows.append({"overlap": overlap, "schedule": "exchange in line" if overlap == 0 else (("overlap where the measured exchange costs more than the hops that hide it (round 4's default rule, MGCG_OVERLAP=1): " if overlap == 1 else "overlap on every level: ") + (
                                  "exchange on the side stream, rows on the main stream (MGCG_HALO_STREAM=1)" if halo_stream else "interior rows on the side stream, every RCCL call on the main stream (default)")),
-                             "ms_per_iteration": r["ms_per_iteration"], "added_us_vs_plain": 1e3 * (r["ms_per_iteration"] - plain), "halo_overlap_active": r["halo_overlap_active"]})
+                             "ms_per_iteration": r["ms_per_iteration"], "added_us_vs_plain": 1e3 * (r["ms_per_iteration"] - plain), "halo_overlap_active": r["halo_overlap_active"],
+                             "measured_exchange_in_line_us": r.get("measured_exchange_in_line_us"), "measured_fork_launch_join_us": r.get("measured_fork_launch_join_us")})
             out[kind]["fresh_process_plain_ms_per_iteration"] = plain
             out[kind]["one_rank_rccl_on_the_several_ranks_path"] = rows
     if a.full:
