@@ -542,6 +542,7 @@ bool halo_overlap_join(MgcgComm* c, hipStream_t mainStream)
 __global__ void overlap_probe_kernel(int* p) { if (p) *p = 0; }
 
 static thread_local double t_lastOverlapTimes[3] = { 0.0, 0.0, 0.0 };   // measured?, exchange in line (us), fork + launch + join (us)
+void halo_overlap_clear_times() { t_lastOverlapTimes[0] = 0.0; t_lastOverlapTimes[1] = 0.0; t_lastOverlapTimes[2] = 0.0; }
 void halo_overlap_last_times(double out[3]) { out[0] = t_lastOverlapTimes[0]; out[1] = t_lastOverlapTimes[1]; out[2] = t_lastOverlapTimes[2]; }
 
 // Does hiding THIS plan's exchange behind the interior rows pay on THIS communicator?  Measured once per plan, on the stream the loop

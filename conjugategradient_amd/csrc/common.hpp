@@ -228,7 +228,8 @@ struct MgcgSparse {
 struct MgcgMatDescr { int type = 0; int base = 0; };
 struct Vector    { double* data = nullptr; long long size = 0; int device = -1;
                    bool rawExported = false;   // ToRawPtr_Double handed the address out: the library must not move the data any more
-                   bool placed = false; };     // the placement draw (solver.hip) has looked at this vector
+                   bool placed = false;        // the placement draw (solver.hip) has looked at this vector
+                   int drawCount = 0, drawChosen = -1; float drawMs[16] = {}; };   // ... and what it measured (MgcgLastPlacement)
 struct VectorInt { int* data = nullptr;    long long size = 0; int device = -1; };
 
 namespace mgcg {
@@ -453,6 +454,7 @@ hipStream_t halo_overlap_fork(MgcgComm* c, hipStream_t mainStream);   // side st
 bool halo_overlap_join(MgcgComm* c, hipStream_t mainStream);          // mainStream waits for the side stream
 // the measured overlap rule (collective; once per plan): *pays = this plan's exchange in line costs more than the hops that would hide it
 bool halo_overlap_pays(MgcgComm* c, HaloPlan* h, double* vec, hipStream_t s, bool* pays);
+void halo_overlap_clear_times();
 void halo_overlap_last_times(double out[3]);   // calling thread's last decision: {measured?, exchange in line (us), fork + launch + join (us)}
 
 } // namespace mgcg

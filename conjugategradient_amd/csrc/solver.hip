@@ -83,6 +83,7 @@ static bool plan_overlap(hipStream_t s, MgcgComm* comm, bool multi, const int* r
                          HaloPlan* halo, double* vec, long long nGlobal)
 {
     *active = false; *i0 = 0; *i1 = 0;
+    halo_overlap_clear_times();                     // MgcgLastOverlapTimes speaks of the last plan: nothing measured yet
     if (!multi) return true;
     const int mode = tuning().overlap.load(std::memory_order_relaxed);
     bool wanted = mode == 2;
@@ -431,13 +432,19 @@ constexpr long long kPlacementMinEntries = 32LL << 20;
 static thread_local double t_placementMs[16];
 static thread_local int t_placementInfo[2] = { 0, -1 };     // candidates timed, chosen
 
+static void placement_report(const Vector* v)
+{
+    t_placementInfo[0] = v ? v->drawCount : 0; t_placementInfo[1] = v ? v->drawChosen : -1;
+    for (int i = 0; v && i < v->drawCount && i < 16; ++i) t_placementMs[i] = v->drawMs[i];
+}
+
 static void placement_draw(CgRun& R)
 {
     Vector* v = R.pVec;
+    placement_report(v);                           // MgcgLastPlacement speaks of THIS solve's p: the record of its one draw, or nothing
     const int extra = tuning().placement.load(std::memory_order_relaxed);
     if (!v || v->placed || v->rawExported || extra <= 0 || v->size < kPlacementMinEntries || v->data != R.p || R.nLocal < 4096 || R.elementsCount < 8) return;
     v->placed = true;                              // one draw per vector, whatever comes of it
-    t_placementInfo[0] = 0; t_placementInfo[1] = -1;
     hipStream_t s = R.ws->stream;
     const size_t bytes = sizeof(double) * (size_t)v->size;
     size_t freeB = 0, totalB = 0;
@@ -476,7 +483,7 @@ static void placement_draw(CgRun& R)
     if (best != 0) { vector_registry_remove(v->data); v->data = cand[best]; R.p = v->data; vector_registry_add(v->data, bytes); }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    if (ok) { t_placementInfo[0] = n; t_placementInfo[1] = best; }
+    if (ok) { v->drawCount = n; v->drawChosen = best; for (int i = 0; i < n; ++i) v->drawMs[i] = (float)t_placementMs[i]; placement_report(v); }
     if (ok && tuning().verbose.load(std::memory_order_relaxed) >= 1) {
         fprintf(stderr, "[MgcgGpu] placement draw for p (%lld entries): SpMV", v->size);
         for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f", t_placementMs[i]);

@@ -122,6 +122,99 @@ def test_one_rank_rccl_communicator_takes_the_several_ranks_path(oracle, mgcg_en
     L.MgcgCommDestroy(comm)
 
 
+def test_overlap_is_decided_by_measurement_on_the_live_communicator(oracle, mgcg_env):
+    """MGCG_OVERLAP=1 (the default): for slices of >= 1 M rows per rank the plan's own exchange is timed in line against the fork / launch /
+    join round trip of the overlap schedule on the communicator itself (halo_overlap_pays, comm.hip) and the exchange is hidden only where
+    it costs more than the hops that hide it.  On a one-rank RCCL communicator the self send/recv of a plane is cheap: the measured rule
+    must choose the exchange in line -- the cheapest schedule measured on such a box (profiles/r4/slab_latency_measured_overlap_rule.json)
+    -- report both times, and change no result."""
+    L = _lib.lib()
+    L.SetDevice(0)
+    buf = (C.c_char * 128)()
+    assert L.MgcgCommGetUniqueId(buf) == 0, _lib.last_error()
+    comm = L.MgcgCommInitRank(buf, 1, 0)
+    assert comm and L.MgcgCommTransport(comm) == b"rccl", _lib.last_error()
+    nx, nz = 128, 64                                               # 1 048 576 rows: the smallest slice the rule measures
+    mgcg_env.setenv("MGCG_FORCE_MULTIRANK", str(nx * nx))
+    mgcg_env.delenv("MGCG_OVERLAP", raising=False)
+    us = (C.c_double * 2)(0.0, 0.0)
+    res = {}
+    for mode in ("1", "0", "2"):
+        mgcg_env.setenv("MGCG_OVERLAP", mode)
+        cg = ConjugateGradientRankGpu(nx * nx * nz, 7, 0, 10**6, 1e-8, rank=0, world=1, comm=comm)
+        cg.InitializePoisson(nx, nx, nz)
+        res[mode] = cg.Steps(12, restart=True)
+        active = cg.LastOverlap()[0]
+        measured = L.MgcgLastOverlapTimes(us)
+        if mode == "1":
+            assert measured == 1 and us[0] > 0.0 and us[1] > 0.0, (measured, us[0], us[1])
+            assert active == (us[0] > us[1] + 13.0)                # the rule as stated; on one GPU: in line
+            assert not active
+        else:
+            assert measured == 0 and active == (mode == "2")
+        cg.Dispose()
+    # schedules only: the same iteration up to the grouping of the dot products' partial sums (interior and boundary rows are separate launches)
+    assert abs(res["1"] - res["0"]) <= 1e-12 * res["0"] and abs(res["2"] - res["0"]) <= 1e-12 * res["0"]
+    assert res["1"] == res["0"]                                    # (the measured rule chose the in-line schedule: the very same launches)
+    mgcg_env.setenv("MGCG_FORCE_MULTIRANK", "0")
+    plain = ConjugateGradientRankGpu(nx * nx * nz, 7, 0, 10**6, 1e-8, rank=0, world=1)
+    plain.InitializePoisson(nx, nx, nz)
+    assert abs(plain.Steps(12, restart=True) - res["1"]) <= 1e-12 * res["1"]     # (one rank: reduction order of the single-rank loop differs in the last bits)
+    plain.Dispose()
+    L.MgcgCommDestroy(comm)
+
+
+def test_a_rank_with_unusable_arguments_leaves_together_with_its_peers(oracle, mgcg_env):
+    """a rank that fails its local preconditions before the first collective must not simply return -- its peers would block in
+    the loop's first all-reduce for ever.  Rank 1 of 2 hands SolveParallel / CgSteps a partition that lies outside the matrix: both ranks
+    come back with an error (the healthy one says that another rank failed), nobody hangs, and the communicator is still usable."""
+    import threading
+
+    world = 2
+    mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    s = problems.poisson(16, 16, 8)
+    L = _lib.lib()
+    group = L.MgcgLoopbackCreate(world)
+    out = [None] * world
+
+    def body(rank):
+        L.SetDevice(rank)
+        comm = L.MgcgCommInitLoopback(group, rank)
+        cg = ConjugateGradientRankGpu(s.Count, 7, 0, s.Count, 1e-8, rank=rank, world=world, comm=comm, device=rank).load(s)
+        cg.Initialize()
+        good = cg.part.offset
+        msgs = []
+        for call in ("Solve", "Steps"):
+            if rank == 1:
+                cg.part.offset = s.Count                             # [offset, offset + count) runs past the last row
+            try:
+                cg.Solve() if call == "Solve" else cg.Steps(3)
+                msgs.append("no error")
+            except Exception as ex:     # noqa: BLE001
+                msgs.append(str(ex))
+            L.MgcgClearLastError()
+            cg.part.offset = good
+        cg.Solve()                                                   # the same communicator afterwards: a normal solve
+        msgs.append(cg.Iteration)
+        out[rank] = msgs
+        cg.Dispose()
+        L.MgcgCommDestroy(comm)
+
+    ts = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ts), "a rank is still blocked in a collective"
+    L.MgcgLoopbackDestroy(group)
+    ref = oracle.cg_parallel(s, world, max_iteration=s.Count)
+    for rank in range(world):
+        solve_msg, steps_msg, it = out[rank]
+        assert "bad partition" in solve_msg if rank == 1 else "another rank failed" in solve_msg, out
+        assert "bad partition" in steps_msg if rank == 1 else "another rank failed" in steps_msg, out
+        assert it == ref["iteration"]
+
+
 def test_comm_probe_prices_the_steps_of_the_several_ranks_path():
     """MgcgCommProbe (tools/slab_latency.py): every kind of step returns a finite, positive time on a one-rank RCCL communicator and on
     a communicator without a transport; bad arguments are refused."""

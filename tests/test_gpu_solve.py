@@ -262,3 +262,39 @@ def test_front_ends_driven_from_their_own_builders(oracle):
     assert gpu.Iteration() == ref["iteration"] + 1
     assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
     gpu.Dispose()
+
+
+def test_placement_draw_moves_p_once_and_changes_no_bit(mgcg_env):
+    """The library's placement draw (solver.hip: placement_draw; knob `placement`): at the first solve on a p of >= 32 M entries the loop's
+    own SpMV is timed on 3 more allocations of p and the fastest is kept -- the same doubles at another address.  Checked on 328^3
+    (35.3 M rows): four candidates timed, one chosen, the draw happens once per vector, results identical with the draw off, and a vector
+    whose address ToRawPtr_Double has handed out is never moved."""
+    from conjugategradient_amd.parallel import ConjugateGradientRankGpu
+
+    L = _lib.lib()
+    n = 328
+    ms = (C.c_double * 16)()
+    chosen = C.c_int(-1)
+
+    def run(placement, export_first=False):
+        mgcg_env.setenv("MGCG_PLACEMENT", str(placement))
+        cg = ConjugateGradientRankGpu(n**3, 7, 0, 10**6, 1e-8, rank=0, world=1)
+        cg.InitializePoisson(n, n, n)
+        before = cg.vectorP.ToRawPtr() if export_first else None
+        r1 = cg.Steps(6, restart=True)
+        cand = L.MgcgLastPlacement(ms, 16, C.byref(chosen))
+        times = [ms[i] for i in range(cand)]
+        L.MgcgFill(cg.vectorX.Ptr, 0.0)
+        r2 = cg.Steps(6, restart=True)                            # a second solve from the same x0 on the same vector: no second draw, same result
+        again = L.MgcgLastPlacement(ms, 16, C.byref(chosen))
+        after = cg.vectorP.ToRawPtr()
+        cg.Dispose()
+        return r1, r2, cand, times, chosen.value, again, before, after
+
+    r1, r2, cand, times, pick, again, _, _ = run(3)
+    assert cand == 4 and 0 <= pick < 4 and all(t > 0 for t in times) and times[pick] == min(times), (times, pick)
+    assert again == 4 and r1 == r2                                 # (the record of the one draw is still there; nothing was timed again)
+    o1, o2, cand0, *_ = run(0)
+    assert cand0 == 0 and (o1, o2) == (r1, r2)                      # the draw off: the same bits
+    e1, e2, cande, _, _, _, before, after = run(3, export_first=True)
+    assert cande == 0 and before == after and (e1, e2) == (r1, r2)  # an exported address stays where it is
