@@ -791,12 +791,17 @@ def main():
     with _watchdog(f"rank {rank}: the warm-up iterations (halo plan, first exchanges and all-reduces)", enabled=world > 1):
         run_steps(max(a.warmup, 1), True)
 
-    # the library's placement draw for p (first solve on a p beyond the Infinity Cache: the loop's SpMV timed on extra allocations, the fastest kept)
-    pl_ms = (C.c_double * 16)()
-    pl_chosen = C.c_int(-1)
-    pl_n = L.MgcgLastPlacement(pl_ms, 16, C.byref(pl_chosen))
-    placement = ({"candidates_spmv_ms": [pl_ms[i] for i in range(min(pl_n, 16))], "chosen": pl_chosen.value,
-                  "note": "one-off, inside the warm-up: candidate 0 is the allocation p came with (MGCG_PLACEMENT=0 switches the draw off)"} if pl_n > 0 else None)
+    # the library's placement draw (first solve on vectors beyond the Infinity Cache: the loop's SpMV timed on extra allocations of Ap, then of p; the fastest kept)
+    placement = None
+    stages = {}
+    for which, name in ((0, "Ap (the SpMV's output)"), (1, "p (its gathered input)")):
+        pl_ms = (C.c_double * 16)()
+        pl_chosen = C.c_int(-1)
+        pl_n = L.MgcgLastPlacement(which, pl_ms, 16, C.byref(pl_chosen))
+        if pl_n > 0:
+            stages[name] = {"candidates_spmv_ms": [pl_ms[i] for i in range(min(pl_n, 16))], "chosen": pl_chosen.value}
+    if stages:
+        placement = dict(stages, note="one-off, inside the warm-up: candidate 0 is the allocation the vector came with (MGCG_PLACEMENT=0 switches the draw off)")
 
     def barrier():
         if dist is not None:

@@ -123,7 +123,7 @@ SIGNATURES = {
     "CgSteps": (_d, [_vp] * 11 + [_i, _i, _i, _i, _i, _i, _i, _i]),
     "MgcgLastOverlap": (_i, [_vp]),
     "MgcgLastOverlapTimes": (_i, [_vp]),
-    "MgcgLastPlacement": (_i, [_vp, _i, _pi]),
+    "MgcgLastPlacement": (_i, [_i, _vp, _i, _pi]),
     "MgcgLastVcycleFolds": (_i, []),
     "MgcgLastHalo": (_i, [_vp]),
     "MgcgDebugTileOrder": (_i, [_ll, _i, _i, _i, _vp, _i]),

@@ -381,7 +381,8 @@ struct CgRun {
     long long interior0 = 0, interior1 = 0;
     bool noFoldedFinalize = false;         // tuning knobs, resolved once per solve (every iteration of every rank takes the same path)
     bool haloOnSide = false;
-    Vector* pVec = nullptr;                // the handle behind p (the placement draw may move its data)
+    Vector* pVec = nullptr;                // the handles behind p and Ap (the placement draw may move their data)
+    Vector* ApVec = nullptr;
 };
 
 static thread_local long long t_lastOverlap[3] = { 0, 0, 0 };
@@ -419,31 +420,34 @@ __global__ void snapshot_kernel(const CgScalars* sc, HostMirror* m, volatile int
 
 __global__ void clear_done_kernel(CgScalars* sc) { sc->done = 0; sc->status = 0; }
 
-// ---------------------------------------------------------------- placement draw for p
-// The same SpMV binary on the same matrix runs +-5 % apart depending on WHERE the runtime placed the gathered vector (identical HBM
-// traffic and L2 hit rates: the timing of the same requests -- the channel / bank hash of the physical pages; profiles/r2/
-// spmv_placement_*.log).  A kernel cannot steer that, but the library owns every vector (Create_Double): at the
-// first solve on a p of at least kPlacementMinEntries entries (256 MB: beyond the Infinity Cache) it allocates `placement` more buffers of
-// p's size, times the loop's own SpMV (fused with p.Ap) on each, keeps the fastest and frees the rest -- one draw becomes the best of k.
-// One-off cost at 512^3: 4 candidates x 4 launches x 2.5 ms + 3 GiB of copies ~ 45 ms, inside the first solve (the role cuSPARSE's csrmv
-// analysis plays in the reference's stack).  Nothing numerical changes: the same doubles at another address.  A vector whose address
-// the caller has seen (ToRawPtr_Double) is never moved.
+// ---------------------------------------------------------------- placement draw for Ap and p
+// The same SpMV binary on the same matrix runs up to 17 % apart depending on WHERE the runtime placed its two vectors (identical HBM
+// traffic and L2 hit rates: the timing of the same requests -- the channel / bank hash of the physical pages).  Round 4's probe
+// (tools/placement_probe2.py, profiles/r4/placement_probe2.log: every pair of 4 x and 4 y allocations in one process) shows the WRITTEN
+// vector dominating -- one y allocation is good or bad with every x (2.23-2.28 against 2.48-2.62 ms) -- and the gathered one adding a
+// few per cent.  A kernel cannot steer that, but the library owns every vector (Create_Double): at the first solve on vectors of at
+// least kPlacementMinEntries entries (256 MB: beyond the Infinity Cache) it allocates `placement` more buffers for Ap, times the loop's
+// own SpMV (fused with p.Ap) on each and keeps the fastest, then does the same for p: one draw becomes the best of k, twice.
+// One-off cost at 512^3: 2 x 4 candidates x 7 launches x 2.4 ms + 3 GiB of copies ~ 0.14 s, inside the first solve (the role cuSPARSE's
+// csrmv analysis plays in the reference's stack).  Nothing numerical changes: the same doubles at another address.  A vector whose
+// address the caller has seen (ToRawPtr_Double) is never moved.
 constexpr long long kPlacementMinEntries = 32LL << 20;
-static thread_local double t_placementMs[16];
-static thread_local int t_placementInfo[2] = { 0, -1 };     // candidates timed, chosen
+static thread_local double t_placementMs[2][16];
+static thread_local int t_placementInfo[2][2] = { { 0, -1 }, { 0, -1 } };     // per stage (0: Ap, 1: p): candidates timed, chosen
 
-static void placement_report(const Vector* v)
+static void placement_report(int stage, const Vector* v)
 {
-    t_placementInfo[0] = v ? v->drawCount : 0; t_placementInfo[1] = v ? v->drawChosen : -1;
-    for (int i = 0; v && i < v->drawCount && i < 16; ++i) t_placementMs[i] = v->drawMs[i];
+    t_placementInfo[stage][0] = v ? v->drawCount : 0; t_placementInfo[stage][1] = v ? v->drawChosen : -1;
+    for (int i = 0; v && i < v->drawCount && i < 16; ++i) t_placementMs[stage][i] = v->drawMs[i];
 }
 
-static void placement_draw(CgRun& R)
+// one stage: candidates for vector v (stage 0: the SpMV's output Ap, whose contents do not matter at this point; stage 1: its input p)
+static void placement_stage(CgRun& R, int stage, Vector* v)
 {
-    Vector* v = R.pVec;
-    placement_report(v);                           // MgcgLastPlacement speaks of THIS solve's p: the record of its one draw, or nothing
+    placement_report(stage, v);                    // MgcgLastPlacement speaks of THIS solve's vectors: the record of their one draw, or nothing
     const int extra = tuning().placement.load(std::memory_order_relaxed);
-    if (!v || v->placed || v->rawExported || extra <= 0 || v->size < kPlacementMinEntries || v->data != R.p || R.nLocal < 4096 || R.elementsCount < 8) return;
+    double*& mine = stage == 0 ? R.Ap : R.p;
+    if (!v || v->placed || v->rawExported || extra <= 0 || v->size < kPlacementMinEntries || v->data != mine || R.nLocal < 4096 || R.elementsCount < 8) return;
     v->placed = true;                              // one draw per vector, whatever comes of it
     hipStream_t s = R.ws->stream;
     const size_t bytes = sizeof(double) * (size_t)v->size;
@@ -463,32 +467,40 @@ static void placement_draw(CgRun& R)
     for (int i = 1; ok && i < n; ++i) ok = MGCG_HIP(hipMemcpyAsync(cand[i], v->data, bytes, hipMemcpyDeviceToDevice, s));   // the same contents everywhere
     int best = 0;
     constexpr int kReps = 6;
+    double ms[16];
     for (int i = 0; ok && i < n; ++i) {
         SpmvArgs a{};
-        a.elements = R.elements; a.rowOffsets = R.rowOffsets; a.columnIndeces = R.columnIndeces; a.x = cand[i]; a.y = R.Ap;
+        a.elements = R.elements; a.rowOffsets = R.rowOffsets; a.columnIndeces = R.columnIndeces;
+        a.x = stage == 1 ? cand[i] : R.p; a.y = stage == 0 ? cand[i] : R.Ap;
         a.elementsCount = R.elementsCount; a.rowCount = (int)R.nLocal; a.columnCount = (int)R.count;
-        a.w = cand[i] + R.offset; a.partials = R.ws->partials; a.doneFlag = nullptr;
+        a.w = a.x + R.offset; a.partials = R.ws->partials; a.doneFlag = nullptr;
         (void)launch_spmv_auto(s, EPI_DOT, a, R.cfg, R.dcsr);                              // warm-up (Ap and the partial sums are rewritten by the solve)
         ok = MGCG_HIP(hipEventRecord(e0, s));
         for (int k = 0; k < kReps; ++k) (void)launch_spmv_auto(s, EPI_DOT, a, R.cfg, R.dcsr);
         ok = ok && MGCG_HIP(hipEventRecord(e1, s)) && MGCG_HIP(hipEventSynchronize(e1));
-        float ms = 0.0f;
-        ok = ok && MGCG_HIP(hipEventElapsedTime(&ms, e0, e1));
-        t_placementMs[i] = (double)ms / kReps;
-        if (ok && t_placementMs[i] < t_placementMs[best]) best = i;
+        float t = 0.0f;
+        ok = ok && MGCG_HIP(hipEventElapsedTime(&t, e0, e1));
+        ms[i] = (double)t / kReps;
+        if (ok && ms[i] < ms[best]) best = i;
     }
     (void)hipStreamSynchronize(s);
     if (!ok) { best = 0; (void)hipGetLastError(); }
-    for (int i = 0; i < n; ++i) if (i != best) { analysis_note_write(cand[i], bytes); (void)hipFree(cand[i]); }   // (freed addresses may be handed out again)
-    if (best != 0) { vector_registry_remove(v->data); v->data = cand[best]; R.p = v->data; vector_registry_add(v->data, bytes); }
+    for (int i = 0; i < n; ++i) if (i != best) { analysis_note_write(cand[i], bytes); if (i == 0) vector_registry_remove(cand[0]); (void)hipFree(cand[i]); }   // (freed addresses may be handed out again)
+    if (best != 0) { v->data = cand[best]; mine = v->data; vector_registry_add(v->data, bytes); }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    if (ok) { v->drawCount = n; v->drawChosen = best; for (int i = 0; i < n; ++i) v->drawMs[i] = (float)t_placementMs[i]; placement_report(v); }
+    if (ok) { v->drawCount = n; v->drawChosen = best; for (int i = 0; i < n; ++i) v->drawMs[i] = (float)ms[i]; placement_report(stage, v); }
     if (ok && tuning().verbose.load(std::memory_order_relaxed) >= 1) {
-        fprintf(stderr, "[MgcgGpu] placement draw for p (%lld entries): SpMV", v->size);
-        for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f", t_placementMs[i]);
+        fprintf(stderr, "[MgcgGpu] placement draw for %s (%lld entries): SpMV", stage == 0 ? "Ap" : "p", v->size);
+        for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f", ms[i]);
         fprintf(stderr, " ms -> candidate %d\n", best);
     }
+}
+
+static void placement_draw(CgRun& R)
+{
+    placement_stage(R, 0, R.ApVec);                // the written vector first: it decides the most
+    placement_stage(R, 1, R.pVec);
 }
 
 static bool cg_enqueue_init(CgRun& R)
@@ -724,7 +736,7 @@ int SolveEx(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr,
     CgRun R;
     R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse;
     R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCount;
-    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data; R.pVec = pVector;
+    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data; R.pVec = pVector; R.ApVec = ApVector;
     R.count = count; R.nLocal = count; R.offset = 0;
     R.tol = allowableResidual; R.minIt = minIteration; R.maxIt = maxIteration; R.rule = rule;
     return cg_solve(R, iteration, residual, residualTrace, traceCapacity);
@@ -770,7 +782,7 @@ int SolveParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMa
     CgRun R;
     R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse; R.comm = comm; R.nranks = MgcgCommSize(comm); R.multi = comm_multi(comm);
     R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCountForDevice;
-    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data; R.pVec = pVector;
+    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data; R.pVec = pVector; R.ApVec = ApVector;
     R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice;
     R.tol = allowableResidual; R.minIt = minIteration; R.maxIt = maxIteration; R.rule = rule;
     if (R.multi) {
@@ -802,7 +814,7 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     CgRun R;
     R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse; R.comm = comm; R.nranks = MgcgCommSize(comm); R.multi = comm_multi(comm);
     R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCountForDevice;
-    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data; R.pVec = pVector;
+    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data; R.pVec = pVector; R.ApVec = ApVector;
     R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice; R.rule = MGCG_RULE_NATIVE;
     double* savedTrace = R.ws->trace; const int savedCap = R.ws->traceCap;
     R.ws->trace = nullptr; R.ws->traceCap = 0;
@@ -841,11 +853,12 @@ int MgcgLastHalo(long long volume[2])
 
 int MgcgLastVcycleFolds(void) { return t_lastFolds; }
 
-int MgcgLastPlacement(double milliseconds[], int capacity, int* chosen)
+int MgcgLastPlacement(int which, double milliseconds[], int capacity, int* chosen)
 {
-    const int n = t_placementInfo[0];
-    for (int i = 0; milliseconds && i < n && i < capacity; ++i) milliseconds[i] = t_placementMs[i];
-    if (chosen) *chosen = t_placementInfo[1];
+    if (which < 0 || which > 1) { if (chosen) *chosen = -1; return 0; }
+    const int n = t_placementInfo[which][0];
+    for (int i = 0; milliseconds && i < n && i < capacity; ++i) milliseconds[i] = t_placementMs[which][i];
+    if (chosen) *chosen = t_placementInfo[which][1];
     return n;
 }
 
@@ -1104,7 +1117,7 @@ int SolveMgParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, Mgcg
     CgRun R;
     R.ws = &cublas->ws; R.cfg = cfg_of(cusparse); R.prof = &cusparse->prof; R.cusparse = cusparse; R.mg = mg; R.comm = comm; R.nranks = MgcgCommSize(comm); R.multi = comm_multi(comm);
     R.elements = elementsVector->data; R.rowOffsets = rowOffsetsVector->data; R.columnIndeces = columnIndecesVector->data; R.elementsCount = elementsCountForDevice;
-    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data; R.z = zVector->data; R.pVec = pVector;
+    R.x = xVector->data; R.b = bVector->data; R.Ap = ApVector->data; R.p = pVector->data; R.r = rVector->data; R.z = zVector->data; R.pVec = pVector; R.ApVec = ApVector;
     R.count = count; R.nLocal = countForDevice; R.offset = offsetForDevice;
     R.tol = allowableResidual; R.minIt = minIteration; R.maxIt = maxIteration; R.rule = rule;
     if (R.multi) {

@@ -11,7 +11,7 @@ import json, sys
 d = json.loads(sys.stdin.readline())
 p = d.get('placement_draw_rank0') or {}
 print(json.dumps({'placement': $k, 'round': $i, 'it_per_s': round(d['value'], 2), 'spmv_in_loop_ms': round(d['roofline']['avg_launch_ms'], 4), 'frac': round(d['roofline']['frac'], 4),
-                  'export_frac': round(d['roofline_csr_spmv']['frac'], 4), 'candidates_ms': [round(v, 4) for v in p.get('candidates_spmv_ms', [])], 'chosen': p.get('chosen')}))" >> "$OUT"
+                  'export_frac': round(d['roofline_csr_spmv']['frac'], 4), 'draw': {k[:2]: [[round(t, 3) for t in v['candidates_spmv_ms']], v['chosen']] for k, v in p.items() if isinstance(v, dict)}}))" >> "$OUT"
     tail -1 "$OUT"
   done
 done

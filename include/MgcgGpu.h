@@ -174,9 +174,9 @@ int         MgcgAbiVersion(void);
  *   rank's slab, opt-in until RCCL on two streams of one communicator has been run on real multi-GPU hardware),
  *   force_multirank (MGCG_FORCE_MULTIRANK = w > 0: a one-rank RCCL communicator takes the several-ranks code path with an
  *   artificial halo of w entries, for measuring that path's device-side cost on a one-GPU box),
- *   placement (MGCG_PLACEMENT, default 3: the first Solve-family call on a p of >= 32 M entries times the loop's SpMV on that many
- *   EXTRA allocations of p and keeps the fastest -- where the runtime places the gathered vector moves the SpMV by +-5 %; 0: off;
- *   a vector whose address ToRawPtr_Double has handed out is never moved),
+ *   placement (MGCG_PLACEMENT, default 3: the first Solve-family call on vectors of >= 32 M entries times the loop's SpMV on that many
+ *   EXTRA allocations of Ap, keeps the fastest, and then does the same for p -- where the runtime places the two vectors moves the
+ *   SpMV by up to 17 %, the written one most; 0: off; a vector whose address ToRawPtr_Double has handed out is never moved),
  *   fail_comm_init (MGCG_FAIL_COMM_INIT, tests only: MgcgCommInitAll / MgcgCommInitRank report failure, as on a host whose RCCL
  *   cannot form a communicator -- callers must then fall back or fail loudly).
  * MgcgSetTuning / MgcgGetTuning take the knob's name or its environment variable; they return 0, or -1 for an unknown
@@ -426,10 +426,11 @@ int MgcgEstimateSpectrum(MgcgBlas* cublas, MgcgSparse* cusparse,
  * (rows outside it wait for the halo), or 0 when the exchange ran in line (single rank, MGCG_OVERLAP=0, or the
  * slice has too few rows that reference local columns only).  interior may be NULL. */
 int MgcgLastOverlap(long long interior[2]);
-/* The calling thread's last placement draw for p (tuning knob `placement`): returns the number of candidate allocations timed (0: no
- * draw happened -- small vector, knob off, address already exported), milliseconds[i] = the loop's SpMV on candidate i (candidate 0 is
- * the allocation the vector came with), *chosen = the one kept.  milliseconds / chosen may be NULL. */
-int MgcgLastPlacement(double milliseconds[], int capacity, int* chosen);
+/* The calling thread's last placement draw (tuning knob `placement`): which = 0 the SpMV's output vector Ap, 1 its gathered input p.
+ * Returns the number of candidate allocations timed (0: no draw happened -- small vector, knob off, address already exported),
+ * milliseconds[i] = the loop's SpMV on candidate i (candidate 0 is the allocation the vector came with), *chosen = the one kept.
+ * milliseconds / chosen may be NULL. */
+int MgcgLastPlacement(int which, double milliseconds[], int capacity, int* chosen);
 /* The measurement behind that choice (overlap = 1): returns 1 and microseconds[0] = one halo exchange in line, microseconds[1] = one
  * fork / empty launch / join round trip, both averaged over the ranks, if the calling thread's last plan was decided by measurement;
  * 0 if it was decided by the knob or the slice's size alone.  microseconds may be NULL. */
