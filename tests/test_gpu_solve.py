@@ -290,7 +290,7 @@ def test_placement_draw_moves_p_once_and_changes_no_bit(mgcg_env):
         again = L.MgcgLastPlacement(1, ms, 16, C.byref(chosen))
         after = cg.vectorP.ToRawPtr()
         cg.Dispose()
-        assert cand_ap == (4 if (placement and not export_first) else 0)      # (the written vector Ap is drawn first; its address was not exported here)
+        assert cand_ap == (4 if placement else 0)      # (the written vector Ap is drawn first; only p's address was exported, if any)
         return r1, r2, cand, times, chosen.value, again, before, after
 
     r1, r2, cand, times, pick, again, _, _ = run(3)
