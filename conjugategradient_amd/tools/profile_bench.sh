@@ -19,5 +19,6 @@ echo "stats rc=$?"
 echo "pmc_rd rc=$?"
 (cd /tmp && rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/pmc_wr" -- $BENCH) > "$OUT/pmc_wr.log" 2>&1
 echo "pmc_wr rc=$?"
-python3 conjugategradient_amd/tools/profile_summarize.py "$OUT" > "$OUT/summary.json"
+STEPS=$(echo " $ARGS " | sed -n 's/.* --steps \([0-9][0-9]*\) .*/\1/p'); STEPS=${STEPS:-100}
+python3 conjugategradient_amd/tools/profile_summarize.py "$OUT" "$STEPS" > "$OUT/summary.json"
 cat "$OUT/summary.json"

@@ -47,6 +47,15 @@ def main(out):
             res.setdefault("spmv_all", []).append(entry)      # every SpMV kernel of the run (the loop's fused launch AND the bare CsrMV export)
             if res["spmv"] is None or n > res["spmv"]["launches"]:
                 res["spmv"] = entry
+    # the loop's own launches of the fused SpMV: the LAST `steps` of the run (argv[2]; the library's placement draw launches the same kernel
+    # 2 x 4 x 7 times in the warm-up, on candidate allocations some of which are slow: they are in the stats file's average, not in this one)
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True):
+        with open(f) as fh:
+            sp = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(fh) if "spmv_rowtile_kernel<1" in r["Kernel_Name"])
+        if steps > 0 and len(sp) >= steps:
+            d = [x[1] for x in sp[-steps:]]
+            res["spmv_in_loop"] = {"launches": steps, "avg_ms": sum(d) / len(d) / 1e6, "all_launches_of_the_kernel": len(sp), "avg_ms_all": sum(x[1] for x in sp) / len(sp) / 1e6}
     print(json.dumps(res, indent=1))
 
 
