@@ -2,6 +2,7 @@
 cannot finish these in seconds, so the checks are a closed-form product (A.1 counts the missing neighbours),
 linearity, symmetry, and the recurrence residual against a recomputed b - A x."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -142,7 +143,8 @@ def test_config3_first_iterations_against_the_oracle_at_full_size(oracle):
     mg.InitializePoisson()
     mg.Solve(trace=True)
     assert mg.Iteration == its - 1
-    assert L.MgcgLastVcycleFolds() == 3                   # the schedule of record: first sweep and (on the 256^3 level) prolongation folded
+    if "MGCG_NO_FOLD" not in os.environ and os.environ.get("MGCG_FOLD_UP", "-1") != "0":
+        assert L.MgcgLastVcycleFolds() == 3               # the schedule of record: first sweep and (on the 256^3 level) prolongation folded
     x = np.empty(N)
     mg.vectorX.CopyTo(x, N)
     mg.Dispose()
