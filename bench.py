@@ -351,6 +351,42 @@ class _watchdog:
         return False
 
 
+class _ExtrasGuard:
+    """The untimed extras of an N > 1 line (config 4, probes, schedule sweeps) run stage by stage under this guard: a stage that does not
+    finish within MGCG_BENCH_EXTRAS_TIMEOUT seconds (default 150) -- a collective that never returns -- ends the run with status 0 and, on
+    rank 0, the line as far as it got plus `extras_aborted` = the stage.  The timed result is in `out` before the first stage starts: an
+    extra can never cost it.  (os._exit: the blocked call holds the GPU runtime's locks, a normal exit would wait for it.)"""
+
+    def __init__(self, rank: int, out: dict):
+        self.rank, self.out, self.name, self.timer = rank, out, "start", None
+        self.limit = float(os.environ.get("MGCG_BENCH_EXTRAS_TIMEOUT", "150"))
+
+    def _fire(self):
+        print(f"bench.py: rank {self.rank}: extras stage '{self.name}' did not finish within {self.limit:.0f} s -- ending the run with the line as far as it got",
+              file=sys.stderr, flush=True)
+        if self.rank == 0:
+            try:
+                line = json.dumps(dict(self.out, extras_aborted=self.name))
+            except Exception:       # noqa: BLE001 -- (the main thread was adding a key at this very moment)
+                line = json.dumps({k: v for k, v in list(self.out.items())} | {"extras_aborted": self.name}, default=str)
+            print(line, flush=True)
+        os._exit(0)
+
+    def stage(self, name: str):
+        import threading
+
+        self.done()
+        self.name = name
+        self.timer = threading.Timer(self.limit, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def done(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
 def _free_port() -> int:
     import socket
 
@@ -1062,28 +1098,8 @@ def main():
     # ---- N > 1, the driver's command (--solver cg): config 4, the communicator's prices and the halo schedules -- untimed extras behind a
     # guard that never costs the line
     if world > 1 and a.solver == "cg" and a.compression == 0 and not a.no_extras:
-        import threading
-
-        guard = {"stage": "start", "timer": None}
-        limit = float(os.environ.get("MGCG_BENCH_EXTRAS_TIMEOUT", "150"))
-
-        def fire():
-            print(f"bench.py: rank {rank}: extras stage '{guard['stage']}' did not finish within {limit:.0f} s -- ending the run with the line as far as it got", file=sys.stderr, flush=True)
-            if rank == 0:
-                try:
-                    line = json.dumps(dict(out, extras_aborted=guard["stage"]))
-                except Exception:       # noqa: BLE001 -- (the main thread was adding a key at this very moment)
-                    line = json.dumps({k: v for k, v in list(out.items())} | {"extras_aborted": guard["stage"]}, default=str)
-                print(line, flush=True)
-            os._exit(0)
-
-        def stage(name):
-            guard["stage"] = name
-            if guard["timer"] is not None:
-                guard["timer"].cancel()
-            guard["timer"] = threading.Timer(limit, fire)
-            guard["timer"].daemon = True
-            guard["timer"].start()
+        guard = _ExtrasGuard(rank, out)
+        stage = guard.stage
 
         broken = None
         try:
@@ -1110,10 +1126,9 @@ def main():
             if rank == 0:
                 out["mgcg"]["schedules"][SCHEDULE_LAST[0]] = lastm
         except Exception as ex:     # noqa: BLE001 -- this rank is now out of step with its peers' collectives: no further extras, no final barrier
-            broken = f"{guard['stage']}: {ex}"
+            broken = f"{guard.name}: {ex}"
             L.MgcgClearLastError()
-        if guard["timer"] is not None:
-            guard["timer"].cancel()
+        guard.done()
         if broken is not None:
             print(f"bench.py: rank {rank}: extras failed at {broken}", file=sys.stderr, flush=True)
             if rank == 0:

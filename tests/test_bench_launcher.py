@@ -148,3 +148,35 @@ def test_byte_counts_of_the_line():
     rv_nofold, _ = bench.vcycle_required_bytes(n, 3, 1, 4, fold=False)
     assert rv < rv_nofold
     assert abs((rv + rshell) - 60.43e9) < 0.01e9
+
+
+def test_a_blocked_extra_ends_the_run_with_the_line_as_far_as_it_got():
+    """The guard around the untimed extras of an N > 1 line (config 4, comm_probe, schedules): a stage that never returns -- a collective
+    waiting for a rank that is gone -- must not cost the timed result.  Rank 0 prints the line it already has with `extras_aborted`,
+    every rank leaves with status 0; a stage that finishes cancels its timer."""
+    code = textwrap.dedent(f"""
+        import json, os, sys, time
+        sys.path.insert(0, {ROOT!r})
+        os.environ["MGCG_BENCH_EXTRAS_TIMEOUT"] = "0.3"
+        import bench
+        rank = int(sys.argv[1])
+        out = {{"metric": "m", "value": 123.0}} if rank == 0 else {{}}
+        g = bench._ExtrasGuard(rank, out)
+        g.stage("comm_probe")
+        out["comm_probe"] = {{"allreduce_8B_us": 25.0}}
+        g.stage("cg schedules")                         # the previous stage finished in time: its timer is gone
+        time.sleep(0.1)
+        g.stage("mgcg: partitioned iterations and solve")
+        time.sleep(30)                                  # blocked
+        print("not reached")
+    """)
+    for rank in (0, 1):
+        out = subprocess.run([sys.executable, "-c", code, str(rank)], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0 and "not reached" not in out.stdout
+        assert "extras stage 'mgcg: partitioned iterations and solve' did not finish" in out.stderr
+        if rank == 0:
+            rec = json.loads(out.stdout.strip().splitlines()[-1])
+            assert rec["value"] == 123.0 and rec["comm_probe"]["allreduce_8B_us"] == 25.0
+            assert rec["extras_aborted"] == "mgcg: partitioned iterations and solve"
+        else:
+            assert out.stdout.strip() == ""
