@@ -164,6 +164,46 @@ def test_overlap_is_decided_by_measurement_on_the_live_communicator(oracle, mgcg
     L.MgcgCommDestroy(comm)
 
 
+def test_measured_overlap_rule_is_one_collective_decision_of_all_ranks(mgcg_env):
+    """The measured rule with SEVERAL ranks (two loopback ranks of 1 M rows each, the smallest slices it measures): every rank walks through
+    the same exchanges and the one all-reduce of the two times, so both ranks hold the same bits and take the same decision -- here the
+    host-staged exchange of the loopback transport costs far more than a fork / join, so the rule hides it -- and the iteration is the
+    single-rank loop's.  The multigrid set-up takes the same decision level by level (collective too: it must simply come back)."""
+    from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu
+
+    world, n = 2, 128
+    mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    mgcg_env.delenv("MGCG_OVERLAP", raising=False)
+    L = _lib.lib()
+
+    def make_rank(rank, comm):
+        cg = ConjugateGradientRankGpu(n**3, 7, 0, 10**6, 1e-8, rank=rank, world=world, comm=comm, device=rank)
+        cg.InitializePoisson(n, n, n)
+        res = cg.Steps(10, restart=True)
+        us = (C.c_double * 2)(0.0, 0.0)
+        measured = L.MgcgLastOverlapTimes(us)
+        active = cg.LastOverlap()[0]
+        cg.Dispose()
+        mg = ConjugateGradientMgRankGpu(n**3, 7, 0, 10**6, 1e300, (n, n, n), rank=rank, world=world, comm=comm, device=rank, rule=_lib.RULE_NATIVE, levels=3)
+        mg.InitializePoisson(n, n, n)
+        mg.Setup()
+        mg.MinIteration = 3
+        mg.Solve()
+        mres = mg.Residual
+        mg.Dispose()
+        return res, measured, us[0], us[1], active, mres
+
+    out = _run_ranks_in_threads(world, make_rank)
+    assert out[0][1] == out[1][1] == 1
+    assert out[0][2] == out[1][2] > 0.0 and out[0][3] == out[1][3] > 0.0          # the all-reduced times: the same bits on both ranks
+    assert out[0][4] == out[1][4] == (out[0][2] > out[0][3] + 13.0)               # the rule as stated, the same answer everywhere
+    assert out[0][0] == out[1][0] and out[0][5] == out[1][5]
+    single = ConjugateGradientRankGpu(n**3, 7, 0, 10**6, 1e-8, rank=0, world=1)
+    single.InitializePoisson(n, n, n)
+    assert abs(single.Steps(10, restart=True) - out[0][0]) <= 1e-12 * out[0][0]
+    single.Dispose()
+
+
 def test_a_rank_with_unusable_arguments_leaves_together_with_its_peers(oracle, mgcg_env):
     """a rank that fails its local preconditions before the first collective must not simply return -- its peers would block in
     the loop's first all-reduce for ever.  Rank 1 of 2 hands SolveParallel / CgSteps a partition that lies outside the matrix: both ranks
