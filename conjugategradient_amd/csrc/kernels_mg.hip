@@ -1,6 +1,6 @@
 // Multigrid transfer / set-up kernels and the device problem generator (gfx950).
 // The reference's "Mgcg" never implemented its multigrid; the algorithm is
-// defined in DESIGN.md section 5 and stated on the CPU in oracle/mg_oracle.c, whose arithmetic
+// defined in DESIGN.md section 6 and stated on the CPU in oracle/mg_oracle.c, whose arithmetic
 // order every kernel here reproduces (restriction adds the children in (z,y,x) order, etc.).
 // The smoother and residual passes are SpMV epilogues (kernels_spmv.hip: EPI_JACOBI, EPI_RESIDUAL).
 #include "common.hpp"

@@ -1,7 +1,7 @@
 """Multigrid-preconditioned CG ("MGCG") on one GPU through the C ABI (MgSetup / MgApply / SolveMg).
 
 The reference names itself MGCG (Mgcg/cuBlas/Mgcg/MgcgMain.cs:8) but never implemented the
-preconditioner; DESIGN.md section 5 defines the one built here (cell-centred geometric hierarchy,
+preconditioner; DESIGN.md section 6 defines the one built here (cell-centred geometric hierarchy,
 piecewise-constant transfer, Galerkin coarse operators scaled by 1/2, weighted-Jacobi V(nu,nu)).
 """
 from __future__ import annotations

@@ -81,7 +81,7 @@ def EstimateSpectrum(solver, jacobiScaled: bool = False, steps: int = 40, seed: 
 def jacobi_omega(lambdaMaxDinvA: float, dim: int | None = None) -> float:
     """Damping of x += omega D^-1 (b - A x).  For the constant-coefficient Laplacian the smoothing optimum over the
     high-frequency band [lambdaMax/(2 dim), lambdaMax] of D^-1 A is 2 / (lambdaMax (1 + 1/(2 dim))): 6/7 in 3-D and 4/5
-    in 2-D at lambdaMax = 2 -- the values the V-cycle uses (DESIGN.md section 5).  Without a dimension: 4 / (3 lambdaMax)."""
+    in 2-D at lambdaMax = 2 -- the values the V-cycle uses (DESIGN.md section 6).  Without a dimension: 4 / (3 lambdaMax)."""
     if dim is None:
         return 4.0 / (3.0 * lambdaMaxDinvA)
     return 2.0 / (lambdaMaxDinvA * (1.0 + 1.0 / (2.0 * dim)))

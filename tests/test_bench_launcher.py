@@ -147,7 +147,7 @@ def test_byte_counts_of_the_line():
     assert rshell == shell and rv < v                                          # no D^-1 array, folded first sweep and prolongation
     rv_nofold, _ = bench.vcycle_required_bytes(n, 3, 1, 4, fold=False)
     assert rv < rv_nofold
-    assert abs((rv + rshell) - 60.43e9) < 0.01e9                               # DESIGN section 5
+    assert abs((rv + rshell) - 60.43e9) < 0.01e9                               # DESIGN section 6
 
 
 def test_a_blocked_extra_ends_the_run_with_the_line_as_far_as_it_got():

@@ -28,7 +28,7 @@ def test_transfer_and_galerkin_match_scipy(oracle, dims):
     ref = (0.5 * (P.T @ A @ P)).tocsr()
     ref.sort_indices()
     assert abs(Ac - ref).max() == 0
-    # for the 7-point Laplacian (6,-1) this IS the rediscretised operator 2*(6,-1) (DESIGN.md section 5)
+    # for the 7-point Laplacian (6,-1) this IS the rediscretised operator 2*(6,-1) (DESIGN.md section 6)
     if dims[2] > 1:
         assert set(np.unique(e)) == {-2.0, 12.0}
     rng = np.random.default_rng(0)
