@@ -148,14 +148,15 @@ def test_overlap_is_decided_by_measurement_on_the_live_communicator(oracle, mgcg
         measured = L.MgcgLastOverlapTimes(us)
         if mode == "1":
             assert measured == 1 and us[0] > 0.0 and us[1] > 0.0, (measured, us[0], us[1])
-            assert active == (us[0] > us[1] + 13.0)                # the rule as stated; on one GPU: in line
-            assert not active
+            assert active == (us[0] > us[1] + 13.0)                # the rule as stated (on one GPU a self send/recv is cheap: in line, unless the box hiccups)
+            chose_in_line = not active
         else:
             assert measured == 0 and active == (mode == "2")
         cg.Dispose()
     # schedules only: the same iteration up to the grouping of the dot products' partial sums (interior and boundary rows are separate launches)
     assert abs(res["1"] - res["0"]) <= 1e-12 * res["0"] and abs(res["2"] - res["0"]) <= 1e-12 * res["0"]
-    assert res["1"] == res["0"]                                    # (the measured rule chose the in-line schedule: the very same launches)
+    if chose_in_line:
+        assert res["1"] == res["0"]                                # the in-line schedule: the very same launches
     mgcg_env.setenv("MGCG_FORCE_MULTIRANK", "0")
     plain = ConjugateGradientRankGpu(nx * nx * nz, 7, 0, 10**6, 1e-8, rank=0, world=1)
     plain.InitializePoisson(nx, nx, nz)
