@@ -180,3 +180,15 @@ def test_a_blocked_extra_ends_the_run_with_the_line_as_far_as_it_got():
             assert rec["extras_aborted"] == "mgcg: partitioned iterations and solve"
         else:
             assert out.stdout.strip() == ""
+
+
+def test_cpu_baseline_leg_reports_the_oracle_in_both_summation_orders():
+    """bench.py's cpu_baseline leg on a small grid (the only place outside tests/ that may run the oracle): the reference-order figure, the
+    exactly summed yardstick next to it (oracle_set_dot_mode, switched back afterwards), the bounded-sample bookkeeping."""
+    from oracle import oracle as O
+
+    cb = bench.cpu_baseline(24, 3)
+    assert cb["cores"] == 1 and cb["kind"] == "port" and cb["grid"] == 24 and cb["iterations"] == 3 and cb["value"] > 0
+    assert cb["residual"] > 0 and abs(cb["residual"] - cb["residual_with_compensated_dots"]) <= 1e-12 * cb["residual"]
+    assert O.lib().oracle_get_dot_mode() == 0
+    assert "24^3" in cb["sample"] and cb["all_cores_variant"].get("value", 1) > 0
