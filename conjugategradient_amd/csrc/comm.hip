@@ -96,6 +96,7 @@ struct MgcgComm {
     int nranks = 1, rank = 0;
     hipStream_t stream = nullptr;
     double* scratch = nullptr;       // device, 8 doubles
+    double* gather = nullptr;        // device, nranks * 8 doubles (knob dot_order: the ranks' values side by side, added in rank order); allocated at first use
     // callback transport (host-staged; MgcgCommInitCallbacks)
     MgcgAllGatherFn cbAllGather = nullptr; MgcgAllReduceFn cbAllReduce = nullptr; MgcgExchangeFn cbExchange = nullptr; void* cbUser = nullptr;
     std::vector<std::vector<double>> cbSend, cbRecv;
@@ -119,9 +120,49 @@ bool comm_multi(const MgcgComm* c)
     return c->nranks > 1 || (c->comm != nullptr && tuning().forceMultiRank.load(std::memory_order_relaxed) > 0);
 }
 
+// out[i] = ((0 + v[0][i]) + v[1][i]) + ... : the order of resultsDot.Sum() (ConjugateGradientParallelGpu.cs:463,499,525)
+__global__ void rank_order_sum_kernel(const double* __restrict__ all, int nranks, int count, double* __restrict__ out)
+{
+    const int i = threadIdx.x;
+    if (i >= count) return;
+    double a = 0.0;
+    for (int q = 0; q < nranks; ++q) a += all[(size_t)q * count + i];
+    out[i] = a;
+}
+
 bool comm_allreduce_sum(MgcgComm* c, double* devPtr, int count, hipStream_t s)
 {
     if (!c) return true;
+    const bool rankOrder = tuning().dotOrder.load(std::memory_order_relaxed) != 0;     // validation mode (the loopback transport adds in rank order anyway)
+    if (rankOrder && c->cbAllGather && c->cbAllReduce && c->nranks > 1) {
+        // callbacks: the caller's all-reduce adds in an order of its own; its all-gather (4 int64 per rank) carries the bit patterns instead
+        if (count > 8) { set_error("callback all-reduce: at most 8 values"); return false; }
+        double vals[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        bool ok = MGCG_HIP(hipMemcpyAsync(vals, devPtr, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
+        if (!ok) for (int i = 0; i < count; ++i) vals[i] = NAN;
+        std::vector<long long> all(4 * (size_t)c->nranks);
+        double sum[8];
+        for (int at = 0; at < count; at += 4) {
+            long long mine[4];
+            memcpy(mine, vals + at, sizeof(mine));
+            c->cbAllGather(mine, all.data(), c->cbUser);
+            for (int i = at; i < count && i < at + 4; ++i) {
+                double a = 0.0;
+                for (int q = 0; q < c->nranks; ++q) { double v; memcpy(&v, &all[4 * (size_t)q + (size_t)(i - at)], sizeof(v)); a += v; }
+                sum[i] = a;
+            }
+        }
+        return MGCG_HIP(hipMemcpyAsync(devPtr, sum, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s)) && MGCG_HIP(hipStreamSynchronize(s)) && ok;
+    }
+    if (rankOrder && c->comm != nullptr && !c->loop && !c->cbAllReduce && c->nranks > 1) {
+        Rccl* r = rccl();
+        if (!r) return false;
+        if (count > 8) { set_error("rank-ordered all-reduce: at most 8 values"); return false; }
+        if (!c->gather && !MGCG_HIP(hipMalloc((void**)&c->gather, sizeof(double) * 8 * (size_t)c->nranks))) return false;
+        if (!nccl_ok(r->AllGather(devPtr, c->gather, (size_t)count, NCCL_DOUBLE, c->comm, s), "ncclAllGather")) return false;
+        hipLaunchKernelGGL(rank_order_sum_kernel, dim3(1), dim3(8), 0, s, (const double*)c->gather, c->nranks, count, devPtr);
+        return MGCG_HIP(hipGetLastError());
+    }
     if (c->loop) {
         if (count > 8) { set_error("loopback all-reduce: at most 8 values"); return false; }
         MgcgLoopback* g = c->loop;
@@ -804,6 +845,7 @@ void MgcgCommDestroy(MgcgComm* c)
     if (c->cachedPlan) { c->cachedPlan->cached = false; halo_plan_destroy(c->cachedPlan); c->cachedPlan = nullptr; }
     if (c->comm) { Rccl* r = rccl(); if (r && r->CommDestroy) (void)r->CommDestroy(c->comm); }
     if (c->scratch) (void)hipFree(c->scratch);
+    if (c->gather) (void)hipFree(c->gather);
     if (c->evReady) (void)hipEventDestroy(c->evReady);
     if (c->evHalo) (void)hipEventDestroy(c->evHalo);
     if (c->haloStream) (void)hipStreamDestroy(c->haloStream);

@@ -67,6 +67,9 @@ struct Tuning {
                                              //                         opt-in until RCCL on two streams of one communicator has run on real multi-GPU hardware)
     std::atomic<int> forceMultiRank{0};      // MGCG_FORCE_MULTIRANK    a one-rank communicator takes the several-ranks code path (measurement)
     std::atomic<int> placement{3};           // MGCG_PLACEMENT          Solve-family calls on >= 32 M-entry p: time the SpMV on this many EXTRA allocations of p and keep the fastest (0: off)
+    std::atomic<int> dotOrder{0};            // MGCG_DOT_ORDER          validation only: 1 = every dot product adds its rounded products strictly left to right and the ranks'
+                                             //                         sums in rank order, as the reference's CPU twin does (LongVector.cs:15-31, resultsDot.Sum()) -- traces and
+                                             //                         iterates then EQUAL the oracle's; ~0.5 s per 1.3e8-entry dot, never on a timed path
     std::atomic<int> failCommInit{0};        // MGCG_FAIL_COMM_INIT     tests only: MgcgCommInitAll / MgcgCommInitRank report failure (what a host without a working RCCL does)
 };
 Tuning& tuning();
@@ -285,10 +288,13 @@ struct SpmvArgs {
 // Kernel family by average row length (measured on banded and random matrices, profiles/r1/rowlen_sweep.log):
 // 10 row-tile "lane = row" form (kernels_rowtile.hip; 9 = its single-wavefront predecessor, kernels_rows.hip),
 // 1 row-block stream form, 5 / 6 / 7 = 8 / 16 / 32 lanes per row.
+// Validation mode (knob dot_order): every sum in the reference's order -- the lanes-per-row forms add a row's products lane by lane and
+// then across lanes (1e-13 from the stored order of SparseMatrix.cs:68-88); the row-block stream form adds them in stored order.
+bool dot_reference_order();
 inline int spmv_auto_kernel(double avgRow)
 {
     if (avgRow <= 8.0) return 10;
-    if (avgRow <= 20.0) return 1;
+    if (avgRow <= 20.0 || dot_reference_order()) return 1;
     if (avgRow <= 28.0) return 5;
     if (avgRow <= 128.0) return 6;
     return 7;
@@ -371,6 +377,8 @@ void launch_scal(hipStream_t s, double* x, double alpha, long long n);
 void launch_xpay(hipStream_t s, double* y, const double* x, long long n, double beta);
 void launch_copy(hipStream_t s, double* y, const double* x, long long n);
 void launch_fill(hipStream_t s, double* y, double v, long long n);
+// knob dot_order: every dot product in the reference's order (one serial sum; the launch_* functions below then return 1 partial)
+void launch_dot_serial(hipStream_t s, const double* x, const double* y, long long n, double* out, const int* done);   // out[0] = ((x0 y0 + x1 y1) + x2 y2) + ...
 // partials[0..grid) = per-workgroup partial of sum x_i*y_i ; returns grid
 int  launch_dot_partials(hipStream_t s, const double* x, const double* y, long long n, double* partials);
 int  launch_nrminf_partials(hipStream_t s, const double* x, long long n, double* partials);

@@ -175,8 +175,54 @@ __global__ __launch_bounds__(kBlock) void dot_kernel(const double* __restrict__ 
     const double t = block_sum(acc, s_red);
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
+// ------------------------------------------------------------------ reference-order dot (validation mode: knob dot_order)
+// The reference's CPU twin adds the rounded products strictly left to right (Mgcg/cuBlas/Mgcg/LongVector.cs:15-31) and the host adds
+// the per-device sums in device order (ConjugateGradientParallelGpu.cs:463,499,525).  Everything element-wise in this library is
+// already bit-identical to that twin; with dot_order = 1 every dot product of Dot / CsrMVDot / Solve / Solve0..2 / SolveParallel /
+// SolveMg* takes this kernel instead of the tree sums, so whole residual traces and iterates become EQUAL to the oracle's, at any size
+// and rank count.  One workgroup: waves 1-3 stage the rounded products of the next batch in LDS (coalesced) while lane 0 of wave 0
+// adds the current batch in index order -- one dependent fp64 add per element, ~0.5 s per 1.3e8 entries.  A test instrument, never
+// on a timed path.  (Padding a batch with +0.0 changes nothing: a running sum that started at +0.0 is never -0.0.)
+constexpr int kSerialBatch = 2048;
+__global__ __launch_bounds__(kBlock) void dot_serial_kernel(const double* __restrict__ x, const double* __restrict__ y, long long n,
+                                                            double* __restrict__ out, const int* done)
+{
+    __shared__ double s_prod[2][kSerialBatch];
+    if (done != nullptr && *done != 0) return;
+    const int tid = threadIdx.x;
+    const long long nBatches = (n + kSerialBatch - 1) / kSerialBatch;
+    auto fill = [&](int buf, long long b) {
+        const long long base = b * kSerialBatch;
+        for (int k = tid - kWave; k < kSerialBatch; k += kBlock - kWave) {
+            const long long i = base + k;
+            double t = 0.0;
+            if (i < n) t = x[i] * y[i];
+            s_prod[buf][k] = t;
+        }
+    };
+    if (tid >= kWave) fill(0, 0);
+    __syncthreads();
+    double acc = 0.0;
+    for (long long b = 0; b < nBatches; ++b) {
+        if (tid >= kWave) { if (b + 1 < nBatches) fill((int)((b + 1) & 1), b + 1); }
+        else if (tid == 0) {
+            const double* q = s_prod[b & 1];
+#pragma unroll 16
+            for (int k = 0; k < kSerialBatch; ++k) acc += q[k];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out[0] = acc;
+}
+bool dot_reference_order() { return tuning().dotOrder.load(std::memory_order_relaxed) != 0; }
+void launch_dot_serial(hipStream_t s, const double* x, const double* y, long long n, double* out, const int* done)
+{
+    hipLaunchKernelGGL(dot_serial_kernel, dim3(1), dim3(kBlock), 0, s, x, y, n < 0 ? 0 : n, out, done);
+}
+
 int launch_dot_partials(hipStream_t s, const double* x, const double* y, long long n, double* partials)
 {
+    if (dot_reference_order()) { launch_dot_serial(s, x, y, n, partials, nullptr); return 1; }
     const bool v2 = al16(x) && al16(y);
     const int grid = grid_for(n, v2 ? 4 : 2);
     if (v2 && n >= (8LL << 20)) hipLaunchKernelGGL((dot_kernel<true, true>), dim3(grid), dim3(kBlock), 0, s, x, y, n, partials);
@@ -217,6 +263,14 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(const double* __restrict
     const double t = reduce_partials_block(partials, n, s_red, mode);
     if (threadIdx.x == 0) out[0] = t;
 }
+// partials[0] = sum / max of partials[0..n), in place (every read happens before the barrier inside the block reduction)
+__global__ __launch_bounds__(kBlock) void reduce_inplace_kernel(double* partials, int n, int mode, const int* done)
+{
+    __shared__ double s_red[4];
+    if (done != nullptr && *done != 0) return;
+    const double t = reduce_partials_block(partials, n, s_red, mode);
+    if (threadIdx.x == 0) partials[0] = t;
+}
 void launch_reduce(hipStream_t s, const double* partials, int n, double* out, int mode)
 {
     hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(kBlock), 0, s, partials, n, out, mode, (const int*)nullptr);
@@ -246,6 +300,7 @@ int launch_copy_dot(hipStream_t s, double* p, const double* r, long long n, doub
     const int grid = grid_for(n, v2 ? 4 : 2);
     if (v2) hipLaunchKernelGGL(copy_dot_kernel<true>, dim3(grid), dim3(kBlock), 0, s, p, r, n, partials, done);
     else hipLaunchKernelGGL(copy_dot_kernel<false>, dim3(grid), dim3(kBlock), 0, s, p, r, n, partials, done);
+    if (dot_reference_order()) { launch_dot_serial(s, r, r, n, partials, done); return 1; }      // the one sum in the reference's order replaces the partial sums
     return grid;
 }
 
@@ -293,6 +348,11 @@ int launch_update_xr(hipStream_t s, const CgScalars* sc, double* x, double* r, c
     if (v2) { if (inf) GO(true, true); else GO(true, false); }
     else { if (inf) GO(false, true); else GO(false, false); }
 #undef GO
+    if (dot_reference_order()) {
+        launch_dot_serial(s, r, r, n, partials, nullptr);
+        if (inf) hipLaunchKernelGGL(reduce_inplace_kernel, dim3(1), dim3(kBlock), 0, s, partialsInf, grid, 1, (const int*)nullptr);   // max of the partial maxima (order-free)
+        return 1;
+    }
     return grid;
 }
 
@@ -375,6 +435,11 @@ int launch_update_r(hipStream_t s, CgScalars* sc, double* r, const double* Ap, l
     if (v2) { if (inf) GO(true, true); else GO(true, false); }
     else { if (inf) GO(false, true); else GO(false, false); }
 #undef GO
+    if (dot_reference_order()) {
+        launch_dot_serial(s, r, r, n, partials, &sc->done);
+        if (inf) hipLaunchKernelGGL(reduce_inplace_kernel, dim3(1), dim3(kBlock), 0, s, partialsInf, grid, 1, (const int*)&sc->done);
+        return 1;
+    }
     return grid;
 }
 

@@ -80,7 +80,8 @@ double CsrMVDot(MgcgBlas* cublas, MgcgSparse* cusparse, double* y,
     a.elementsCount = elementsCount; a.rowCount = rowCount; a.columnCount = columnCount; a.w = w; a.partials = cublas->ws.partials;
     const SpmvConfig cfg = cfg_for(cusparse, a, 0);
     const DcsrMatrix* dc = dcsr_lookup_op(cusparse, a, 0);
-    const int n = launch_spmv_auto(cublas->ws.stream, EPI_DOT, a, cfg, dc);
+    int n = launch_spmv_auto(cublas->ws.stream, EPI_DOT, a, cfg, dc);
+    if (dot_reference_order()) { launch_dot_serial(cublas->ws.stream, w, y, rowCount, cublas->ws.partials, nullptr); n = 1; }
     return finish_reduction(cublas->ws, n, 0);
 }
 
@@ -274,7 +275,8 @@ double Solve1(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr,
     a.x = pVector->data; a.y = ApVector->data; a.elementsCount = elementsCountForDevice; a.rowCount = countForDevice; a.columnCount = count;
     a.w = pVector->data + offsetForDevice; a.partials = cublas->ws.partials;
     const SpmvConfig cfg = cfg_for(cusparse, a, offsetForDevice);
-    const int n = launch_spmv_auto(cublas->ws.stream, EPI_DOT, a, cfg, dcsr_lookup_op(cusparse, a, offsetForDevice));   // Ap = A p ; p_loc.Ap  (:161-162) in one pass
+    int n = launch_spmv_auto(cublas->ws.stream, EPI_DOT, a, cfg, dcsr_lookup_op(cusparse, a, offsetForDevice));   // Ap = A p ; p_loc.Ap  (:161-162) in one pass
+    if (dot_reference_order()) { launch_dot_serial(cublas->ws.stream, a.w, a.y, countForDevice, cublas->ws.partials, nullptr); n = 1; }
     return finish_reduction(cublas->ws, n, 0);
 }
 

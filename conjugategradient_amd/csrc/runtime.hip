@@ -49,6 +49,7 @@ const Knob kKnobs[] = {
     { "MGCG_HALO_STREAM", "halo_stream", &Tuning::haloStream, 0, false },
     { "MGCG_FORCE_MULTIRANK", "force_multirank", &Tuning::forceMultiRank, 0, false },
     { "MGCG_FAIL_COMM_INIT", "fail_comm_init", &Tuning::failCommInit, 0, false },
+    { "MGCG_DOT_ORDER", "dot_order", &Tuning::dotOrder, 0, false },
     { "MGCG_PLACEMENT", "placement", &Tuning::placement, 3, false },
 };
 Tuning g_tuning;

@@ -524,7 +524,7 @@ static bool cg_enqueue_init(CgRun& R)
     int n;
     if (R.mg) {
         int nz = 0;
-        if (!mg_apply(R.mg, R.r, R.z, nullptr, R.ws->partials, &nz)) return false;   // z = M^-1 r (+ r.z)
+        if (!mg_apply(R.mg, R.r, R.z, nullptr, dot_reference_order() ? nullptr : R.ws->partials, &nz)) return false;   // z = M^-1 r (+ r.z)
         launch_copy(s, pLoc, R.z, R.nLocal);                                         // p = z
         n = nz > 0 ? nz : launch_dot_partials(s, R.r, R.z, R.nLocal, R.ws->partials);   // rz = r.z
     } else {
@@ -576,6 +576,8 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
         n = launch_spmv_auto(s, EPI_DOT, a, R.cfg, R.dcsr);                          // Ap = A p ; p.Ap   (Mgcg.cu:244-245)
         prof_mark(R, false);
     }
+    const bool refDots = dot_reference_order();                                      // validation mode: p.Ap once more, in the reference's order
+    if (refDots) { launch_dot_serial(s, pLoc, R.Ap, R.nLocal, R.ws->partials, done); n = 1; }
     double* pInf = R.wantInf ? R.ws->partials + kMaxPartials : nullptr;
     double* rrPartials = R.ws->partials;
     // one rank, no preconditioner: the x/p update finalises the iteration itself (one launch fewer; MGCG_NO_FOLDED_FINALIZE for A/B)
@@ -606,7 +608,7 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
         // which costs one wasted V-cycle at the very end and saves a collective per iteration.
         launch_reduce_to(s, rrPartials, n, &sc->rrNew, done);                        // local r.r (before the V-cycle reuses the partial sums)
         int nz = 0;
-        if (!mg_apply(R.mg, R.r, R.z, done, R.ws->partials, &nz)) return false;      // z = M^-1 r (+ partial sums of r.z on the last sweep)
+        if (!mg_apply(R.mg, R.r, R.z, done, refDots ? nullptr : R.ws->partials, &nz)) return false;      // z = M^-1 r (+ partial sums of r.z on the last sweep)
         n = nz > 0 ? nz : launch_dot_partials(s, R.r, R.z, R.nLocal, R.ws->partials);
         launch_reduce_to(s, R.ws->partials, n, &sc->rzNew, done);                    // local r.z
         if (!comm_allreduce_sum(R.comm, &sc->rrNew, 2, s)) return false;             // {rrNew, rzNew} are adjacent in CgScalars  (:525 and the PCG's r.z)
@@ -628,7 +630,7 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
     }
     if (R.mg) {
         int nz = 0;
-        if (!mg_apply(R.mg, R.r, R.z, done, !R.multi ? R.ws->partials : nullptr, &nz)) return false;   // z = M^-1 r (+ r.z on the last sweep)
+        if (!mg_apply(R.mg, R.r, R.z, done, (!R.multi && !refDots) ? R.ws->partials : nullptr, &nz)) return false;   // z = M^-1 r (+ r.z on the last sweep)
         n = nz > 0 ? nz : launch_dot_partials(s, R.r, R.z, R.nLocal, R.ws->partials);
         if (R.multi) {
             launch_reduce_to(s, R.ws->partials, n, &sc->rzNew, done);

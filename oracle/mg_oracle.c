@@ -383,9 +383,34 @@ void oracle_mg_apply(mg_hierarchy *H, const double *r, double *z)
  *         beta = rzNew / rz; p = z + beta p; rz = rzNew
  * rule: 0 = ConjugateGradient.cs:56-79, 1 = Mgcg.cu:252 (min <= it && res < tol, plus maxIteration cap).
  */
+/* The dot products of the row-partitioned loop: every device sums its own rows left to right, the host adds the per-device sums in
+ * device order starting from 0 (resultsDot.Sum(), Mgcg/cuBlas/Mgcg/ConjugateGradientParallelGpu.cs:463,499,525).  One device: oracle_dot. */
+static double dot_parts(const double *l, const double *r, int deviceCount, const int64_t *off)
+{
+    double sum = 0;
+    for (int d = 0; d < deviceCount; d++) sum += oracle_dot(l + off[d], r + off[d], off[d + 1] - off[d]);
+    return sum;
+}
+
+int oracle_pcg_parts(mg_hierarchy *H, double *x, const double *b,
+                     int rule, double allowableResidual, int minIteration, int maxIteration,
+                     int deviceCount, const int64_t *off,
+                     int *iteration, double *residual, double *trace, int64_t traceCap);
+
 int oracle_pcg(mg_hierarchy *H, double *x, const double *b,
                int rule, double allowableResidual, int minIteration, int maxIteration,
                int *iteration, double *residual, double *trace, int64_t traceCap)
+{
+    const int64_t off[2] = { 0, H->lv[0].n };
+    return oracle_pcg_parts(H, x, b, rule, allowableResidual, minIteration, maxIteration, 1, off, iteration, residual, trace, traceCap);
+}
+
+/* The same loop with its dot products cut at the row ranges off[0..deviceCount] of a row partition (the preconditioner itself does not
+ * depend on the partition: the V-cycle has no sums across rows other than the SpMV rows themselves). */
+int oracle_pcg_parts(mg_hierarchy *H, double *x, const double *b,
+                     int rule, double allowableResidual, int minIteration, int maxIteration,
+                     int deviceCount, const int64_t *off,
+                     int *iteration, double *residual, double *trace, int64_t traceCap)
 {
     mg_level *L = &H->lv[0];
     const int64_t n = L->n;
@@ -396,15 +421,15 @@ int oracle_pcg(mg_hierarchy *H, double *x, const double *b,
     oracle_set_added(r, b, Ap, -1, n);
     oracle_mg_apply(H, r, z);
     memcpy(p, z, sizeof(double) * (size_t)n);
-    double rz = oracle_dot(r, z, n);
+    double rz = dot_parts(r, z, deviceCount, off);
     double res = 0;
     int it;
     for (it = 0;; it++) {
         oracle_spmv(L->elements, L->columnIndeces, L->rowOffsets, n, Ap, p);
-        double alpha = rz / oracle_dot(p, Ap, n);
+        double alpha = rz / dot_parts(p, Ap, deviceCount, off);
         oracle_set_added(x, x, p, alpha, n);
         oracle_set_added(r, r, Ap, -alpha, n);
-        double rrNew = oracle_dot(r, r, n);
+        double rrNew = dot_parts(r, r, deviceCount, off);
         res = sqrt(rrNew);
         if (trace && it < traceCap) trace[it] = res;
         int converged;
@@ -419,7 +444,7 @@ int oracle_pcg(mg_hierarchy *H, double *x, const double *b,
         if (converged) break;
         if (!(res == res) || isinf(res)) { status = 3; break; }
         oracle_mg_apply(H, r, z);
-        double rzNew = oracle_dot(r, z, n);
+        double rzNew = dot_parts(r, z, deviceCount, off);
         double beta = rzNew / rz;
         oracle_set_added(p, z, p, beta, n);
         rz = rzNew;

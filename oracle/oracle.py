@@ -89,6 +89,9 @@ def lib():
         L.oracle_pcg.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_double, C.c_int, C.c_int,
                                  C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p, C.c_int64]
         L.oracle_pcg.restype = C.c_int
+        L.oracle_pcg_parts.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, _lp,
+                                       C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p, C.c_int64]
+        L.oracle_pcg_parts.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -265,7 +268,9 @@ class Multigrid:
         lib().oracle_mg_apply(self.h, _f(r), z)
         return z
 
-    def pcg(self, rule=RULE_CSHARP, allowable_residual=1e-8, min_iteration=0, max_iteration=None, trace=False):
+    def pcg(self, rule=RULE_CSHARP, allowable_residual=1e-8, min_iteration=0, max_iteration=None, trace=False, offsets=None):
+        """offsets: row offsets of a row partition (len = devices + 1) -- the dot products are then per-device sums added in device
+        order, as the reference's host does for the unpreconditioned loop (ConjugateGradientParallelGpu.cs:463,499,525)."""
         n = self.system.Count
         x = _f(self.system.x).copy()
         max_iteration = n if max_iteration is None else max_iteration
@@ -273,8 +278,14 @@ class Multigrid:
         res = C.c_double(0)
         cap = max_iteration + 3
         tr = np.zeros(cap) if trace else None
-        st = lib().oracle_pcg(self.h, x, _f(self.system.b), rule, allowable_residual, min_iteration, max_iteration,
-                              C.byref(it), C.byref(res), tr.ctypes.data if trace else None, cap if trace else 0)
+        if offsets is None:
+            st = lib().oracle_pcg(self.h, x, _f(self.system.b), rule, allowable_residual, min_iteration, max_iteration,
+                                  C.byref(it), C.byref(res), tr.ctypes.data if trace else None, cap if trace else 0)
+        else:
+            off = np.ascontiguousarray(offsets, dtype=np.int64)
+            assert off[0] == 0 and off[-1] == n and np.all(np.diff(off) >= 0)
+            st = lib().oracle_pcg_parts(self.h, x, _f(self.system.b), rule, allowable_residual, min_iteration, max_iteration,
+                                        off.shape[0] - 1, off, C.byref(it), C.byref(res), tr.ctypes.data if trace else None, cap if trace else 0)
         out = dict(x=x, iteration=it.value, residual=res.value, status=st)
         if trace:
             out["trace"] = tr[: it.value + 1].copy()
