@@ -330,3 +330,46 @@ def test_one_rank_rccl_communicator_on_the_several_ranks_path_equals_the_oracle(
     assert_equal_bits(mg.x, mref["x"], "x")
     mg.Dispose()
     L.MgcgCommDestroy(comm)
+
+
+def test_config2_sixty_cg_iterations_equal_the_oracle_at_full_size(oracle, reference_order):
+    """BASELINE config 2 at its size (7-point 256^3, 16 777 216 rows, 117 047 296 nonzeros): 60 iterations of the unpreconditioned loop on
+    one rank and 12 on eight loopback ranks -- residual trace and all of x equal to oracle.cg / oracle.cg_parallel, bit for bit."""
+    from tests.test_gpu_parallel import _run_ranks_in_threads
+
+    n, its = 256, 60
+    N = n**3
+    e, c, r = oracle.poisson_csr(n, n, n)
+    s = problems.LinearSystem(e, c, r, np.zeros(N), np.ones(N), f"poisson{n}", grid=(n, n, n))
+    ref = oracle.cg(s, rule=oracle.RULE_NATIVE, allowable_residual=1e300, min_iteration=its - 1, max_iteration=its + 2, hard_cap=its + 3, trace=True)
+    assert ref["iteration"] == its - 1
+    cg = ConjugateGradientRankGpu(N, 7, its - 1, 1000, 1e300, rank=0, world=1, rule=_lib.RULE_NATIVE)
+    cg.InitializePoisson(n, n, n)
+    cg.Solve(trace=True)
+    assert cg.Iteration == its - 1
+    x = np.empty(N)
+    cg.vectorX.CopyTo(x, N, 0)
+    cg.Dispose()
+    assert_equal_bits(cg.trace, ref["trace"], "trace")
+    assert_equal_bits(x, ref["x"], "x")
+    # eight z-slabs of 32 planes (the reference's partition: floor(N / 8) rows each)
+    world, its8 = 8, 12
+    ref8 = oracle.cg_parallel(s, world, allowable_residual=1e300, min_iteration=its8 - 1, max_iteration=its8 + 2, trace=True)
+    assert ref8["iteration"] == its8 - 1
+    reference_order.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    reference_order.setenv("MGCG_OVERLAP", "2")
+
+    def make_rank(rank, comm):
+        cg = ConjugateGradientRankGpu(N, 7, its8 - 1, 1000, 1e300, rank=rank, world=world, comm=comm, device=rank)
+        cg.InitializePoisson(n, n, n)
+        cg.Solve(trace=True)
+        xs = np.empty(cg.part.count)
+        cg.vectorX.CopyTo(xs, cg.part.count, 0)
+        out = (cg.part.offset, cg.part.count, xs, cg.Iteration, cg.trace)
+        cg.Dispose()
+        return out
+
+    for off, cnt, xs, it, tr in _run_ranks_in_threads(world, make_rank):
+        assert it == its8 - 1
+        assert_equal_bits(tr, ref8["trace"], "8 ranks: trace")
+        assert_equal_bits(xs, ref8["x"][off: off + cnt], "8 ranks: x")

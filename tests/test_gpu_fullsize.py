@@ -110,23 +110,29 @@ def test_config5_like_irregular_rows(oracle):
     np.testing.assert_allclose(cg.x, np.ones(s.Count), rtol=1e-7)             # b = A.1
 
 
-def test_config3_first_iterations_against_the_oracle_at_full_size(oracle):
-    """BASELINE config 3 AT its size against the ORACLE (oracle/mg_oracle.c: hierarchy, V(1,1) Jacobi cycle and PCG shell restated on the
-    CPU): the first two MGCG iterations on the 7-point 512^3 system, plain CSR on every level.  They exercise every kernel of the cycle on
-    every level at full size (Galerkin set-up, folded first sweep and residual, restriction, coarse sweeps, prolongation, last sweep fused
-    with r.z, the PCG updates); the whole 157-iteration solve is beyond a CPU loop that takes ten seconds per V-cycle here.
+def test_config3_first_iterations_against_the_oracle_at_full_size(oracle, mgcg_env):
+    """BASELINE configs 3 and 4 AT their size against the ORACLE (oracle/mg_oracle.c: hierarchy, V(1,1) Jacobi cycle and PCG shell restated
+    on the CPU): the first two MGCG iterations on the 7-point 512^3 system, plain CSR on every level.  They exercise every kernel of the
+    cycle on every level at full size (Galerkin set-up, folded first sweep and residual, restriction, coarse sweeps, prolongation, last
+    sweep fused with r.z, the PCG updates); the whole 157-iteration solve is beyond a CPU loop that takes ten seconds per V-cycle here.
 
-    What can be demanded at this size: the V-cycle is bit-identical to the oracle's, so the loops differ only in their dot products --
+    The V-cycle and every vector update are bit-identical to the oracle's, so the loops differ only in the ORDER of their dot-product sums --
     and at 1.3e8 terms the reference's serial left-to-right sums (LongVector.cs:15-31) carry a rounding error of their own of order 1e-9
     (a running sum 1e8 times the addend, rounded the same way for long stretches), where the device's tree sums are good to 1e-15.  So:
-      (1) against the oracle with the SAME products summed exactly (compensated_dots): residual trace and iterate to the north star's 1e-10;
-      (2) against the reference-order oracle: within twice that oracle's own distance from the exactly summed one -- asserted, with the
-          distance itself required to be what the argument says (above 1e-10), so the bound cannot quietly become vacuous or unnecessary.
-    About two minutes of host time."""
+      (1) default mode against the oracle with the SAME products summed exactly (compensated_dots): trace and iterate to 1e-10;
+      (2) validation mode dot_order = 1 (the sums in the reference's order) against the reference-order oracle: EQUAL, bit for bit --
+          residual trace and all 134 217 728 entries of x;
+      (3) config 4 as stated -- the same system row-partitioned over EIGHT ranks (loopback ranks on the one card), dot_order = 1 -- against
+          the oracle with its sums cut at the ranks' rows and added in rank order (oracle_pcg_parts): equal again;
+      and the evidence that (1) needed its yardstick: the reference order's own distance from the exact sums is above 1e-10 here.
+    About three minutes of host time."""
     import conjugategradient_amd.problems as problems
     from conjugategradient_amd.multigrid import ConjugateGradientMgGpu
+    from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu
+    from tests.test_gpu_dot_order import assert_equal_bits
+    from tests.test_gpu_parallel import _run_ranks_in_threads
 
-    n, its = 512, 2
+    n, its, world = 512, 2, 8
     N = n**3
     L = _lib.lib()
     e, c, r = oracle.poisson_csr(n, n, n)
@@ -134,30 +140,60 @@ def test_config3_first_iterations_against_the_oracle_at_full_size(oracle):
     M = oracle.Multigrid(s, levels=3)
     kw = dict(rule=oracle.RULE_NATIVE, allowable_residual=1e300, min_iteration=its - 1, max_iteration=its + 2, trace=True)
     ref = M.pcg(**kw)
+    ref_parts = M.pcg(offsets=oracle.partition(N, world), **kw)
     with oracle.compensated_dots():
         exact = M.pcg(**kw)
-    assert ref["iteration"] == exact["iteration"] == its - 1 and len(ref["trace"]) == len(exact["trace"]) == its
-    del M
-    mg = ConjugateGradientMgGpu(N, 7, its - 1, 1000, 1e300, (n, n, n), levels=3, rule=_lib.RULE_NATIVE)
-    L.MgcgSetMatrixCompression(mg.cusparse, 0)
-    mg.InitializePoisson()
-    mg.Solve(trace=True)
-    assert mg.Iteration == its - 1
+    assert ref["iteration"] == exact["iteration"] == ref_parts["iteration"] == its - 1 and len(ref["trace"]) == len(exact["trace"]) == its
+    del M, s, e, c, r
+
+    def solve_single():
+        mg = ConjugateGradientMgGpu(N, 7, its - 1, 1000, 1e300, (n, n, n), levels=3, rule=_lib.RULE_NATIVE)
+        L.MgcgSetMatrixCompression(mg.cusparse, 0)
+        mg.InitializePoisson()
+        mg.Solve(trace=True)
+        assert mg.Iteration == its - 1
+        folds = L.MgcgLastVcycleFolds()
+        x = np.empty(N)
+        mg.vectorX.CopyTo(x, N)
+        mg.Dispose()
+        return mg.trace, x, folds
+
+    # (1) default mode: the same algorithm with exactly summed dot products
+    trace, x, folds = solve_single()
     if "MGCG_NO_FOLD" not in os.environ and os.environ.get("MGCG_FOLD_UP", "-1") != "0":
-        assert L.MgcgLastVcycleFolds() == 3               # the schedule of record: first sweep and (on the 256^3 level) prolongation folded
-    x = np.empty(N)
-    mg.vectorX.CopyTo(x, N)
-    mg.Dispose()
-    # (1) the same algorithm with exactly summed dot products
-    np.testing.assert_allclose(mg.trace, exact["trace"], rtol=1e-10)
+        assert folds == 3                                  # the schedule of record: first sweep and (on the 256^3 level) prolongation folded
+    np.testing.assert_allclose(trace, exact["trace"], rtol=1e-10)
     scale = np.abs(exact["x"]).max()
     assert np.abs(x - exact["x"]).max() <= 1e-10 * scale
-    # (2) the reference's summation order
     own_trace = np.abs(ref["trace"] - exact["trace"]) / exact["trace"]
-    own_x = np.abs(ref["x"] - exact["x"]).max() / scale
-    assert own_trace.max() > 1e-10, own_trace               # the reference order's own rounding at this size is what stands between the two
-    assert np.all(np.abs(mg.trace - ref["trace"]) / ref["trace"] <= 2.0 * own_trace + 1e-10), (mg.trace, ref["trace"], own_trace)
-    assert np.abs(x - ref["x"]).max() / scale <= 2.0 * own_x + 1e-10
+    assert own_trace.max() > 1e-10, own_trace               # the reference order's own rounding at this size: why (1) compares with exact sums
+    del exact
+    # (2) the reference's summation order: equality
+    mgcg_env.setenv("MGCG_DOT_ORDER", "1")
+    trace, x, _ = solve_single()
+    assert_equal_bits(trace, ref["trace"], "config 3 trace")
+    assert_equal_bits(x, ref["x"], "config 3 x")
+    del ref
+    # (3) config 4: eight z-slabs of 64 planes
+    mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    mgcg_env.setenv("MGCG_OVERLAP", "2")
+
+    def make_rank(rank, comm):
+        cg = ConjugateGradientMgRankGpu(N, 7, its - 1, 1000, 1e300, (n, n, n), rank=rank, world=world, comm=comm, device=rank, levels=3, rule=_lib.RULE_NATIVE)
+        cg.InitializePoisson(n, n, n)
+        cg.Setup()
+        cg.Solve(trace=True)
+        xs = np.empty(cg.part.count)
+        cg.vectorX.CopyTo(xs, cg.part.count, 0)
+        out = (cg.part.offset, cg.part.count, xs, cg.Iteration, cg.trace)
+        cg.Dispose()
+        return out
+
+    res = _run_ranks_in_threads(world, make_rank)
+    for off, cnt, xs, it, tr in res:
+        assert it == its - 1 and cnt == N // world
+        assert_equal_bits(tr, ref_parts["trace"], "config 4 trace")
+        assert_equal_bits(xs, ref_parts["x"][off: off + cnt], "config 4 x")
 
 
 @pytest.mark.parametrize("compression", [0, 1])
