@@ -378,13 +378,12 @@ HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long 
     for (int q = 0; q < n; ++q) h->contiguousRecv += h->recvCount[q];
     // Unstructured slices: the contiguous ranges degenerate to (nearly) the whole vector.  Whether index lists pay is a
     // collective decision (every rank must take the same path): all ranks look at the same table.
-    const bool noIndex = tuning().noIndexedHalo.load(std::memory_order_relaxed) != 0;
     bool wide = false;
     for (int q = 0; q < n; ++q) {
         const long long qCnt = all[4 * q + 1], qMin = all[4 * q + 2], qMax = all[4 * q + 3];
         if (qCnt > 0 && qMax >= qMin && (qMax - qMin + 1 - qCnt) * 4 >= count) wide = true;     // some rank asks for >= a quarter of the vector from others
     }
-    if (wide && !noIndex && columnIndeces != nullptr && count < 0x7fffffffLL) {
+    if (wide && columnIndeces != nullptr && count < 0x7fffffffLL) {
         if (!halo_plan_index(c, h, all, count, offset, countLocal, columnIndeces, nnz)) { halo_plan_destroy(h); return nullptr; }
     }
     // contiguous ranges are a function of the table every rank has just agreed on: keep them; `wide` is the same on every rank (same

@@ -46,21 +46,11 @@ struct Tuning {
     std::atomic<int> noFold{0};              // MGCG_NO_FOLD            V(1,*): store the first sweep instead of forming it per gather
     std::atomic<int> foldUp{-1};             // MGCG_FOLD_UP            V(1,1): x1 + P e formed per gather of the last sweep instead of a prolongation kernel + stored iterate:
                                              //                         -1 by level size (it pays up to a few ten million rows), 0 never, 1 wherever possible
-    std::atomic<int> noFoldedFinalize{0};    // MGCG_NO_FOLDED_FINALIZE separate finalisation kernel
     std::atomic<int> checkEvery{4};          // MGCG_CHECK_EVERY        iterations the host enqueues ahead of the stop flag
-    std::atomic<int> noUniformDiagonal{0};   // MGCG_NO_UNIFORM_DIAGONAL read the D^-1 array even when it is constant
-    std::atomic<int> noZsweep{0};            // MGCG_NO_ZSWEEP          memory-order tiles
-    std::atomic<int> rowtileNt{-1};          // MGCG_ROWTILE_NT         -1 by size, 0 / 1 forced
-    std::atomic<int> vecNt{-1};              // MGCG_VEC_NT             -1 by size, 0 / 1 forced
-    std::atomic<int> vecGrid{0}, rGrid{0}, xpGrid{0};      // MGCG_VEC_GRID / MGCG_R_GRID / MGCG_XP_GRID  workgroup caps (0: default)
-    std::atomic<int> patternGroup{0}, patternWaves{16};    // MGCG_PATTERN_GROUP / MGCG_PATTERN_WAVES
-    std::atomic<int> noIndexedHalo{0};       // MGCG_NO_INDEXED_HALO
-    std::atomic<int> tileNt{0}, tileShift{0};              // MGCG_TILE_NT / MGCG_TILE_SHIFT (0: default 19)
-    std::atomic<int> vectorValsNt{-1};       // MGCG_VECTOR_VALS_NT     lanes-per-row SpMV: values with the non-temporal hint (-1 by size)
+    std::atomic<int> tileShift{0};           // MGCG_TILE_SHIFT         column tiles of 2^shift columns (0: equal-width tiles of ~2.85 MiB of x, the default)
     std::atomic<int> tilePack{1};            // MGCG_TILE_PACK          column tiles with 12-byte entries (0: the 16-byte form)
     std::atomic<int> autoTiles{1};           // MGCG_AUTO_TILES         Solve-family calls build the column tiles themselves for matrices without locality
     std::atomic<int> verbose{0};             // MGCG_VERBOSE            errors also go to stderr
-    std::atomic<int> lazyCodeObjects{0};     // MGCG_LAZY_CODE_OBJECTS
     std::atomic<int> virtualDevices{0};      // MGCG_VIRTUAL_DEVICES    one physical GPU shown as n devices (tests)
     std::atomic<int> haloStream{0};          // MGCG_HALO_STREAM        overlap schedule: 0 (default) the interior rows on the side stream, every RCCL call on the main stream;
                                              //                         1 the halo exchange on the side stream, all rows on the main stream (measured faster on one GPU, solver.hip;

@@ -47,8 +47,7 @@ __device__ __forceinline__ double block_max(double v, double* s_red)
 
 static inline int grid_for(long long n, int perThread)
 {
-    const int knob = tuning().vecGrid.load(std::memory_order_relaxed);
-    const int cap = (knob >= 64 && knob <= kMaxGrid) ? knob : kMaxGrid;
+    const int cap = kMaxGrid;
     long long blocks = (n + (long long)kBlock * perThread - 1) / ((long long)kBlock * perThread);
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
@@ -63,11 +62,7 @@ static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // of one rank's slab of an 8-GPU run, 2 % at 134 M) and 2.5 % slower at 2 M rows and below, where every vector stays in the caches anyway.
 template <bool NTV, typename T> __device__ __forceinline__ T ldv(const T* p) { if constexpr (NTV) return __builtin_nontemporal_load(p); else return *p; }
 template <bool NTV, typename T> __device__ __forceinline__ void stv(const T& v, T* p) { if constexpr (NTV) __builtin_nontemporal_store(v, p); else *p = v; }
-static bool vec_nt(long long n)
-{
-    const int knob = tuning().vecNt.load(std::memory_order_relaxed);
-    return knob >= 0 ? knob != 0 : n > 3000000;
-}
+static bool vec_nt(long long n) { return n > 3000000; }
 
 template <bool V2, typename F2, typename F1>
 __device__ __forceinline__ void grid_stride(long long n, F2 f2, F1 f1)
@@ -422,11 +417,9 @@ int launch_update_r(hipStream_t s, CgScalars* sc, double* r, const double* Ap, l
     const bool v2 = al16(r) && al16(Ap);
     int grid = grid_for(n, v2 ? 4 : 2);
     // two workgroups per CU measured best for this 2-reads-1-write pass (0.565 ms against 0.59-0.61 for 768 / 1024 / 2048 and 0.72 for 256
-    // workgroups at 512^3; the 3-reads-2-writes x/p pass keeps 2048); MGCG_R_GRID overrides
-    const int rknob = tuning().rGrid.load(std::memory_order_relaxed);                 // (tools/slab_grid_ab.py)
-    const int rcap = (rknob >= 64 && rknob <= kMaxGrid) ? rknob : 0;
+    // workgroups at 512^3; the 3-reads-2-writes x/p pass keeps 2048)
     DeviceState* d = device_state();
-    const int want = rcap > 0 ? rcap : 2 * (d ? d->numCu : kNumCu);
+    const int want = 2 * (d ? d->numCu : kNumCu);
     if (grid > want) grid = want;
     const bool inf = partialsInf != nullptr;
     const bool nt = vec_nt(n);
@@ -583,8 +576,7 @@ void launch_update_xp_final(hipStream_t s, const FinalizeArgs& f, const double* 
     if (n <= 0) return;
     const bool v2 = al16(x) && al16(p) && al16(z);
     const bool nt = vec_nt(n);
-    int g2 = grid_for(n, 2);
-    { const int v = tuning().xpGrid.load(std::memory_order_relaxed); if (v >= 64 && v <= 16384 && v < g2) g2 = v; }      // (A/B: tools/slab_grid_ab.py)
+    const int g2 = grid_for(n, 2);
     if (v2 && nt) hipLaunchKernelGGL((update_xp_final_kernel<true, true>), dim3(g2), dim3(kBlock), 0, s, f, partials, partialsInf, nPartials, x, p, z, n);
     else if (v2) hipLaunchKernelGGL((update_xp_final_kernel<true, false>), dim3(g2), dim3(kBlock), 0, s, f, partials, partialsInf, nPartials, x, p, z, n);
     else hipLaunchKernelGGL((update_xp_final_kernel<false, false>), dim3(grid_for(n, 1)), dim3(kBlock), 0, s, f, partials, partialsInf, nPartials, x, p, z, n);

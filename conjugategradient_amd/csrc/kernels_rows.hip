@@ -259,7 +259,7 @@ __global__ __launch_bounds__(64) void spmv_pattern_kernel(SpmvArgs a, DcsrView m
     // Trip -> row block.  Workgroup k runs on XCD k % 8 (round-robin dispatch); with groupBlocks = G > 0 every XCD owns
     // every 8th run of G consecutive row blocks, so the +-1 grid-line (and, for the usual extents, +-1 plane) neighbours
     // of a row are multiplied on the same XCD and their x lines are shared through its L2.  G = 0 (default): plain
-    // grid-stride -- measured equal or faster at 512^3 (profiles/r1/spmv_sweep_pattern_512.log), MGCG_PATTERN_GROUP sets G.
+    // grid-stride -- measured equal or faster at 512^3 (profiles/r1/spmv_sweep_pattern_512.log); the launcher passes G = 0 since round 5.
     const bool grouped = groupBlocks > 0 && (gridDim.x & 7) == 0;
     const long long G = grouped ? groupBlocks : 1;
     const int xcd = grouped ? (int)(blockIdx.x & 7) : 0;
@@ -372,30 +372,20 @@ __global__ __launch_bounds__(64) void spmv_pattern_kernel(SpmvArgs a, DcsrView m
     }
 }
 
-static int pattern_group_blocks()
-{
-    const int r = tuning().patternGroup.load(std::memory_order_relaxed);
-    return (r >= 0 && r <= 65536) ? r : 0;
-}
-static int pattern_waves_per_cu()
-{
-    const int r = tuning().patternWaves.load(std::memory_order_relaxed);
-    return (r >= 1 && r <= 32) ? r : 16;
-}
+constexpr int kPatternWavesPerCu = 16;     // (A/B of rounds 2-3: 8 / 16 / 32 wavefronts per CU and grouped row blocks; 16 ungrouped stayed)
 
 template <int EPI>
 static int launch_pattern_epi(hipStream_t s, const SpmvArgs& a, const DcsrView& m, int gridReq, int periodRows)
 {
     const int nRowBlocks = (int)(((long long)a.rowCount + 127) / 128);
     DeviceState* d = device_state();
-    int grid = gridReq > 0 ? gridReq : pattern_waves_per_cu() * (d ? d->numCu : kNumCu);
+    int grid = gridReq > 0 ? gridReq : kPatternWavesPerCu * (d ? d->numCu : kNumCu);
     if (grid > kMaxPartials) grid = kMaxPartials;
     if (grid > nRowBlocks) grid = nRowBlocks;
     if (grid < 1) grid = 1;
     const size_t lds = (size_t)m.nPattern * m.patWidth * 12 + (size_t)m.nPattern * 4;
-    const int group = (grid % 8 == 0 && nRowBlocks >= 64 * 8) ? pattern_group_blocks() : 0;
-    const bool noSweep = tuning().noZsweep.load(std::memory_order_relaxed) != 0;
-    TileMap tm = make_tile_map(a.rowCount, (noSweep || group > 0 || a.rowCount % 128 != 0) ? 0 : periodRows, grid, 128);
+    const int group = 0;
+    TileMap tm = make_tile_map(a.rowCount, (a.rowCount % 128 != 0) ? 0 : periodRows, grid, 128);
     // slots per pass = the longest row when it is 5 or 7 (the 2-D / 3-D stencils), else 8
     if (m.patWidth == 7) hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 7>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks, group, tm);
     else if (m.patWidth == 5) hipLaunchKernelGGL((spmv_pattern_kernel<EPI, 5>), dim3(grid), dim3(64), lds, s, a, m, nRowBlocks, group, tm);

@@ -300,16 +300,14 @@ static int launch_rowtile_epi(hipStream_t s, const SpmvArgs& a, int periodRows, 
     if (nWG * kTW > kMaxPartials) nWG = kMaxPartials / kTW;
     if (nWG > nTiles) nWG = nTiles;
     if (nWG < 1) nWG = 1;
-    const bool noSweep = tuning().noZsweep.load(std::memory_order_relaxed) != 0;
-    TileMap tm = make_tile_map(a.rowCount, (noSweep || gapSkip > 0) ? 0 : periodRows, nWG, kTRows);
+    TileMap tm = make_tile_map(a.rowCount, gapSkip > 0 ? 0 : periodRows, nWG, kTRows);
     tm.gapAt = gapAt; tm.gapSkip = gapSkip;
     // Matrix streams with the non-temporal hint when the vectors of the system are small enough to live in the 256 MB Infinity Cache
     // between the kernels of an iteration (the slab of one rank of an 8-GPU run, the coarse levels of a hierarchy): the matrix, read once
     // per product, then does not push them out.  CG iteration, alternating inside one process (tools/nt_ab.py): -1 % at 8.4 M rows, -3.5 % at 16.8 M,
     // -1.5 % at 33.5 M, +0.2 % at 42 M, +1.5 % at 134 M (there the hint only costs) and +10 % at 2 M (there the matrix itself would have stayed in the cache).  Only the plain CG loop asks for it (SpmvConfig::flags & 8): inside the V-cycle
-    // the same hint made the slab's MGCG iteration 1-3 % slower.  MGCG_ROWTILE_NT=0/1 overrides.
-    const int ntKnob = tuning().rowtileNt.load(std::memory_order_relaxed);
-    const bool nt = ntKnob >= 0 ? ntKnob != 0 : (ntWindow && a.rowCount >= 8000000 && a.rowCount <= 36000000);
+    // the same hint made the slab's MGCG iteration 1-3 % slower.
+    const bool nt = ntWindow && a.rowCount >= 8000000 && a.rowCount <= 36000000;
     const bool seven = maxRow > 0 && maxRow <= 7;
     if (a.xScaled == 2) {                                         // (the multigrid's last sweep of a V(1,1) cycle: x1 + P e per gather)
         if constexpr (EPI == EPI_JACOBI || EPI == EPI_JACOBI_DOT) {

@@ -502,10 +502,9 @@ static int launch_vector_l(hipStream_t s, const SpmvArgs& a, const SpmvConfig& c
     int grid = cfg.gridBlocks > 0 ? cfg.gridBlocks : kMaxGrid;
     if (grid > blocks) grid = (int)blocks;
     if (grid < 1) grid = 1;
-    // values past the Infinity Cache, column ids inside it (see the kernel): MGCG_VECTOR_VALS_NT=0/1 overrides
-    const int knob = tuning().vectorValsNt.load(std::memory_order_relaxed);
+    // values past the Infinity Cache, column ids inside it (see the kernel)
     const long long idBytes = 4LL * a.elementsCount;
-    const bool vnt = knob >= 0 ? knob != 0 : (3 * idBytes > (256LL << 20) && idBytes <= (224LL << 20));
+    const bool vnt = 3 * idBytes > (256LL << 20) && idBytes <= (224LL << 20);
     if (vnt) hipLaunchKernelGGL((spmv_vector_kernel<EPI, LANES, true>), dim3(grid), dim3(kBlock), 0, s, a);
     else hipLaunchKernelGGL((spmv_vector_kernel<EPI, LANES>), dim3(grid), dim3(kBlock), 0, s, a);
     return grid;

@@ -292,11 +292,6 @@ __global__ __launch_bounds__(kBlock) void tiled_epilogue_kernel(SpmvArgs a)
     }
 }
 
-static bool tile_streams_nontemporal()
-{
-    return tuning().tileNt.load(std::memory_order_relaxed) != 0;
-}
-
 template <int EPI>
 static int launch_tiled_epi(hipStream_t s, const SpmvArgs& a, const DcsrView& m)
 {
@@ -311,8 +306,7 @@ static int launch_tiled_epi(hipStream_t s, const SpmvArgs& a, const DcsrView& m)
                                (int)((long long)t * m.tileWidth), m.tileShift, a.doneFlag);
             continue;
         }
-        if (tile_streams_nontemporal()) hipLaunchKernelGGL(spmv_tile_pass_kernel<true>, g, dim3(kBlock), 0, s, a.x, a.y, m.tileVals, m.tileCols, m.tileRowIds, kb, ke, a.doneFlag);
-        else hipLaunchKernelGGL(spmv_tile_pass_kernel<false>, g, dim3(kBlock), 0, s, a.x, a.y, m.tileVals, m.tileCols, m.tileRowIds, kb, ke, a.doneFlag);
+        hipLaunchKernelGGL(spmv_tile_pass_kernel<false>, g, dim3(kBlock), 0, s, a.x, a.y, m.tileVals, m.tileCols, m.tileRowIds, kb, ke, a.doneFlag);
     }
     if (EPI == EPI_AXPBY && a.alpha == 1.0) return 0;                // y = A x is already in place
     const int grid = grid_rows(a.rowCount);

@@ -25,26 +25,12 @@ struct Knob { const char* env; const char* name; std::atomic<int> Tuning::*field
 const Knob kKnobs[] = {
     { "MGCG_OVERLAP", "overlap", &Tuning::overlap, 1, false },
     { "MGCG_NO_FOLD", "no_fold", &Tuning::noFold, 0, true },
-    { "MGCG_NO_FOLDED_FINALIZE", "no_folded_finalize", &Tuning::noFoldedFinalize, 0, true },
     { "MGCG_FOLD_UP", "fold_up", &Tuning::foldUp, -1, false },
     { "MGCG_CHECK_EVERY", "check_every", &Tuning::checkEvery, 4, false },
-    { "MGCG_NO_UNIFORM_DIAGONAL", "no_uniform_diagonal", &Tuning::noUniformDiagonal, 0, true },
-    { "MGCG_NO_ZSWEEP", "no_zsweep", &Tuning::noZsweep, 0, true },
-    { "MGCG_ROWTILE_NT", "rowtile_nt", &Tuning::rowtileNt, -1, false },
-    { "MGCG_VEC_NT", "vec_nt", &Tuning::vecNt, -1, false },
-    { "MGCG_VEC_GRID", "vec_grid", &Tuning::vecGrid, 0, false },
-    { "MGCG_R_GRID", "r_grid", &Tuning::rGrid, 0, false },
-    { "MGCG_XP_GRID", "xp_grid", &Tuning::xpGrid, 0, false },
-    { "MGCG_PATTERN_GROUP", "pattern_group", &Tuning::patternGroup, 0, false },
-    { "MGCG_PATTERN_WAVES", "pattern_waves", &Tuning::patternWaves, 16, false },
-    { "MGCG_NO_INDEXED_HALO", "no_indexed_halo", &Tuning::noIndexedHalo, 0, true },
-    { "MGCG_TILE_NT", "tile_nt", &Tuning::tileNt, 0, false },
     { "MGCG_TILE_SHIFT", "tile_shift", &Tuning::tileShift, 0, false },
-    { "MGCG_VECTOR_VALS_NT", "vector_vals_nt", &Tuning::vectorValsNt, -1, false },
     { "MGCG_TILE_PACK", "tile_pack", &Tuning::tilePack, 1, false },
     { "MGCG_AUTO_TILES", "auto_tiles", &Tuning::autoTiles, 1, false },
     { "MGCG_VERBOSE", "verbose", &Tuning::verbose, 0, false },
-    { "MGCG_LAZY_CODE_OBJECTS", "lazy_code_objects", &Tuning::lazyCodeObjects, 0, true },
     { "MGCG_VIRTUAL_DEVICES", "virtual_devices", &Tuning::virtualDevices, 0, false },
     { "MGCG_HALO_STREAM", "halo_stream", &Tuning::haloStream, 0, false },
     { "MGCG_FORCE_MULTIRANK", "force_multirank", &Tuning::forceMultiRank, 0, false },
@@ -118,10 +104,8 @@ DeviceState* device_state()
         if (!MGCG_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking))) return nullptr;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, pd) == hipSuccess) d->numCu = prop.multiProcessorCount;
-        if (!tuning().lazyCodeObjects.load(std::memory_order_relaxed)) {
-            preload_kernels_spmv(); preload_kernels_rowtile(); preload_kernels_blas1(); preload_solver(); preload_ops();
-            preload_kernels_rows(); preload_kernels_mg(); preload_kernels_dcsr(); preload_kernels_tiled(); preload_comm(); preload_spectrum();
-        }
+        preload_kernels_spmv(); preload_kernels_rowtile(); preload_kernels_blas1(); preload_solver(); preload_ops();
+        preload_kernels_rows(); preload_kernels_mg(); preload_kernels_dcsr(); preload_kernels_tiled(); preload_comm(); preload_spectrum();
     }
     return d;
 }

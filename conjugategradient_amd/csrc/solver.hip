@@ -379,8 +379,7 @@ struct CgRun {
     // rows [interior0, interior1) reference local columns only: they are multiplied (side stream) while the halo of p is in flight
     bool overlap = false;
     long long interior0 = 0, interior1 = 0;
-    bool noFoldedFinalize = false;         // tuning knobs, resolved once per solve (every iteration of every rank takes the same path)
-    bool haloOnSide = false;
+    bool haloOnSide = false;               // tuning knob, resolved once per solve (every iteration of every rank takes the same path)
     Vector* pVec = nullptr;                // the handles behind p and Ap (the placement draw may move their data)
     Vector* ApVec = nullptr;
 };
@@ -497,13 +496,20 @@ static void placement_stage(CgRun& R, int stage, Vector* v)
     }
 }
 
-static void placement_draw(CgRun& R)
+// Is the draw worth its price for THIS call?  It costs about 2 stages x 3 candidates x 7 launches = 42 SpMV times (+ 3 GiB of copies at 512^3:
+// 0.14 s in all) and wins about 4-5 % of one SpMV per iteration (profiles/r4/placement_ab_*.log): it pays from about a thousand iterations.
+// The preconditioned loop converges in a few hundred (config 3: 157, where the draw recovered 28 ms of its 140: ADVICE r4) -- no draw there;
+// the plain loop draws when its iteration cap leaves room for that many (the 512^3 system needs 1225), and CgSteps -- the fixed-length
+// form a caller uses to time the steady state -- always does (steps = 0 in R.maxIt).
+constexpr int kPlacementMinIterations = 1000;
+static void placement_draw(CgRun& R, bool fixedSteps)
 {
+    if (R.mg != nullptr || (!fixedSteps && R.maxIt < kPlacementMinIterations)) { placement_report(0, nullptr); placement_report(1, nullptr); return; }
     placement_stage(R, 0, R.ApVec);                // the written vector first: it decides the most
     placement_stage(R, 1, R.pVec);
 }
 
-static bool cg_enqueue_init(CgRun& R)
+static bool cg_enqueue_init(CgRun& R, bool fixedSteps = false)
 {
     hipStream_t s = R.ws->stream;
     long long meanDistance = 0;
@@ -511,7 +517,7 @@ static bool cg_enqueue_init(CgRun& R)
     if (R.cusparse) R.dcsr = dcsr_lookup(R.cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset, R.count, R.mg ? -1 : meanDistance);
     if (meanDistance >= (1LL << 19) && R.count >= (8LL << 19)) R.cfg.flags |= 16;      // gathers without locality: the stream form among the CSR kernels
     if (!R.mg) R.cfg.flags |= 8;                 // plain CG loop: the row-tile kernel may read the matrix with the non-temporal hint (kernels_rowtile.hip)
-    placement_draw(R);                           // (before p is touched: may move p's data once per vector)
+    placement_draw(R, fixedSteps);               // (before p is touched: may move p's data once per vector)
     CgScalars* sc = R.ws->scalars;
     double* pLoc = R.p + R.offset;
     if (R.rule == MGCG_RULE_SIMPLE) launch_fill(s, R.x, 0.0, R.nLocal);             // SimpleConjugateGradient.cu:53
@@ -580,10 +586,9 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
     if (refDots) { launch_dot_serial(s, pLoc, R.Ap, R.nLocal, R.ws->partials, done); n = 1; }
     double* pInf = R.wantInf ? R.ws->partials + kMaxPartials : nullptr;
     double* rrPartials = R.ws->partials;
-    // one rank, no preconditioner: the x/p update finalises the iteration itself (one launch fewer; MGCG_NO_FOLDED_FINALIZE for A/B)
-    const bool noFold = R.noFoldedFinalize;
-    const bool fold = !R.multi && !R.mg && R.nLocal > 0 && !noFold;
-    const bool foldRanks = R.multi && !R.mg && R.nLocal > 0 && !noFold;         // several ranks: the same fold behind the all-reduce of r.r
+    // one rank, no preconditioner: the x/p update finalises the iteration itself (one launch fewer)
+    const bool fold = !R.multi && !R.mg && R.nLocal > 0;
+    const bool foldRanks = R.multi && !R.mg && R.nLocal > 0;                    // several ranks: the same fold behind the all-reduce of r.r
     if (R.multi) {
         launch_reduce_to(s, R.ws->partials, n, &sc->pAp, done);
         if (!comm_allreduce_sum(R.comm, &sc->pAp, 1, s)) return false;               // (:499)
@@ -658,7 +663,6 @@ static int cg_solve(CgRun& R, int* iteration, double* residual, double* residual
     double* savedTrace = R.ws->trace; const int savedCap = R.ws->traceCap;
     if (!devTraceCap) { R.ws->trace = nullptr; R.ws->traceCap = 0; } else R.ws->traceCap = devTraceCap;
 
-    R.noFoldedFinalize = tuning().noFoldedFinalize.load(std::memory_order_relaxed) != 0;
     R.haloOnSide = tuning().haloStream.load(std::memory_order_relaxed) != 0;
     int status = MGCG_ERROR;
     int checkEvery = 4;
@@ -827,9 +831,8 @@ double CgSteps(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     R.dcsr = dcsr_lookup(cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset, R.count, meanDistance);
     if (meanDistance >= (1LL << 19) && R.count >= (8LL << 19)) R.cfg.flags |= 16;
     R.cfg.flags |= 8;
-    R.noFoldedFinalize = tuning().noFoldedFinalize.load(std::memory_order_relaxed) != 0;
     R.haloOnSide = tuning().haloStream.load(std::memory_order_relaxed) != 0;
-    if (ok && restart) ok = cg_enqueue_init(R);
+    if (ok && restart) ok = cg_enqueue_init(R, true);
     else if (ok) hipLaunchKernelGGL(clear_done_kernel, dim3(1), dim3(1), 0, R.ws->stream, R.ws->scalars);
     const bool report = tuning().verbose.load(std::memory_order_relaxed) >= 2;      // MGCG_VERBOSE=2: is the host or the device the limit?
     const auto h0 = std::chrono::steady_clock::now();
@@ -990,7 +993,7 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
             if (ok) launch_uniform_check(s, L.dinv, L.n, dmm);
             ok = ok && MGCG_HIP(hipMemcpyAsync(&differs, dmm, sizeof(int), hipMemcpyDeviceToHost, s)) &&
                  MGCG_HIP(hipMemcpyAsync(&L.dinvScalar, L.dinv, sizeof(double), hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
-            L.dinvUniform = ok && differs == 0 && tuning().noUniformDiagonal.load(std::memory_order_relaxed) == 0;
+            L.dinvUniform = ok && differs == 0;
         }
         if (ok) L.dcsr = dcsr_lookup(cusparse, L.elements, L.rowOffsets, L.columnIndeces, L.n, L.nnz, L.offset);
         L.cfg = mg->cfg;

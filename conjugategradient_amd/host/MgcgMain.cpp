@@ -5,7 +5,9 @@
 // compared with each other here and tests/test_gpu_host_cpp.py compares the printed solution
 // checksum with the CPU oracle.
 //
-//   MgcgMain [COUNT] [MIN_ITERATION] [phases] [balance]      (defaults: 34567*6 and 200, the reference's constants)
+//   MgcgMain [COUNT] [MIN_ITERATION] [phases] [balance] [write=PREFIX]      (defaults: 34567*6 and 200, the reference's constants)
+// write=PREFIX: the three solutions as raw doubles in PREFIX.single.f64 / PREFIX.phases.f64 / PREFIX.parallel.f64, so that a test can do what
+// the reference's driver does with its CPU leg (:129-162): compare element by element.
 // The multi-device solver runs twice: on the reference's host-driven phases (Solve0..3, P2Host / P2Device) and on the native
 // loop (SolveParallel on every device's own thread, collectives on the device streams); which path produced the kept answer
 // is printed ("phases" as third argument keeps the phase structure for it).
@@ -29,7 +31,16 @@ int main(int argc, char** argv)
     const int MAX_ITERATION = COUNT;                                    // :30
     const double ALLOWABLE_RESIDUAL = 1e-8;                             // :35
     bool usePhasesOnly = false, balance = false;
+    std::string writePrefix;
+    auto writeX = [&](const char* which, const std::vector<double>& x) {
+        if (writePrefix.empty()) return;
+        const std::string path = writePrefix + "." + which + ".f64";
+        FILE* f = fopen(path.c_str(), "wb");
+        if (!f || fwrite(x.data(), sizeof(double), x.size(), f) != x.size()) { if (f) fclose(f); throw MgcgError("cannot write " + path); }
+        fclose(f);
+    };
     for (int i = 3; i < argc; i++) {
+        if (std::string(argv[i]).rfind("write=", 0) == 0) writePrefix = std::string(argv[i]).substr(6);
         if (std::string(argv[i]) == "phases") usePhasesOnly = true;           // keep the reference's phase structure for the kept answer too
         if (std::string(argv[i]) == "balance") balance = true;                // row ranges of equal nonzero count (BalanceNonzeros) instead of equal row count
     }
@@ -93,6 +104,7 @@ int main(int argc, char** argv)
         double maxRelPhases = 0;
         for (int i = 0; i < COUNT; i++) if (std::fabs(xPhases[(size_t)i]) > 0) maxRelPhases = std::max(maxRelPhases, std::fabs(xPhases[(size_t)i] - cgGpuParallel.x[(size_t)i]) / std::fabs(xPhases[(size_t)i]));
 
+        writeX("single", cgGpuSingle.x); writeX("phases", xPhases); writeX("parallel", cgGpuParallel.x);
         int mismatches = 0;
         double checksum = 0, maxRel = 0;
         for (int i = 0; i < COUNT; i++) {                               // :151-162 with the single-GPU result as the baseline

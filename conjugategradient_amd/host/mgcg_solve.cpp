@@ -3,6 +3,7 @@
 // runs CG or MGCG on one device or on R devices of this process and prints one JSON line.
 //   mgcg_solve [--nx N] [--ny N] [--nz N] [--mgcg] [--levels L] [--nu K] [--nu-coarse K] [--omega W] [--linear-transfer] [--tol T] [--rel-tol T]
 //              [--min-it I] [--max-it I] [--rule native|csharp|simple|viennacl|handmadecl] [--compression 0|1|2] [--b V] [--x0 V] [--ranks R]
+//              [--write-x FILE]     (the solution as raw little-endian doubles, for element-by-element comparison: MgcgMain.cs:129-162 compares so)
 // --ranks R > 1: the grid is split into R equal z-slabs, one per device of this process and one host thread per device (the shape of the
 // reference's ConjugateGradientParallelGpu), communicators from MgcgCommInitAll, SolveParallel / MgSetupParallel + SolveMgParallel per rank.
 #include <chrono>
@@ -34,7 +35,7 @@ int main(int argc, char** argv)
     int nx = 64, ny = 64, nz = 64, levels = 3, nu = 1, nuCoarse = 4, minIt = 0, maxIt = -1, compression = 1, ranks = 1;
     double omega = 0, tol = 1e-8, relTol = 0, bValue = 1.0, x0Value = 0.0;
     bool mgcg = false, linearTransfer = false;
-    std::string rule = "csharp";
+    std::string rule = "csharp", writeX;
     try {
         for (int i = 1; i < argc; ++i) {
             const std::string a = argv[i];
@@ -48,6 +49,7 @@ int main(int argc, char** argv)
             else if (a == "--min-it") minIt = std::atoi(val()); else if (a == "--max-it") maxIt = std::atoi(val());
             else if (a == "--rule") rule = val(); else if (a == "--compression") compression = std::atoi(val());
             else if (a == "--ranks") ranks = std::atoi(val());
+            else if (a == "--write-x") writeX = val();
             else if (a == "--b") bValue = std::atof(val()); else if (a == "--x0") x0Value = std::atof(val());
             else throw MgcgError("unknown flag " + a);
         }
@@ -119,6 +121,11 @@ int main(int argc, char** argv)
         });
         const double solveS = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         each([&](int, Rank& k) { k.x->CopyTo(hx.data() + k.offset, k.rows); });
+        if (!writeX.empty()) {
+            FILE* f = std::fopen(writeX.c_str(), "wb");
+            if (!f || std::fwrite(hx.data(), sizeof(double), hx.size(), f) != hx.size()) { if (f) std::fclose(f); throw MgcgError("cannot write " + writeX); }
+            std::fclose(f);
+        }
         int st = MGCG_OK; std::string err;
         for (int d = 0; d < ranks; ++d) if (R[(size_t)d].status != MGCG_OK) { st = R[(size_t)d].status; err = errors[(size_t)d]; break; }
         const int iteration = R[0].iteration; const double residual = R[0].residual;

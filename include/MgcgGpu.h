@@ -158,27 +158,43 @@ const char* MgcgGetLastError(void);
 void        MgcgClearLastError(void);
 /* Library ABI revision. */
 int         MgcgAbiVersion(void);
-/* Tuning knobs.  Every MGCG_* environment variable the library honours is read once, at first use; launches never read
- * the environment.  All knobs choose between schedules that give bit-identical results:
+/* Tuning knobs (14).  Every MGCG_* environment variable the library honours is read once, at first use; launches never read the
+ * environment.  No knob changes an element-wise result (SpMV rows, vector updates, the V-cycle: the same doubles under every
+ * setting).  What a SCHEDULE knob may change is how a dot product's partial sums are grouped: "overlap" reduces p.Ap from the
+ * interior rows' launch and the boundary rows' launch instead of one launch, so with the default overlap = 1 -- a decision taken
+ * from a timing -- two runs of a several-ranks solve on >= 1 M rows per rank can differ in the last bits of alpha / beta (1e-16
+ * relative; near the tolerance, by one iteration).  For reproducible bits set overlap to 0 or 2, or dot_order to 1 (which makes
+ * every sum independent of every schedule).  bench.py's N > 1 line names the schedule that ran.
  *   overlap (MGCG_OVERLAP: 0 halo exchange in line; 1 [default] hidden behind the interior rows where that pays BY MEASUREMENT -- for
- *   slices of >= 1 M rows per rank the plan's own exchange is timed in line against the fork / launch / join round trip of the overlap
- *   schedule on the live communicator, once per plan, and every rank takes the same decision from the all-reduced times; 2 whenever an
- *   interior exists), no_fold, fold_up (MGCG_FOLD_UP: -1 [default] the prolongation of a V(1,1) cycle is formed per gather of the
- *   post-smoothing sweep on levels of up to 100 M rows, 0 never, 1 on every level), no_folded_finalize, check_every (iterations
- *   enqueued ahead of the stop flag, default 4), vector_vals_nt, tile_pack, auto_tiles,
- *   no_uniform_diagonal, no_zsweep, rowtile_nt / vec_nt (-1 by size, 0 / 1 forced), vec_grid, r_grid, xp_grid,
- *   pattern_group, pattern_waves, no_indexed_halo, tile_nt, tile_shift, verbose, lazy_code_objects,
- *   virtual_devices (MGCG_VIRTUAL_DEVICES: one physical GPU shown as n devices, tests only),
+ *     slices of >= 1 M rows per rank the plan's own exchange is timed in line against the fork / launch / join round trip of the overlap
+ *     schedule on the live communicator, once per plan, and every rank takes the same decision from the all-reduced times; 2 whenever an
+ *     interior exists);
  *   halo_stream (overlap schedule: 0 [default] the interior rows run on the communicator's side stream and every RCCL call on the
- *   main stream; 1 the halo exchange runs on the side stream and all rows on the main stream -- 19 us less per iteration on one
- *   rank's slab, opt-in until RCCL on two streams of one communicator has been run on real multi-GPU hardware),
+ *     main stream; 1 the halo exchange runs on the side stream and all rows on the main stream -- opt-in until RCCL on two streams of
+ *     one communicator has been run on real multi-GPU hardware);
+ *   no_fold (MGCG_NO_FOLD: the first Jacobi sweep of a V(1,.) cycle is stored instead of being formed per gather of the residual pass);
+ *   fold_up (MGCG_FOLD_UP: -1 [default] the prolongation of a V(1,1) cycle is formed per gather of the post-smoothing sweep on levels of
+ *     up to 100 M rows, 0 never, 1 on every level);
+ *   check_every (iterations enqueued ahead of the stop flag, default 4);
+ *   auto_tiles (MGCG_AUTO_TILES, default 1: Solve-family and per-op calls build column tiles themselves for matrices without locality);
+ *   tile_shift (MGCG_TILE_SHIFT: column tiles of 2^shift columns; 0 [default] equal-width tiles of about 2.85 MiB of x),
+ *     tile_pack (MGCG_TILE_PACK, default 1: 12-byte tile entries; 0 the 16-byte form);
+ *   placement (MGCG_PLACEMENT, default 3: the first CG Solve-family call on vectors of >= 32 M entries times the loop's SpMV on that many
+ *     EXTRA allocations of Ap, keeps the fastest, and then does the same for p -- where the runtime places the two vectors moves the
+ *     SpMV by up to 17 %, the written one most; 0: off; a vector whose address ToRawPtr_Double has handed out is never moved; the
+ *     preconditioned loop draws only when maxIteration leaves room to win the draw's cost back);
+ *   dot_order (MGCG_DOT_ORDER, default 0; VALIDATION ONLY: 1 = every dot product adds its rounded products strictly left to right, the
+ *     ranks' sums are added in rank order and SpMV rows are always summed in stored order -- the reference CPU twin's arithmetic,
+ *     LongVector.cs:15-31, SparseMatrix.cs:68-88, resultsDot.Sum() -- so residual traces and iterates EQUAL the oracle's bit for bit at
+ *     every size and rank count; one serial sum of 1.3e8 terms takes ~0.5 s: never on a timed path);
+ *   verbose (MGCG_VERBOSE: errors and decisions also go to stderr);
+ *   virtual_devices (MGCG_VIRTUAL_DEVICES: one physical GPU shown as n devices, tests only);
  *   force_multirank (MGCG_FORCE_MULTIRANK = w > 0: a one-rank RCCL communicator takes the several-ranks code path with an
- *   artificial halo of w entries, for measuring that path's device-side cost on a one-GPU box),
- *   placement (MGCG_PLACEMENT, default 3: the first Solve-family call on vectors of >= 32 M entries times the loop's SpMV on that many
- *   EXTRA allocations of Ap, keeps the fastest, and then does the same for p -- where the runtime places the two vectors moves the
- *   SpMV by up to 17 %, the written one most; 0: off; a vector whose address ToRawPtr_Double has handed out is never moved),
+ *     artificial halo of w entries, for measuring that path's device-side cost on a one-GPU box);
  *   fail_comm_init (MGCG_FAIL_COMM_INIT, tests only: MgcgCommInitAll / MgcgCommInitRank report failure, as on a host whose RCCL
- *   cannot form a communicator -- callers must then fall back or fail loudly).
+ *     cannot form a communicator -- callers must then fall back or fail loudly).
+ * (MGCG_COMPRESSION and the MGCG_SPMV_* variables are per-handle defaults of MgcgSetMatrixCompression / MgcgSetSpmv*, read by
+ * CreateSparse.)  Knobs whose A/B was settled in rounds 2-4 have been removed with their settled value compiled in.
  * MgcgSetTuning / MgcgGetTuning take the knob's name or its environment variable; they return 0, or -1 for an unknown
  * name (MgcgGetLastError).  MgcgReloadEnvironment reads all variables again.  Change knobs only while no solve is running. */
 int         MgcgSetTuning(const char* name, int value);

@@ -55,14 +55,6 @@ def test_csrmv_vector_kernels(h, oracle, kernel):
         ref = oracle.spmv(system.Elements, system.ColumnIndeces, system.RowOffsets, x)
         y = DeviceCsr(system).spmv(h, x, kernel=kernel)
         np.testing.assert_allclose(y, ref, rtol=2e-13, atol=2e-13 * np.abs(ref).max())
-        # values read with the non-temporal hint (what the kernel does by itself when the column ids fit the Infinity Cache and the
-        # whole matrix does not): a load hint, the same bits
-        L = _lib.lib()
-        assert L.MgcgSetTuning(b"vector_vals_nt", 1) == 0
-        try:
-            assert np.array_equal(DeviceCsr(system).spmv(h, x, kernel=kernel), y)
-        finally:
-            L.MgcgSetTuning(b"vector_vals_nt", -1)
 
 
 @pytest.mark.parametrize("dims,rows,grid,period,tile", [

@@ -300,3 +300,14 @@ def test_placement_draw_moves_p_once_and_changes_no_bit(mgcg_env):
     assert cand0 == 0 and (o1, o2) == (r1, r2)                      # the draw off: the same bits
     e1, e2, cande, _, _, _, before, after = run(3, export_first=True)
     assert cande == 0 and before == after and (e1, e2) == (r1, r2)  # an exported address stays where it is
+    # Solve() draws only when the iteration cap leaves room to win the draw's price back (about a thousand iterations: solver.hip,
+    # kPlacementMinIterations): a call capped at 200 iterations does not, the same call capped at 10^6 does -- same bits either way
+    mgcg_env.setenv("MGCG_PLACEMENT", "3")
+    out = []
+    for cap in (200, 10**6):
+        cg = ConjugateGradientRankGpu(n**3, 7, 3, cap, 1e300, rank=0, world=1, rule=_lib.RULE_NATIVE)
+        cg.InitializePoisson(n, n, n)
+        cg.Solve()
+        out.append((L.MgcgLastPlacement(0, None, 0, None), cg.Iteration, cg.Residual))
+        cg.Dispose()
+    assert [o[0] for o in out] == [0, 4] and out[0][1:] == out[1][1:] and out[0][1] == 3
