@@ -96,6 +96,7 @@ struct MgcgComm {
     int nranks = 1, rank = 0;
     hipStream_t stream = nullptr;
     double* scratch = nullptr;       // device, 8 doubles
+    bool poisoned = false;           // host-staged transports: a local copy failed inside an exchange the peers had already entered -- the next all-reduce carries NaN
     double* gather = nullptr;        // device, nranks * 8 doubles (knob dot_order: the ranks' values side by side, added in rank order); allocated at first use
     // callback transport (host-staged; MgcgCommInitCallbacks)
     MgcgAllGatherFn cbAllGather = nullptr; MgcgAllReduceFn cbAllReduce = nullptr; MgcgExchangeFn cbExchange = nullptr; void* cbUser = nullptr;
@@ -139,6 +140,7 @@ bool comm_allreduce_sum(MgcgComm* c, double* devPtr, int count, hipStream_t s)
         if (count > 8) { set_error("callback all-reduce: at most 8 values"); return false; }
         double vals[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         bool ok = MGCG_HIP(hipMemcpyAsync(vals, devPtr, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
+        if (c->poisoned) { ok = false; c->poisoned = false; }
         if (!ok) for (int i = 0; i < count; ++i) vals[i] = NAN;
         std::vector<long long> all(4 * (size_t)c->nranks);
         double sum[8];
@@ -169,6 +171,7 @@ bool comm_allreduce_sum(MgcgComm* c, double* devPtr, int count, hipStream_t s)
         double mine[8];
         bool ok = MGCG_HIP(hipMemcpyAsync(mine, devPtr, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s));
         ok = ok && MGCG_HIP(hipStreamSynchronize(s));
+        if (c->poisoned) { ok = false; c->poisoned = false; }      // (an exchange before this sum failed locally: every rank must stop in THIS iteration)
         for (int i = 0; i < count; ++i) g->slots[(size_t)c->rank * 8 + i] = ok ? mine[i] : NAN;
         g->barrier();
         double sum[8];
@@ -182,6 +185,7 @@ bool comm_allreduce_sum(MgcgComm* c, double* devPtr, int count, hipStream_t s)
         if (count > 8) { set_error("callback all-reduce: at most 8 values"); return false; }
         double vals[8];
         bool ok = MGCG_HIP(hipMemcpyAsync(vals, devPtr, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
+        if (c->poisoned) { ok = false; c->poisoned = false; }
         if (!ok) for (int i = 0; i < count; ++i) vals[i] = NAN;     // the peers are inside the callback: join them, with a value that poisons the sum
         c->cbAllReduce(vals, count, c->cbUser);
         return MGCG_HIP(hipMemcpyAsync(devPtr, vals, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s)) && MGCG_HIP(hipStreamSynchronize(s)) && ok;
@@ -524,7 +528,10 @@ static bool halo_exchange_ranges(MgcgComm* c, HaloPlan* h, const double* src, do
         }
         ok = MGCG_HIP(hipStreamSynchronize(s)) && ok;
         g->barrier();
-        return ok;
+        // a local copy error: the peers have their halo and carry on -- this rank carries on WITH them and poisons the iteration's next
+        // all-reduce (comm_allreduce_sum), so that every rank stops in the same iteration instead of blocking in a collective this rank left
+        if (!ok) c->poisoned = true;
+        return true;
     }
     if (c->cbExchange) {
         const int n = h->nranks;
@@ -538,10 +545,13 @@ static bool halo_exchange_ranges(MgcgComm* c, HaloPlan* h, const double* src, do
         }
         ok = MGCG_HIP(hipStreamSynchronize(s)) && ok;
         c->cbExchange(n, sp.data(), h->sendCount.data(), rp.data(), h->recvCount.data(), c->cbUser);     // (also after a local copy error: the peers are waiting in it)
-        if (!ok) return false;
-        for (int q = 0; q < n; ++q)
+        for (int q = 0; ok && q < n; ++q)
             if (h->recvCount[q] > 0) ok = ok && MGCG_HIP(hipMemcpyAsync(dst + h->recvBegin[q], c->cbRecv[(size_t)q].data(), sizeof(double) * (size_t)h->recvCount[q], hipMemcpyHostToDevice, s));
-        return MGCG_HIP(hipStreamSynchronize(s)) && ok;
+        ok = MGCG_HIP(hipStreamSynchronize(s)) && ok;
+        // after a local copy error the peers hold garbage of this rank and carry on: stay with them, and let the iteration's next all-reduce
+        // carry NaN (comm_allreduce_sum), so that every rank stops in the same iteration
+        if (!ok) c->poisoned = true;
+        return true;
     }
     Rccl* r = rccl();
     if (!r) return false;
@@ -754,6 +764,12 @@ double MgcgCommProbe(MgcgComm* c, int what, int count, int reps)
     bool ok = MGCG_HIP(hipEventCreate(&e0)) && MGCG_HIP(hipEventCreate(&e1)) && MGCG_HIP(hipMalloc((void**)&buf, sizeof(double) * 4 * n)) &&
               MGCG_HIP(hipMemsetAsync(buf, 0, sizeof(double) * 4 * n, s));
     Rccl* r = (c->comm != nullptr) ? rccl() : nullptr;
+    if ((what == 1 || what == 4) && !r) {                          // host-staged transports: the planes travel through the launcher, nothing to time on the device
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (buf) (void)hipFree(buf);
+        return NAN;                                                // (not an error: no message is set)
+    }
     auto once = [&]() -> bool {
         switch (what) {
         case 0: return comm_allreduce_sum(c, buf, count > 8 ? 8 : (count < 1 ? 1 : count), s);

@@ -180,6 +180,7 @@ struct DcsrMatrix {
     unsigned* tilePacked = nullptr; int2* tileHdr = nullptr; int tileShift = 0, tileWidth = 0;
     std::vector<int> tileStart, tileHdrBase;
     unsigned long long checksum = 0;  // of the CSR arrays the analysis was made from (forms chosen without the caller asking are re-verified per solve)
+    int trustedUses = 0;              // per-op products served from this form since its checksum was last verified (dcsr_lookup_op: re-verified every 16th)
     bool automatic = false;           // built by the library's own choice (column tiles for a matrix without locality), not by MgcgSetMatrixCompression
     bool usable = false;
     std::atomic<bool> stale{false};   // a write through the library touched the arrays the analysis was made from: analyse again at the next use
@@ -338,8 +339,10 @@ const DcsrMatrix* dcsr_lookup(MgcgSparse* h, const double* elements, const int* 
 // Per-op calls (CsrMV, CsrMVDot, Solve0, Solve1: the reference's own phase driver multiplies through these, Mgcg.cu:10-19,116-163): the form
 // the caller asked for (MgcgSetMatrixCompression), or -- compression off -- the library's own column tiles for a matrix without locality
 // once it has been multiplied a few times through this handle, provided the three arrays are library-owned vectors (Create_*): writes
-// through any export mark the form stale (analysis_note_write), so it is trusted without the per-solve checksum.  Writes by the caller's
-// own kernels through ToRawPtr_* pointers are outside the library's view (MgcgAnalysisClear / MGCG_AUTO_TILES=0 are for those).
+// through any export mark the form stale (analysis_note_write), so it is trusted without a checksum per call.  Writes by the caller's
+// own kernels through ToRawPtr_* pointers are outside the library's view: every 16th product served from the form re-verifies the 64-bit
+// checksum of the CSR arrays (0.8 ms per 310 M nonzeros: 2 % of the 16 products), so such a write is noticed within 16 products at the
+// latest; a caller that rewrites matrices that way says so with MgcgAnalysisClear, or switches the feature off (MGCG_AUTO_TILES=0).
 const DcsrMatrix* dcsr_lookup_op(MgcgSparse* h, const SpmvArgs& a, long long rowBase);
 bool vector_owned(const void* p, size_t bytes);   // [p, p + bytes) lies inside a device vector the library allocated
 void vector_registry_add(const void* p, size_t bytes);

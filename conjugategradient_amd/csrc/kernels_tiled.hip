@@ -352,7 +352,7 @@ bool tiled_build(hipStream_t s, const double* elements, const int* rowOffsets, c
 {
     // Width of a tile's x window.  Round 3 used 2^19 columns = 4 MiB, the whole of an XCD's 4 MiB L2: the y lines and the entry streams of a
     // pass then push window lines out again and every XCD fetches its window about nine times per pass (PMC, tools/tile_width_sweep.sh,
-    // profiles/r4/tile_width_pmc.json: 0.55 GB of L2-miss reads per pass where entries + y + window need 0.27; 12.6 GB per product = 1.8 x the
+    // profiles/r4/tile_width/pmc_T20_T32_T40.json, pmc_T24_T27.json: 0.55 GB of L2-miss reads per pass where entries + y + window need 0.27; 12.6 GB per product = 1.8 x the
     // form's own bytes).  At 2.85 MiB the re-fetches all but vanish (9.7 GB per product = 1.2 x its own bytes, 27 passes instead of 20 on the
     // 10 M-column matrix) for the same time per product (2.68 against 2.66 ms: each pass costs its y sweep, ~21 us, whatever its width); below
     // that the additional passes cost more than the misses (2.77 / 2.95 / 3.36 ms at 2.4 / 1.9 / 1.4 MiB).  MGCG_TILE_SHIFT = s asks for 2^s columns.

@@ -204,8 +204,16 @@ const DcsrMatrix* dcsr_lookup_op(MgcgSparse* h, const SpmvArgs& a, long long row
     // a form that exists and has seen no write since: use it
     for (DcsrMatrix* q : h->analysed)
         if (q->automatic && q->elements == a.elements && q->rowOffsets == a.rowOffsets && q->columnIndeces == a.columnIndeces && q->rows == a.rowCount &&
-            q->nnz == a.elementsCount && q->rowBase == rowBase && !q->stale.load(std::memory_order_acquire))
-            return q->usable ? q : nullptr;
+            q->nnz == a.elementsCount && q->rowBase == rowBase && !q->stale.load(std::memory_order_acquire)) {
+            if (!q->usable) return nullptr;
+            if (++q->trustedUses < 16) return q;
+            // every 16th product: is the form still the matrix?  (writes through ToRawPtr_* pointers by the caller's own kernels or copies
+            // are invisible to the write registry)
+            q->trustedUses = 0;
+            if (csr_checksum(h->ws.stream, a.elements, a.rowOffsets, a.columnIndeces, a.rowCount, a.elementsCount, (unsigned long long*)(h->ws.devInts + 4)) == q->checksum) return q;
+            q->stale.store(true, std::memory_order_release);
+            break;                                     // changed behind the library's back: the CSR kernels now, a rebuild after `threshold` products
+        }
     // none, or written to since: the CSR kernels serve the next `threshold` products, then the tiles are (re)built -- a matrix that is rewritten
     // between its products pays for ever fewer builds (the threshold doubles with every rebuild)
     if (++pe->products < pe->threshold) return nullptr;
@@ -435,7 +443,7 @@ extern "C" {
 
 const char* MgcgGetLastError(void) { return mgcg::t_lastError.c_str(); }
 void MgcgClearLastError(void) { mgcg::t_lastError.clear(); }
-int MgcgAbiVersion(void) { return 2; }
+int MgcgAbiVersion(void) { return 3; }   // 3: round 5 -- dot_order, 14 knobs retired, Vector / DcsrMatrix grew
 
 void MgcgReloadEnvironment(void) { mgcg::tuning_reload(); }
 int MgcgSetTuning(const char* name, int value)

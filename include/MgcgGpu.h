@@ -156,7 +156,7 @@ void Solve(MgcgBlas* cublas, MgcgSparse* cusparse, MgcgMatDescr* matDescr,
 /* Thread-local message of the last failed call ("" if none); cleared by MgcgClearLastError. */
 const char* MgcgGetLastError(void);
 void        MgcgClearLastError(void);
-/* Library ABI revision. */
+/* Library ABI revision (3 since round 5: exports added, Vector grew, 14 tuning knobs retired, dot_order added). */
 int         MgcgAbiVersion(void);
 /* Tuning knobs (14).  Every MGCG_* environment variable the library honours is read once, at first use; launches never read the
  * environment.  No knob changes an element-wise result (SpMV rows, vector updates, the V-cycle: the same doubles under every
@@ -367,8 +367,9 @@ const char* MgcgCommTransport(const MgcgComm* comm);
  *   what = 2  fork / join pairs of the overlap schedule (event record + stream wait on the side stream and back),
  *   what = 3  empty single-workgroup kernel launches (the price of a kernel boundary on this stream),
  *   what = 4  the stencil's halo exchange: one grouped send/recv of `count` doubles with ranks rank - 1 and rank + 1 only,
- * timed with HIP events around the batch; returns microseconds per repetition (NaN on error).  Collective: every rank
- * of the communicator must make the same call. */
+ * timed with HIP events around the batch; returns microseconds per repetition (NaN on error -- and, without an error message, for
+ * what = 1 / 4 on a transport without RCCL: host-staged planes travel through the launcher, there is nothing to time on the device).
+ * Collective: every rank of the communicator must make the same call. */
 double    MgcgCommProbe(MgcgComm* comm, int what, int count, int reps);
 int       MgcgCommRank(const MgcgComm* comm);
 int       MgcgCommSize(const MgcgComm* comm);

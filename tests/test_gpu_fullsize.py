@@ -417,6 +417,21 @@ def test_config5_at_full_size(oracle):
     for k in range(16):                                                    # (the threshold doubles with every rebuild: 16 products this time)
         L.CsrMV(*args(dx))
     assert np.array_equal(dy.to_numpy(), ref)
+    # a write BEHIND the library's back -- hipMemcpy on the raw pointer of the values, what a caller's own kernel would do through
+    # ToRawPtr_Double: no export sees it, but every 16th product served from the form re-verifies the checksum of the CSR arrays
+    # (runtime.hip: dcsr_lookup_op), so within 16 products the stale form is dropped and the products are those of the matrix in memory
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    e0 = C.c_double(3.0 * float(s.Elements[0]))
+    assert hip.hipMemcpy(cg.vectorA.ToRawPtr(), C.byref(e0), 8, 1) == 0        # elements[0] *= 3 (host to device)
+    want0 = ref[0] + 2.0 * float(s.Elements[0]) * xs[int(s.ColumnIndeces[0])]
+    seen = None
+    for k in range(17):
+        L.CsrMV(*args(dx))
+        if abs(dy.to_numpy(1)[0] - want0) <= 1e-12 * abs(want0):
+            seen = k
+            break
+    assert seen is not None and seen <= 16, seen
     for v in (dx, dy):
         v.Dispose()
     cg.Dispose()

@@ -274,6 +274,8 @@ def test_comm_probe_prices_the_steps_of_the_several_ranks_path():
     one = (C.c_void_p * 1)()
     assert L.MgcgCommInitAll(one, 1) == 0
     assert np.isfinite(L.MgcgCommProbe(one[0], 3, 0, 10))
+    # a transport without RCCL has no exchange to time on the device: NaN (reported as null by bench.py), never a near-zero figure, and no error
+    assert np.isnan(L.MgcgCommProbe(one[0], 4, 4096, 10)) and np.isnan(L.MgcgCommProbe(one[0], 1, 4096, 10)) and _lib.last_error() == ""
     L.MgcgCommDestroy(one[0])
 
 
