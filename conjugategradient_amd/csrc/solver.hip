@@ -513,11 +513,20 @@ static bool cg_enqueue_init(CgRun& R, bool fixedSteps = false)
 {
     hipStream_t s = R.ws->stream;
     long long meanDistance = 0;
+    // MGCG_VERBOSE=2: what a solve pays before its first iteration is enqueued (the reference's driver times a cold Solve(): MgcgMain.cs:121-126)
+    const bool report = tuning().verbose.load(std::memory_order_relaxed) >= 2;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
     if (R.cusparse && R.elementsCount >= 8) R.cfg.periodRows = spmv_period(R.cusparse, R.rowOffsets, R.columnIndeces, R.nLocal, R.offset, &R.cfg.maxRow, &meanDistance);
+    const double usShape = since(t0);
+    const auto t1 = std::chrono::steady_clock::now();
     if (R.cusparse) R.dcsr = dcsr_lookup(R.cusparse, R.elements, R.rowOffsets, R.columnIndeces, R.nLocal, R.elementsCount, R.offset, R.count, R.mg ? -1 : meanDistance);
+    const double usForm = since(t1);
     if (meanDistance >= (1LL << 19) && R.count >= (8LL << 19)) R.cfg.flags |= 16;      // gathers without locality: the stream form among the CSR kernels
     if (!R.mg) R.cfg.flags |= 8;                 // plain CG loop: the row-tile kernel may read the matrix with the non-temporal hint (kernels_rowtile.hip)
+    const auto t2 = std::chrono::steady_clock::now();
     placement_draw(R, fixedSteps);               // (before p is touched: may move p's data once per vector)
+    if (report) fprintf(stderr, "[MgcgGpu] solve set-up: matrix shape %.0f us, matrix form %.0f us, placement draw %.0f us\n", usShape, usForm, since(t2));
     CgScalars* sc = R.ws->scalars;
     double* pLoc = R.p + R.offset;
     if (R.rule == MGCG_RULE_SIMPLE) launch_fill(s, R.x, 0.0, R.nLocal);             // SimpleConjugateGradient.cu:53
@@ -672,7 +681,15 @@ static int cg_solve(CgRun& R, int* iteration, double* residual, double* residual
     volatile int* slots = (volatile int*)&R.ws->hostScalar[2];   // two ints per double: slots[0..3]
     bool ok = MGCG_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming)) && MGCG_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
     for (int i = 0; i < 4; ++i) slots[i] = 0;
+    const bool report = tuning().verbose.load(std::memory_order_relaxed) >= 2;
+    const auto hostT0 = std::chrono::steady_clock::now();
     ok = ok && cg_enqueue_init(R);
+    if (report) {
+        const double enq = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hostT0).count();
+        (void)hipStreamSynchronize(s);
+        fprintf(stderr, "[MgcgGpu] solve: initial phase enqueued after %.0f us, finished on the device after %.0f us\n", enq,
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hostT0).count());
+    }
     long long enqueued = 0;
     int chunk = 0;
     bool finished = false;
@@ -693,6 +710,8 @@ static int cg_solve(CgRun& R, int* iteration, double* residual, double* residual
         ++chunk;
     }
     ok = MGCG_HIP(hipStreamSynchronize(s)) && ok;
+    if (report) fprintf(stderr, "[MgcgGpu] solve: %lld iterations enqueued, loop drained %.0f us after the call began\n", enqueued,
+                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hostT0).count());
     if (ok) {
         status = m->status;
         if (iteration) *iteration = m->iteration;
