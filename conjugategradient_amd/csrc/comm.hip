@@ -294,6 +294,33 @@ static bool exchange_host(MgcgComm* c, const std::vector<std::vector<double>>& s
 static bool halo_plan_index(MgcgComm* c, HaloPlan* h, const std::vector<long long>& all, long long count, long long offset, long long countLocal,
                             const int* columnIndeces, long long nnz);
 
+// Set-up exchange with the two neighbours in rank order (collective: every rank calls, the end ranks with nothing for the side they lack):
+// toLower goes to rank - 1 (and arrives there as fromUpper), toUpper to rank + 1.  Sizes travel first, then the payloads; a local failure
+// is carried through both rounds so that no rank leaves early.
+bool comm_neighbour_exchange_host(MgcgComm* c, const std::vector<double>& toLower, const std::vector<double>& toUpper,
+                                  std::vector<double>& fromLower, std::vector<double>& fromUpper, bool localOk)
+{
+    fromLower.clear(); fromUpper.clear();
+    if (!c || c->nranks <= 1) return localOk;
+    const int n = c->nranks, lo = c->rank - 1, hi = c->rank + 1;
+    std::vector<std::vector<double>> send((size_t)n), recv((size_t)n);
+    // round 1: sizes (-1: this rank has failed; its neighbours then fail with it)
+    if (lo >= 0) { send[(size_t)lo] = { localOk ? (double)toLower.size() : -1.0 }; recv[(size_t)lo].assign(1, 0.0); }
+    if (hi < n)  { send[(size_t)hi] = { localOk ? (double)toUpper.size() : -1.0 }; recv[(size_t)hi].assign(1, 0.0); }
+    bool ok = exchange_host(c, send, recv) && localOk;
+    long long nLo = lo >= 0 ? (long long)recv[(size_t)lo][0] : 0, nHi = hi < n ? (long long)recv[(size_t)hi][0] : 0;
+    if (nLo < 0 || nHi < 0) { if (ok) set_error("a neighbouring rank failed while the halo rows of a multigrid level were being exchanged"); ok = false; nLo = nLo < 0 ? 0 : nLo; nHi = nHi < 0 ? 0 : nHi; }
+    // round 2: payloads (a failed rank sends what it announced: nothing)
+    for (auto& v : send) v.clear();
+    for (auto& v : recv) v.clear();
+    if (lo >= 0) { if (localOk) send[(size_t)lo] = toLower; recv[(size_t)lo].assign((size_t)nLo, 0.0); }
+    if (hi < n)  { if (localOk) send[(size_t)hi] = toUpper; recv[(size_t)hi].assign((size_t)nHi, 0.0); }
+    ok = exchange_host(c, send, recv) && ok;
+    if (lo >= 0) fromLower.swap(recv[(size_t)lo]);
+    if (hi < n) fromUpper.swap(recv[(size_t)hi]);
+    return ok;
+}
+
 // Agreement on a local precondition among the ranks of a communicator (one all-reduce of a flag): false on EVERY rank when any rank
 // says false, so that no rank walks into the collectives of a call that another rank has already left.
 bool comm_agree(MgcgComm* c, bool localOk, const char* who)

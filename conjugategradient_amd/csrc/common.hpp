@@ -57,6 +57,8 @@ struct Tuning {
                                              //                         opt-in until RCCL on two streams of one communicator has run on real multi-GPU hardware)
     std::atomic<int> forceMultiRank{0};      // MGCG_FORCE_MULTIRANK    a one-rank communicator takes the several-ranks code path (measurement)
     std::atomic<int> placement{3};           // MGCG_PLACEMENT          Solve-family calls on >= 32 M-entry p: time the SpMV on this many EXTRA allocations of p and keep the fastest (0: off)
+    std::atomic<int> deepHalo{1};            // MGCG_DEEP_HALO          row-partitioned V(1,1): one exchange of a few planes of the right-hand side per coarse level and the sweeps
+                                             //                         recomputed on those planes (4 exchanges per MGCG iteration), 0: one exchange per sweep (8)
     std::atomic<int> dotOrder{0};            // MGCG_DOT_ORDER          validation only: 1 = every dot product adds its rounded products strictly left to right and the ranks'
                                              //                         sums in rank order, as the reference's CPU twin does (LongVector.cs:15-31, resultsDot.Sum()) -- traces and
                                              //                         iterates then EQUAL the oracle's; ~0.5 s per 1.3e8-entry dot, never on a timed path
@@ -445,7 +447,10 @@ HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long 
                            const int* columnIndeces = nullptr, long long nnz = 0, bool reuse = false, bool localOk = true);
 // localOk (reuse plans only, several ranks): this rank's verdict on its own arguments, folded into the plan's one all-reduce -- when any
 // rank says false, every rank gets nullptr and nobody enters the solve's collectives.
-bool comm_agree(MgcgComm* c, bool localOk, const char* who);   // the same agreement as a call of its own (set-up paths)
+bool comm_agree(MgcgComm* c, bool localOk, const char* who);
+// set-up only (collective): host vectors to and from ranks rank - 1 and rank + 1
+bool comm_neighbour_exchange_host(MgcgComm* c, const std::vector<double>& toLower, const std::vector<double>& toUpper,
+                                  std::vector<double>& fromLower, std::vector<double>& fromUpper, bool localOk = true);   // the same agreement as a call of its own (set-up paths)
 void halo_last(long long out[3]);   // calling thread's last exchange: {index lists used, entries received, entries the contiguous plan receives}
 void halo_plan_destroy(HaloPlan* h);
 bool halo_exchange(MgcgComm* c, HaloPlan* h, double* p, hipStream_t s);

@@ -36,6 +36,7 @@ const Knob kKnobs[] = {
     { "MGCG_FORCE_MULTIRANK", "force_multirank", &Tuning::forceMultiRank, 0, false },
     { "MGCG_FAIL_COMM_INIT", "fail_comm_init", &Tuning::failCommInit, 0, false },
     { "MGCG_DOT_ORDER", "dot_order", &Tuning::dotOrder, 0, false },
+    { "MGCG_DEEP_HALO", "deep_halo", &Tuning::deepHalo, 1, false },
     { "MGCG_PLACEMENT", "placement", &Tuning::placement, 3, false },
 };
 Tuning g_tuning;

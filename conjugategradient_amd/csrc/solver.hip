@@ -35,6 +35,15 @@ struct MgLevel {
     int minJ = 0, maxJ = -1;
     bool overlap = false;                  // interior rows [interior0, interior1) are multiplied while the halo travels
     long long interior0 = 0, interior1 = 0;
+    // Deep-halo cycle (several ranks, levels >= 1; mg_deep_level below): the right-hand side lives in a FULL-length buffer whose `deep`
+    // planes either side of the slab arrive in ONE exchange per cycle (bHalo), and the level's matrix rows, right-hand side and D^-1 for
+    // those planes are here too (copied from the neighbours at set-up), so that the sweeps can be recomputed on them instead of exchanged.
+    int deep = 0;                          // planes either side (0: the level takes one exchange per sweep)
+    int extZ0 = 0, extZ1 = 0;              // planes [extZ0, extZ1) of the extended slab (clipped to the grid)
+    double* bFull = nullptr;               // b = bFull + offset
+    HaloPlan* bHalo = nullptr;
+    double* extElements = nullptr; int* extRowOffsets = nullptr; int* extColumnIndeces = nullptr; double* extDinv = nullptr;
+    long long extRows = 0, extNnz = 0, extBase = 0;   // rows of the extended slab, its nonzeros, global index of its first row
 };
 
 } // namespace mgcg
@@ -57,6 +66,8 @@ struct MgcgMg {
     // halo of the final iterate) instead of into a full-length buffer that is then copied out
     double* finalOut = nullptr;
     bool finalWritten = false;
+    bool deep = false;                     // every level >= 1 has its deep halo (decided at set-up, the same on every rank)
+    bool skipHalo = false;                 // the next SpMV-shaped pass finds its halo planes already in place (deep-halo cycle: formed locally)
 };
 
 namespace mgcg {
@@ -114,7 +125,7 @@ static bool plan_overlap(hipStream_t s, MgcgComm* comm, bool multi, const int* r
 
 static bool mg_halo(MgcgMg* mg, MgLevel& L, double* xfull)
 {
-    if (!mg->multi) return true;
+    if (!mg->multi || mg->skipHalo) return true;
     return halo_exchange(mg->comm, L.halo, xfull, mg->stream);
 }
 
@@ -129,7 +140,7 @@ static bool mg_spmv2(MgcgMg* mg, MgLevel& L, int epilogue, const SpmvArgs& aInt,
     int n = 0;
     if (nPartials) *nPartials = 0;
     const int half = partials ? kMaxPartials / 2 : 0;
-    if (!L.overlap) {
+    if (!L.overlap || mg->skipHalo) {                  // (nothing travels: nothing to hide)
         if (!mg_halo(mg, L, xfull)) return false;
         if (splitInLine) {                           // two kinds of rows, one stream: interior rows with aInt, the rows either side with aBnd
             n = launch_spmv_range(s, epilogue, aInt, L.cfg, L.dcsr, L.interior0, L.interior1, partials, half);
@@ -227,6 +238,75 @@ static bool mg_smooth(MgcgMg* mg, MgLevel& L, const double* b, double* cur, doub
     return true;
 }
 
+// ---------------------------------------------------------------- deep-halo cycle (several ranks, V(1,1), piecewise-constant transfer)
+// The per-sweep schedule above exchanges a halo plane before EVERY SpMV-shaped pass: on 3 levels with 4 coarse sweeps that is seven exchanges
+// per cycle (two on the finest level, two on the middle one, three on the coarsest), each a latency-bound grouped send/recv -- where the
+// reference's loop has ONE exchange per iteration (SyncP, ConjugateGradientParallelGpu.cs:384-419,469).  Here every level >= 1 takes ONE
+// exchange per cycle: `deep` planes of its RIGHT-HAND SIDE either side of the slab, after which everything the level computes within reach
+// of its boundaries is recomputed locally on those planes -- the same operations on the same values in the same order, so every entry is the
+// bit the owning rank computes (tests: z = M^-1 r equal to the single-domain oracle bit for bit).  Counting planes of the level:
+//   coarsest level, nu_c sweeps, result wanted one plane beyond the slab (the finer level prolongs it onto ITS halo planes):
+//     x_1 = omega D^-1 b on +-nu_c planes, sweep k on +-(nu_c + 1 - k), x_{nu_c} on +-1          -> deep = nu_c
+//   a middle level: x_1 = omega D^-1 b on +-2, residual on the slab, y = x_1 + P e on +-2 (e from below on +-1 of ITS planes = +-2 of these),
+//     post-smoothing sweep on +-1                                                              -> deep = 2
+//   the finest level keeps its one exchange of x_1 before the residual pass (its right-hand side is the caller's local vector); its
+//     post-smoothing sweep finds x_1 in the halo planes from that exchange and adds P e there itself   -> no second exchange.
+// Per MGCG iteration: SyncP of p + 3 exchanges in the cycle instead of SyncP + 7.  The redundant rows are deep planes on slabs of 32 / 16
+// planes of levels that hold 1/8 and 1/64 of the work.
+static bool mg_deep_level(MgcgMg* mg, int l, const int* done, double** result)
+{
+    MgLevel& L = mg->lv[l];
+    hipStream_t s = mg->stream;
+    const long long plane = (long long)L.nx * L.ny;
+    const bool coarsest = l == mg->levels - 1;
+    auto zlo = [&](int d) { const int z = L.z0 - d; return z < L.extZ0 ? L.extZ0 : z; };
+    auto zhi = [&](int d) { const int z = L.z1 + d; return z > L.extZ1 ? L.extZ1 : z; };
+    // rows of planes [za, zb) of the extended slab
+    auto first = [&](int d, double* x) {            // x = omega D^-1 b on +-d planes
+        const long long r0 = (long long)zlo(d) * plane, r1 = (long long)zhi(d) * plane;
+        launch_jacobi_first(s, r1 - r0, mg->omega, L.extDinv + (r0 - L.extBase), 0, 0.0, L.bFull + r0, x + r0, done);
+    };
+    auto sweep = [&](int d, double* xin, double* xout) {   // xout = xin + omega D^-1 (b - A xin) on +-d planes
+        const long long r0 = (long long)zlo(d) * plane - L.extBase, r1 = (long long)zhi(d) * plane - L.extBase;
+        SpmvArgs a{};
+        a.elements = L.extElements; a.rowOffsets = L.extRowOffsets; a.columnIndeces = L.extColumnIndeces; a.x = xin; a.y = xout + L.extBase;
+        a.elementsCount = (int)L.extNnz; a.rowCount = (int)L.extRows; a.columnCount = (int)L.nGlobal;
+        a.w = xin + L.extBase; a.b = L.bFull + L.extBase; a.dinv = L.extDinv; a.dinvUniform = 0; a.omega = mg->omega; a.doneFlag = done;
+        (void)launch_spmv_range(s, EPI_JACOBI, a, L.cfg, nullptr, r0, r1, nullptr, 0);
+    };
+    if (!halo_exchange(mg->comm, L.bHalo, L.bFull, s)) return false;                  // the level's ONE exchange
+    if (coarsest) {
+        double* cur = L.xa; double* other = L.xb;
+        first(mg->nuCoarse, cur);
+        for (int k = 2; k <= mg->nuCoarse; ++k) { sweep(mg->nuCoarse + 1 - k, cur, other); double* t = cur; cur = other; other = t; }
+        *result = cur;                                                               // valid on the slab and one plane either side
+        return true;
+    }
+    MgLevel& C = mg->lv[l + 1];
+    first(2, L.xa);
+    SpmvArgs a{};                                                                    // r = b - A x_1 on the slab (the level's own matrix)
+    a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = L.xa; a.y = L.r;
+    a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal; a.b = L.b; a.doneFlag = done;
+    (void)launch_spmv_auto(s, EPI_RESIDUAL, a, L.cfg, L.dcsr);
+    launch_restrict(s, L.nx, L.ny, L.z1 - L.z0, L.r, C.b, done);                      // b_c = P^T r (slab-local)
+    double* e = nullptr;
+    if (!mg_deep_level(mg, l + 1, done, &e)) return false;
+    const int za = zlo(2), zb = zhi(2);                                              // (even planes: the slab is aligned and 2 is even)
+    launch_prolong_add(s, L.nx, L.ny, zb - za, L.xa + (long long)za * plane, e + (long long)(za / 2) * C.nx * C.ny, done);   // y = x_1 + P e on +-2
+    sweep(1, L.xa, L.xb);
+    *result = L.xb;                                                                  // valid on the slab and one plane either side
+    return true;
+}
+
+// the finest level's halo planes of `cur` hold x_1 (from the exchange before the residual pass): add P e there, so that the post-smoothing
+// sweep needs no exchange.  e: the coarse result, valid one coarse plane beyond the slab.
+static void mg_deep_prolong_halo(MgcgMg* mg, MgLevel& L, MgLevel& C, double* cur, const double* e, const int* done)
+{
+    const long long plane = (long long)L.nx * L.ny, cplane = (long long)C.nx * C.ny;
+    if (L.z0 > 0) launch_prolong_add(mg->stream, L.nx, L.ny, 1, cur + (long long)(L.z0 - 1) * plane, e + (long long)((L.z0 - 1) / 2) * cplane, done);
+    if (L.z1 < L.nz) launch_prolong_add(mg->stream, L.nx, L.ny, 1, cur + (long long)L.z1 * plane, e + (long long)(L.z1 / 2) * cplane, done);
+}
+
 // One V(nu,nu) cycle on level l for right-hand side b (local); x0/x1 are that level's two full-length iterate
 // buffers.  *result receives the buffer that holds the answer.  Mirrors vcycle() of oracle/mg_oracle.c.
 static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1, const int* done, double** result)
@@ -286,7 +366,12 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
         launch_restrict(mg->stream, L.nx, L.ny, L.z1 - L.z0, L.r, C.b, done);                 // b_c = P^T r (slab-local)
     }
     double* e = nullptr;
-    if (!mg_vcycle(mg, l + 1, C.b, C.xa, C.xb, done, &e)) return false;
+    const bool deep = mg->deep && !linear && l == 0;                                      // (levels >= 1 of a deep-halo cycle never come through here)
+    if (deep) { if (!mg_deep_level(mg, 1, done, &e)) return false; t_lastFolds |= 4; }
+    else if (!mg_vcycle(mg, l + 1, C.b, C.xa, C.xb, done, &e)) return false;
+    // deep-halo cycle: the post-smoothing sweep's halo planes are formed here (x_1 is in them since the residual pass's exchange, P e is
+    // added by mg_deep_prolong_halo), so the sweep itself exchanges nothing
+    struct SkipHalo { MgcgMg* m; bool on; ~SkipHalo() { if (on) m->skipHalo = false; } } skip{ mg, deep };
     if (linear) {
         if (mg->multi && !halo_exchange(mg->comm, C.transferHalo, e, mg->stream)) return false;
         launch_prolong_linear_add(mg->stream, L.nx, L.ny, L.nz, L.z0, L.z1, cur + L.offset, e, done);               // x += P e
@@ -320,6 +405,7 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
                                       e + C.offset + (hiStart / 2) * coarsePlane, done);
             }
         }
+        if (deep) { mg_deep_prolong_halo(mg, L, C, cur, e, done); mg->skipHalo = true; }
         if (!mg_jacobi(mg, L, b, cur, other, done, l == 0, e, true)) return false;
         t_lastFolds |= 2;
         *result = other;
@@ -327,6 +413,7 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
     }
     else if (fold || foldInterior) launch_prolong_scaled(mg->stream, L.nx, L.ny, L.z1 - L.z0, cur + L.offset, b, L.dinvScalar, mg->omega, e + C.offset, done);
     else launch_prolong_add(mg->stream, L.nx, L.ny, L.z1 - L.z0, cur + L.offset, e + C.offset, done);   // x += P e (slab-local)
+    if (deep) { mg_deep_prolong_halo(mg, L, C, cur, e, done); mg->skipHalo = true; }
     return mg_smooth(mg, L, b, cur, other, mg->nu, false, done, result, l == 0);
 }
 
@@ -1034,6 +1121,99 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     ok = ok && MGCG_HIP(hipStreamSynchronize(s));
     if (dErr) (void)hipFree(dErr);
     if (dmm) (void)hipFree(dmm);
+    // Deep-halo cycle (mg_deep_level): every level >= 1 gets a full-length right-hand side, the plan that brings `deep` planes of it from
+    // the neighbours, and the neighbours' matrix rows for those planes.  Taken when every such level's slab is at least `deep` planes thick
+    // (then only the two adjacent ranks are involved); the slabs are equal, so every rank decides the same.  Collective from here on: a
+    // local failure is agreed on (comm_agree) before any rank walks into the exchanges.
+    bool wantDeep = ok && multi && nu == 1 && mg->levels >= 2 && tuning().deepHalo.load(std::memory_order_relaxed) != 0;
+    for (int l = 1; wantDeep && l < mg->levels; ++l) {
+        const MgLevel& L = mg->lv[(size_t)l];
+        const int d = (l == mg->levels - 1) ? nuCoarse : 2;
+        if (L.nz <= 1 || (L.z1 - L.z0) < d || (L.z0 & 1) || ((L.z1 - L.z0) & 1)) wantDeep = false;
+    }
+    if (multi && !comm_agree(comm, ok, "MgSetup")) { MgDestroy(mg); return nullptr; }
+    for (int l = 1; ok && wantDeep && l < mg->levels; ++l) {
+        MgLevel& L = mg->lv[(size_t)l];
+        const long long plane = (long long)L.nx * L.ny;
+        const int d = (l == mg->levels - 1) ? nuCoarse : 2;
+        L.deep = d;
+        L.extZ0 = L.z0 - d < 0 ? 0 : L.z0 - d;
+        L.extZ1 = L.z1 + d > L.nz ? L.nz : L.z1 + d;
+        L.extBase = (long long)L.extZ0 * plane; L.extRows = (long long)(L.extZ1 - L.extZ0) * plane;
+        const long long edge = (long long)d * plane;                                  // rows of d planes
+        // my first / last d planes, packed: { rows, nnz, row lengths, values, column ids }
+        std::vector<int> ro((size_t)L.n + 1);
+        bool lok = MGCG_HIP(hipMemcpyAsync(ro.data(), L.rowOffsets, sizeof(int) * (size_t)(L.n + 1), hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
+        auto pack = [&](long long r0, long long r1, std::vector<double>& out) {
+            out.clear();
+            if (!lok || r1 <= r0) return;
+            const long long k0 = ro[(size_t)r0], k1 = ro[(size_t)r1], K = k1 - k0, Rn = r1 - r0;
+            std::vector<double> v((size_t)K); std::vector<int> c((size_t)K);
+            lok = lok && (K == 0 || (MGCG_HIP(hipMemcpyAsync(v.data(), L.elements + k0, sizeof(double) * (size_t)K, hipMemcpyDeviceToHost, s)) &&
+                                     MGCG_HIP(hipMemcpyAsync(c.data(), L.columnIndeces + k0, sizeof(int) * (size_t)K, hipMemcpyDeviceToHost, s)))) && MGCG_HIP(hipStreamSynchronize(s));
+            out.reserve((size_t)(2 + Rn + 2 * K));
+            out.push_back((double)Rn); out.push_back((double)K);
+            for (long long i = r0; i < r1; ++i) out.push_back((double)(ro[(size_t)i + 1] - ro[(size_t)i]));
+            out.insert(out.end(), v.begin(), v.end());
+            for (int j : c) out.push_back((double)j);
+        };
+        std::vector<double> toLower, toUpper, fromLower, fromUpper;
+        if (L.z0 > 0) pack(0, edge, toLower);                                         // becomes the lower neighbour's upper planes
+        if (L.z1 < L.nz) pack(L.n - edge, L.n, toUpper);
+        ok = comm_neighbour_exchange_host(comm, toLower, toUpper, fromLower, fromUpper, lok) && lok;
+        // the extended slab: [rows from below | my rows | rows from above]
+        const long long rowsLo = L.offset - L.extBase, rowsHi = L.extRows - rowsLo - L.n;
+        auto header = [&](const std::vector<double>& v, long long rows, long long& K) {
+            K = 0;
+            if (rows == 0) return v.empty() || nranks == 1;
+            if (v.size() < 2 || (long long)v[0] != rows) return false;
+            K = (long long)v[1];
+            return K >= 0 && (long long)v.size() == 2 + rows + 2 * K;
+        };
+        long long kLo = 0, kHi = 0;
+        if (ok && nranks > 1 && (!header(fromLower, rowsLo, kLo) || !header(fromUpper, rowsHi, kHi))) { set_error("MgSetup: a neighbour sent %zu / %zu values for the halo rows of level %d, not what %lld / %lld rows need", fromLower.size(), fromUpper.size(), l, rowsLo, rowsHi); ok = false; }
+        if (ok && nranks == 1 && (rowsLo != 0 || rowsHi != 0)) ok = false;             // (one rank owns every plane: nothing beyond the slab)
+        L.extNnz = kLo + L.nnz + kHi;
+        if (ok && L.extNnz >= 0x7fffffffLL) { set_error("MgSetup: extended slab of level %d exceeds int32 offsets", l); ok = false; }
+        std::vector<int> ero;
+        std::vector<int> cLo, cHi;
+        if (ok) {
+            ero.resize((size_t)L.extRows + 1);
+            long long run = 0; size_t at = 0;
+            ero[at++] = 0;
+            for (long long i = 0; i < rowsLo; ++i) { run += (long long)fromLower[2 + (size_t)i]; ero[at++] = (int)run; }
+            for (long long i = 0; i < L.n; ++i) { run += ro[(size_t)i + 1] - ro[(size_t)i]; ero[at++] = (int)run; }
+            for (long long i = 0; i < rowsHi; ++i) { run += (long long)fromUpper[2 + (size_t)i]; ero[at++] = (int)run; }
+            if (run != L.extNnz) { set_error("MgSetup: halo rows of level %d are inconsistent", l); ok = false; }
+            cLo.resize((size_t)kLo); cHi.resize((size_t)kHi);
+            for (long long k = 0; k < kLo; ++k) cLo[(size_t)k] = (int)fromLower[2 + (size_t)rowsLo + (size_t)kLo + (size_t)k];
+            for (long long k = 0; k < kHi; ++k) cHi[(size_t)k] = (int)fromUpper[2 + (size_t)rowsHi + (size_t)kHi + (size_t)k];
+        }
+        const size_t nzAlloc = (size_t)(L.extNnz > 0 ? L.extNnz : 1);
+        ok = ok && MGCG_HIP(hipMalloc((void**)&L.extElements, sizeof(double) * nzAlloc)) && MGCG_HIP(hipMalloc((void**)&L.extColumnIndeces, sizeof(int) * nzAlloc)) &&
+             MGCG_HIP(hipMalloc((void**)&L.extRowOffsets, sizeof(int) * ((size_t)L.extRows + 1))) && MGCG_HIP(hipMalloc((void**)&L.extDinv, sizeof(double) * (size_t)(L.extRows > 0 ? L.extRows : 1))) &&
+             MGCG_HIP(hipMalloc((void**)&L.bFull, sizeof(double) * (size_t)L.nGlobal)) && MGCG_HIP(hipMemsetAsync(L.bFull, 0, sizeof(double) * (size_t)L.nGlobal, s));
+        if (ok) {
+            ok = MGCG_HIP(hipMemcpyAsync(L.extRowOffsets, ero.data(), sizeof(int) * ero.size(), hipMemcpyHostToDevice, s));
+            if (kLo > 0) ok = ok && MGCG_HIP(hipMemcpyAsync(L.extElements, fromLower.data() + 2 + rowsLo, sizeof(double) * (size_t)kLo, hipMemcpyHostToDevice, s)) &&
+                                    MGCG_HIP(hipMemcpyAsync(L.extColumnIndeces, cLo.data(), sizeof(int) * (size_t)kLo, hipMemcpyHostToDevice, s));
+            if (L.nnz > 0) ok = ok && MGCG_HIP(hipMemcpyAsync(L.extElements + kLo, L.elements, sizeof(double) * (size_t)L.nnz, hipMemcpyDeviceToDevice, s)) &&
+                                      MGCG_HIP(hipMemcpyAsync(L.extColumnIndeces + kLo, L.columnIndeces, sizeof(int) * (size_t)L.nnz, hipMemcpyDeviceToDevice, s));
+            if (kHi > 0) ok = ok && MGCG_HIP(hipMemcpyAsync(L.extElements + kLo + L.nnz, fromUpper.data() + 2 + rowsHi, sizeof(double) * (size_t)kHi, hipMemcpyHostToDevice, s)) &&
+                                    MGCG_HIP(hipMemcpyAsync(L.extColumnIndeces + kLo + L.nnz, cHi.data(), sizeof(int) * (size_t)kHi, hipMemcpyHostToDevice, s));
+            if (ok && L.extRows > 0) launch_extract_dinv(s, L.extElements, L.extRowOffsets, L.extColumnIndeces, L.extRows, L.extBase, L.extDinv);
+            ok = ok && MGCG_HIP(hipStreamSynchronize(s));                               // (the host staging vectors go out of scope)
+        }
+        if (ok) {                                                                       // the right-hand side moves into the full-length buffer
+            if (L.b) (void)hipFree(L.b);
+            L.b = L.bFull + L.offset;
+        }
+        // the plan that brings the `deep` planes of b (collective; every rank reaches it with the same verdict)
+        if (!comm_agree(comm, ok, "MgSetup")) { ok = false; break; }
+        L.bHalo = halo_plan_create(comm, L.nGlobal, L.offset, L.n, (int)L.extBase, (int)(L.extBase + L.extRows - 1));
+        if (!L.bHalo) { ok = false; break; }
+    }
+    mg->deep = ok && wantDeep;
     if (!ok || mg->levels == 0) { MgDestroy(mg); return nullptr; }
     return mg;
 }
@@ -1060,6 +1240,12 @@ void MgDestroy(MgcgMg* mg)
         if (L.dinv) (void)hipFree(L.dinv);
         if (L.xa) (void)hipFree(L.xa);
         if (L.xb) (void)hipFree(L.xb);
+        if (L.bFull) { (void)hipFree(L.bFull); L.b = nullptr; }      // (b pointed into it)
+        if (L.extElements) (void)hipFree(L.extElements);
+        if (L.extColumnIndeces) (void)hipFree(L.extColumnIndeces);
+        if (L.extRowOffsets) (void)hipFree(L.extRowOffsets);
+        if (L.extDinv) (void)hipFree(L.extDinv);
+        if (L.bHalo) halo_plan_destroy(L.bHalo);
         if (L.b) (void)hipFree(L.b);
         if (L.r) (void)hipFree(L.r);
         if (L.halo) halo_plan_destroy(L.halo);

@@ -233,7 +233,8 @@ def test_mgcg_equals_the_oracle(oracle, reference_order, dims, levels, interpola
     mg.Dispose()
 
 
-@pytest.mark.parametrize("world,dims,levels,interpolation", [(2, (8, 8, 16), 3, 0), (4, (16, 8, 16), 2, 0), (3, (8, 4, 24), 3, 1), (8, (16, 16, 64), 3, 0)])
+@pytest.mark.parametrize("world,dims,levels,interpolation", [(2, (8, 8, 16), 3, 0), (4, (16, 8, 16), 2, 0), (3, (8, 4, 24), 3, 1), (8, (16, 16, 64), 3, 0),
+                                                            (2, (8, 8, 32), 3, 0), (4, (16, 16, 64), 3, 0)])      # (the last two: slabs thick enough for the deep-halo cycle)
 def test_row_partitioned_mgcg_equals_the_oracle_with_partitioned_sums(oracle, reference_order, world, dims, levels, interpolation):
     """Config 4 in miniature: z-slabs over 2-8 ranks; the oracle's PCG with its dot products cut at the same rows and added in rank order
     (oracle_pcg_parts) -- trace and x equal, under the overlap schedule with the interior folds."""

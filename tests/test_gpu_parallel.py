@@ -550,7 +550,9 @@ def test_partition_of_equal_nonzero_counts_over_loopback(oracle, mgcg_env, world
 
 @pytest.mark.parametrize("world,dims,levels,interpolation", [(2, (8, 8, 16), 3, 0), (4, (16, 8, 16), 2, 0), (2, (12, 12, 8), 3, 0),
                                                             (2, (8, 8, 16), 3, 1), (4, (16, 8, 16), 2, 1), (3, (8, 4, 24), 3, 1),
-                                                            (8, (16, 16, 64), 3, 0), (8, (16, 16, 64), 3, 1)])   # config 4's shape: 8 z-slabs, 3 levels
+                                                            (8, (16, 16, 64), 3, 0), (8, (16, 16, 64), 3, 1),    # config 4's shape: 8 z-slabs, 3 levels
+                                                            # slabs thick enough for the deep-halo cycle (16 / 8 / 4 planes per rank; 4 coarse sweeps reach 4 planes):
+                                                            (2, (8, 8, 32), 3, 0), (3, (16, 8, 48), 3, 0), (4, (16, 16, 64), 3, 0), (2, (8, 8, 16), 2, 0), (3, (8, 12, 24), 2, 0)])
 def test_distributed_multigrid_over_loopback(oracle, mgcg_env, world, dims, levels, interpolation):
     """Row-partitioned MGCG (config 4 in miniature): slab-local Galerkin set-up, per-level halo planes, V-cycle
     bit-identical to the single-domain oracle, PCG within the dot-product tolerance."""
@@ -585,10 +587,15 @@ def test_distributed_multigrid_over_loopback(oracle, mgcg_env, world, dims, leve
     res = _run_ranks_in_threads(world, make_rank)
     x, z = np.zeros(s.Count), np.zeros(s.Count)
     plain = os.environ.get("MGCG_COMPRESSION", "0") == "0" and "MGCG_NO_FOLD" not in os.environ and os.environ.get("MGCG_FOLD_UP", "-1") != "0"
-    if interpolation == 0 and dims[2] // world >= 8 and plain:       # (tools/pytest_env_modes.sh runs the suite with these switches too)
+    if interpolation == 0 and dims[2] // world >= 8 and plain and (dims[0] & (dims[0] - 1)) == 0 and (dims[1] & (dims[1] - 1)) == 0:       # (tools/pytest_env_modes.sh runs the suite with these switches too)
         # slabs of eight planes, power-of-two nx and ny: on the finest level the interior rows form the first sweep AND x1 + P e per gather
         # (bits 0 and 1); the boundary rows multiply what is stored within two planes of the rank's boundaries
-        assert all(r[6] == 3 for r in res), [r[6] for r in res]
+        assert all(r[6] & 3 == 3 for r in res), [r[6] for r in res]
+    # bit 2: the deep-halo cycle ran (one exchange per coarse level instead of one per sweep) -- wherever every coarse level's slab is at
+    # least as thick as its halo (2 planes on a middle level, nu_c = 4 on the coarsest), unless MGCG_DEEP_HALO=0 says otherwise
+    planes = [dims[2] // world // 2**l for l in range(1, M.levels)]
+    deep_fits = interpolation == 0 and M.levels >= 2 and all(p >= (4 if l == len(planes) - 1 else 2) and p % 2 == 0 for l, p in enumerate(planes))
+    assert all(bool(r[6] & 4) == (deep_fits and os.environ.get("MGCG_DEEP_HALO", "1") != "0") for r in res), ([r[6] for r in res], planes)
     for off, cnt, zs, xs, it, tr, _folds in res:
         z[off: off + cnt] = zs
         x[off: off + cnt] = xs
