@@ -67,6 +67,11 @@ struct MgcgMg {
     double* finalOut = nullptr;
     bool finalWritten = false;
     bool deep = false;                     // every level >= 1 has its deep halo (decided at set-up, the same on every rank)
+    // deep-halo cycle, finest level: the PCG loop keeps its residual r (the cycle's right-hand side) in this buffer -- the slab's rows with
+    // room for one grid plane either side -- so that ONE exchange brings r's halo planes and every sweep of the level can form its iterate
+    // per gather, exactly as the single-rank cycle does (no stored first sweep, no boundary zones, no separate boundary launches)
+    double* rExt = nullptr;                // plane + n + plane doubles; the loop's r = rExt + plane
+    bool deepFolds = false;                // levels >= 1 form x_1 and x_1 + P e per gather too (uniform diagonals, power-of-two nx and ny)
     bool skipHalo = false;                 // the next SpMV-shaped pass finds its halo planes already in place (deep-halo cycle: formed locally)
 };
 
@@ -186,8 +191,10 @@ static int log2_exact(long long v) { int l = 0; while ((1LL << l) < v) ++l; retu
 // Several ranks (coarse = the FULL-length coarse iterate, interiorOnly): only the interior rows form it on the fly (their columns are
 // local: (b - offset)[col]); the boundary rows multiply the stored iterate, which the caller has written within two planes of the
 // rank's boundaries and mg_spmv2 exchanges.
+// globalB (deep-halo cycle, b has its halo planes): ALL rows of the rank form the iterate per gather -- b is addressed by global column ids
+// ((b - offset)[col]) and coarse is the full-length coarse result; one launch, as on a single rank.
 static bool mg_jacobi(MgcgMg* mg, MgLevel& L, const double* b, double* xin, double* xout, const int* done, bool withDot = false, const double* coarse = nullptr,
-                      bool interiorOnly = false)
+                      bool interiorOnly = false, bool globalB = false)
 {
     SpmvArgs a{};
     a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = xin; a.y = xout + L.offset;
@@ -196,11 +203,11 @@ static bool mg_jacobi(MgcgMg* mg, MgLevel& L, const double* b, double* xin, doub
     SpmvArgs stored = a;                            // (the sweep on a stored iterate: what the boundary rows of several ranks run)
     if (coarse != nullptr) {
         const int lx = log2_exact(L.nx), ly = log2_exact(L.ny);
-        a.x = b - (interiorOnly ? L.offset : 0); a.w = nullptr; a.xScaled = 2; a.xInner = L.dinvScalar; a.xOuter = mg->omega; a.xCoarse = coarse;
+        a.x = b - ((interiorOnly || globalB) ? L.offset : 0); a.w = nullptr; a.xScaled = 2; a.xInner = L.dinvScalar; a.xOuter = mg->omega; a.xCoarse = coarse;
         const int sy = L.ny > 1 ? 1 : 0, sz = L.nz > 1 ? 1 : 0;
         a.cM0 = L.nx / 2 - 1; a.cS1 = 1 + sy; a.cM1 = ((L.ny >> sy) - 1) << (lx - 1);
         a.cS2 = 1 + sy + sz; a.cM2 = (int)(~0u << (lx - 1 + ly - sy));
-        a.cRowBase = interiorOnly ? (int)L.offset : 0;
+        a.cRowBase = (interiorOnly || globalB) ? (int)L.offset : 0;
     }
     if (interiorOnly) {
         if (withDot && mg->finalOut != nullptr) { a.y = mg->finalOut; stored.y = mg->finalOut; mg->finalWritten = true; }
@@ -283,14 +290,33 @@ static bool mg_deep_level(MgcgMg* mg, int l, const int* done, double** result)
         return true;
     }
     MgLevel& C = mg->lv[l + 1];
-    first(2, L.xa);
+    const bool folded = mg->deepFolds && (L.dcsr == nullptr || !L.dcsr->usable) &&   // (a compact form of the level's own matrix keeps the stored iterates)
+                        tuning().noFold.load(std::memory_order_relaxed) == 0 && tuning().foldUp.load(std::memory_order_relaxed) != 0;
+    if (!folded) first(2, L.xa);
     SpmvArgs a{};                                                                    // r = b - A x_1 on the slab (the level's own matrix)
     a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = L.xa; a.y = L.r;
     a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal; a.b = L.b; a.doneFlag = done;
+    if (folded) { a.x = L.bFull; a.xScaled = 1; a.xInner = L.dinvScalar; a.xOuter = mg->omega; }   // x_1[col] = omega (d0 b[col]) per gather: b is full length
     (void)launch_spmv_auto(s, EPI_RESIDUAL, a, L.cfg, L.dcsr);
     launch_restrict(s, L.nx, L.ny, L.z1 - L.z0, L.r, C.b, done);                      // b_c = P^T r (slab-local)
     double* e = nullptr;
     if (!mg_deep_level(mg, l + 1, done, &e)) return false;
+    if (folded) {
+        // post-smoothing sweep on +-1 plane with x_1 + P e formed per gather (and for the row itself): b on +-2 and e on +-1 coarse plane are here
+        const long long r0 = (long long)zlo(1) * plane - L.extBase, r1 = (long long)zhi(1) * plane - L.extBase;
+        SpmvArgs f{};
+        f.elements = L.extElements; f.rowOffsets = L.extRowOffsets; f.columnIndeces = L.extColumnIndeces; f.x = L.bFull; f.y = L.xb + L.extBase;
+        f.elementsCount = (int)L.extNnz; f.rowCount = (int)L.extRows; f.columnCount = (int)L.nGlobal;
+        f.w = nullptr; f.b = L.bFull + L.extBase; f.dinv = L.extDinv; f.dinvUniform = 1; f.dinvScalar = L.dinvScalar; f.omega = mg->omega; f.doneFlag = done;
+        f.xScaled = 2; f.xInner = L.dinvScalar; f.xOuter = mg->omega; f.xCoarse = e;
+        const int lx = log2_exact(L.nx), ly = log2_exact(L.ny), sy = L.ny > 1 ? 1 : 0, sz = L.nz > 1 ? 1 : 0;
+        f.cM0 = L.nx / 2 - 1; f.cS1 = 1 + sy; f.cM1 = ((L.ny >> sy) - 1) << (lx - 1);
+        f.cS2 = 1 + sy + sz; f.cM2 = (int)(~0u << (lx - 1 + ly - sy));
+        f.cRowBase = (int)L.extBase;
+        (void)launch_spmv_range(s, EPI_JACOBI, f, L.cfg, nullptr, r0, r1, nullptr, 0);
+        *result = L.xb;
+        return true;
+    }
     const int za = zlo(2), zb = zhi(2);                                              // (even planes: the slab is aligned and 2 is even)
     launch_prolong_add(s, L.nx, L.ny, zb - za, L.xa + (long long)za * plane, e + (long long)(za / 2) * C.nx * C.ny, done);   // y = x_1 + P e on +-2
     sweep(1, L.xa, L.xb);
@@ -326,6 +352,26 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
     }
     const bool mayFold = mg->nu == 1 && !linear && L.dinvUniform && canScale && tuning().noFold.load(std::memory_order_relaxed) == 0;
     const bool fold = mayFold && !mg->multi;
+    // Deep-halo cycle with the right-hand side in the loop's extended buffer (b = rExt + plane: one grid plane of room either side): ONE
+    // exchange brings b's halo planes, after which every row of the rank -- boundary rows included -- forms x_1 per gather of the residual
+    // pass and x_1 + P e per gather of the post-smoothing sweep: the single-rank cycle's kernels, one launch each, no zones.
+    if (l == 0 && mg->deep && mg->rExt != nullptr && b == mg->rExt + (long long)L.nx * L.ny && mayFold && (L.dcsr == nullptr || !L.dcsr->usable) &&
+        L.nx >= 2 && log2_exact(L.nx) >= 1 && log2_exact(L.ny) >= 0 && L.nGlobal < 0x7fffffffLL && tuning().foldUp.load(std::memory_order_relaxed) != 0) {
+        SpmvArgs a{};
+        a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = b - L.offset; a.y = L.r;
+        a.elementsCount = (int)L.nnz; a.rowCount = (int)L.n; a.columnCount = (int)L.nGlobal; a.b = b; a.doneFlag = done;
+        a.xScaled = 1; a.xInner = L.dinvScalar; a.xOuter = mg->omega;
+        if (!mg_spmv(mg, L, EPI_RESIDUAL, a, const_cast<double*>(b) - L.offset)) return false;     // the level's one exchange (b's halo planes), then r = b - A x_1
+        launch_restrict(mg->stream, L.nx, L.ny, L.z1 - L.z0, L.r, C.b, done);
+        double* e = nullptr;
+        if (!mg_deep_level(mg, 1, done, &e)) return false;
+        t_lastFolds |= 1 | 2 | 4 | 8;
+        struct SkipHalo { MgcgMg* m; ~SkipHalo() { m->skipHalo = false; } } skip{ mg };
+        mg->skipHalo = true;
+        if (!mg_jacobi(mg, L, b, x0, x1, done, true, e, false, true)) return false;              // the last sweep (+ r.z), straight into the caller's z
+        *result = x1;
+        return true;
+    }
     // Several ranks: the same fold for the INTERIOR rows (they reference local columns only: x1[col] formed per gather
     // from the local right-hand side), while the boundary rows multiply the stored iterate, which therefore exists only where they reach --
     // the local rows within two grid planes of a boundary (every level is a 27-point-neighbourhood operator: MgSetup's Galerkin pass has
@@ -1126,6 +1172,7 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     // (then only the two adjacent ranks are involved); the slabs are equal, so every rank decides the same.  Collective from here on: a
     // local failure is agreed on (comm_agree) before any rank walks into the exchanges.
     bool wantDeep = ok && multi && nu == 1 && mg->levels >= 2 && tuning().deepHalo.load(std::memory_order_relaxed) != 0;
+    bool foldsEverywhere = true;
     for (int l = 1; wantDeep && l < mg->levels; ++l) {
         const MgLevel& L = mg->lv[(size_t)l];
         const int d = (l == mg->levels - 1) ? nuCoarse : 2;
@@ -1208,12 +1255,37 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
             if (L.b) (void)hipFree(L.b);
             L.b = L.bFull + L.offset;
         }
+        // may the level form its iterates per gather (mg_deep_level)?  One diagonal for every row of the extended slab, power-of-two nx and
+        // ny, the row-tile kernel on both matrices.  (A rank-local decision: the results are the same bits either way.)
+        if (ok && l < mg->levels - 1) {
+            int differs = 1; double d0 = 0.0;
+            int* dflag = nullptr;
+            bool u = MGCG_HIP(hipMalloc((void**)&dflag, sizeof(int))) && MGCG_HIP(hipMemsetAsync(dflag, 0, sizeof(int), s));
+            if (u) launch_uniform_check(s, L.extDinv, L.extRows, dflag);
+            u = u && MGCG_HIP(hipMemcpyAsync(&differs, dflag, sizeof(int), hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipMemcpyAsync(&d0, L.extDinv, sizeof(double), hipMemcpyDeviceToHost, s)) &&
+                MGCG_HIP(hipStreamSynchronize(s));
+            if (dflag) (void)hipFree(dflag);
+            SpmvArgs own{}; own.elements = L.elements; own.columnIndeces = L.columnIndeces; own.elementsCount = (int)L.nnz; own.rowCount = (int)L.n;
+            SpmvArgs ext{}; ext.elements = L.extElements; ext.columnIndeces = L.extColumnIndeces; ext.elementsCount = (int)L.extNnz; ext.rowCount = (int)L.extRows;
+            const bool can = u && differs == 0 && L.dinvUniform && d0 == L.dinvScalar && L.nx >= 2 && log2_exact(L.nx) >= 1 && log2_exact(L.ny) >= 0 && L.nGlobal < 0x7fffffffLL &&
+                             spmv_takes_rowtile(own, L.cfg) && spmv_takes_rowtile(ext, L.cfg);
+            foldsEverywhere = foldsEverywhere && can;
+        }
         // the plan that brings the `deep` planes of b (collective; every rank reaches it with the same verdict)
         if (!comm_agree(comm, ok, "MgSetup")) { ok = false; break; }
         L.bHalo = halo_plan_create(comm, L.nGlobal, L.offset, L.n, (int)L.extBase, (int)(L.extBase + L.extRows - 1));
         if (!L.bHalo) { ok = false; break; }
     }
     mg->deep = ok && wantDeep;
+    mg->deepFolds = mg->deep && foldsEverywhere;
+    if (mg->deep) {       // the loop's residual with room for one grid plane either side (SolveMgParallel keeps r there)
+        const MgLevel& L0 = mg->lv[0];
+        const size_t len = (size_t)(L0.n + 2LL * L0.nx * L0.ny);
+        if (!MGCG_HIP(hipMalloc((void**)&mg->rExt, sizeof(double) * len)) || !MGCG_HIP(hipMemsetAsync(mg->rExt, 0, sizeof(double) * len, s)) || !MGCG_HIP(hipStreamSynchronize(s))) {
+            if (mg->rExt) { (void)hipFree(mg->rExt); mg->rExt = nullptr; }      // (not fatal: the cycle then keeps its boundary zones on the finest level)
+            (void)hipGetLastError();
+        }
+    }
     if (!ok || mg->levels == 0) { MgDestroy(mg); return nullptr; }
     return mg;
 }
@@ -1231,6 +1303,7 @@ void MgDestroy(MgcgMg* mg)
 {
     if (!mg) return;
     if (mg->stream) (void)hipStreamSynchronize(mg->stream);
+    if (mg->rExt) (void)hipFree(mg->rExt);
     for (auto& L : mg->lv) {
         if (L.ownsMatrix) {       // freed addresses may be handed out again: analyses keyed by them are void
             if (L.elements) { analysis_note_write(L.elements, sizeof(double) * (size_t)(L.nnz > 0 ? L.nnz : 1)); (void)hipFree(L.elements); }
@@ -1335,7 +1408,15 @@ int SolveMgParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse, Mgcg
         if (!R.halo) return MGCG_ERROR;
         if (!cg_plan_overlap(R)) { halo_plan_destroy(R.halo); return MGCG_ERROR; }
     }
-    const int st = cg_solve(R, iteration, residual, residualTrace, traceCapacity);
+    // deep-halo cycle: the loop keeps r in the hierarchy's extended buffer (room for the halo planes the cycle's one exchange brings) and the
+    // caller's vector receives it when the solve is over
+    const bool rExtended = R.multi && mg->deep && mg->rExt != nullptr;
+    if (rExtended) R.r = mg->rExt + (long long)mg->lv[0].nx * mg->lv[0].ny;
+    int st = cg_solve(R, iteration, residual, residualTrace, traceCapacity);
+    if (rExtended && countForDevice > 0) {
+        analysis_note_write(rVector->data, sizeof(double) * (size_t)countForDevice);
+        if (!MGCG_HIP(hipMemcpyAsync(rVector->data, R.r, sizeof(double) * (size_t)countForDevice, hipMemcpyDeviceToDevice, R.ws->stream)) || !MGCG_HIP(hipStreamSynchronize(R.ws->stream))) st = MGCG_ERROR;
+    }
     if (R.halo) halo_plan_destroy(R.halo);
     return st;
 }
