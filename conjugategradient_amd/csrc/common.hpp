@@ -408,6 +408,7 @@ struct FinalizeArgs {
 };
 // Single-workgroup kernels that turn partial sums into the loop's scalars.
 void launch_reduce_to(hipStream_t s, const double* partials, int n, double* dst, const int* done);          // dst = sum
+void launch_reduce2_to(hipStream_t s, const double* pA, int nA, double* dstA, const double* pB, int nB, double* dstB, const int* done);   // two sums, one launch
 void launch_finalize(hipStream_t s, const double* partials, const double* partialsInf, int n, bool reduceFirst, const FinalizeArgs& f);
 void launch_finalize_precond(hipStream_t s, const double* partials, int n, bool reduceFirst, CgScalars* sc);  // rzNew -> beta, rr
 void launch_init_scalars(hipStream_t s, const double* partials, int n, bool reduceFirst, CgScalars* sc, HostMirror* mirror, int rule);

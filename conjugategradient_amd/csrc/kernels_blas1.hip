@@ -274,6 +274,21 @@ void launch_reduce_to(hipStream_t s, const double* partials, int n, double* dst,
 {
     hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(kBlock), 0, s, partials, n, dst, 0, done);
 }
+// two sums in one launch (the preconditioned loop of several ranks: r.r and r.z in front of their one all-reduce), each in reduce_kernel's order
+__global__ __launch_bounds__(kBlock) void reduce2_kernel(const double* __restrict__ pA, int nA, double* __restrict__ dstA,
+                                                         const double* __restrict__ pB, int nB, double* __restrict__ dstB, const int* done)
+{
+    __shared__ double s_red[4];
+    __shared__ double s_red2[4];
+    if (done != nullptr && *done != 0) return;
+    const double ta = reduce_partials_block(pA, nA, s_red, 0);
+    const double tb = reduce_partials_block(pB, nB, s_red2, 0);
+    if (threadIdx.x == 0) { dstA[0] = ta; dstB[0] = tb; }
+}
+void launch_reduce2_to(hipStream_t s, const double* pA, int nA, double* dstA, const double* pB, int nB, double* dstB, const int* done)
+{
+    hipLaunchKernelGGL(reduce2_kernel, dim3(1), dim3(kBlock), 0, s, pA, nA, dstA, pB, nB, dstB, done);
+}
 
 // ------------------------------------------------------------------ fused CG pieces
 // p = r ; partial r.r

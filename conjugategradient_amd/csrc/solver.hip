@@ -734,6 +734,7 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
     if (R.multi) {
         launch_reduce_to(s, R.ws->partials, n, &sc->pAp, done);
         if (!comm_allreduce_sum(R.comm, &sc->pAp, 1, s)) return false;               // (:499)
+        if (R.mg) rrPartials = R.ws->partials + 2 * kMaxPartials;                    // (they must outlive the V-cycle, whose r.z partial sums take the first region)
         n = launch_update_r(s, sc, R.r, R.Ap, R.nLocal, rrPartials, pInf, nullptr, 0, foldRanks);   // r -= a Ap ; r.r  (:247-248); x += a p rides with the p update below
     } else {
         // one rank: the workgroups of the r update add the p.Ap partial sums themselves (one launch fewer per iteration);
@@ -753,11 +754,11 @@ static bool cg_enqueue_iteration(CgRun& R, bool withStopTest)
         // Preconditioned, several ranks: r.r (stop test) and r.z (beta) travel in ONE all-reduce of two doubles behind the
         // V-cycle ("[r.z, r.r] batched"); the stop decision of an iteration is taken one V-cycle later,
         // which costs one wasted V-cycle at the very end and saves a collective per iteration.
-        launch_reduce_to(s, rrPartials, n, &sc->rrNew, done);                        // local r.r (before the V-cycle reuses the partial sums)
+        const int nrr = n;
         int nz = 0;
         if (!mg_apply(R.mg, R.r, R.z, done, refDots ? nullptr : R.ws->partials, &nz)) return false;      // z = M^-1 r (+ partial sums of r.z on the last sweep)
         n = nz > 0 ? nz : launch_dot_partials(s, R.r, R.z, R.nLocal, R.ws->partials);
-        launch_reduce_to(s, R.ws->partials, n, &sc->rzNew, done);                    // local r.z
+        launch_reduce2_to(s, rrPartials, nrr, &sc->rrNew, R.ws->partials, n, &sc->rzNew, done);   // local r.r and r.z, one launch
         if (!comm_allreduce_sum(R.comm, &sc->rrNew, 2, s)) return false;             // {rrNew, rzNew} are adjacent in CgScalars  (:525 and the PCG's r.z)
         f.preconditioned = 2;                                                        // finalize also does beta = rzNew / rz, rz = rzNew
         launch_finalize(s, rrPartials, pInf, n, false, f);
