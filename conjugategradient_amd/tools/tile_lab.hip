@@ -3,7 +3,8 @@
 // gathers, which the y read-modify-write, which the streams -- and what a 12-byte entry (value + one packed word) buys.  Measurement
 // tool, not part of the library.  Every variant is checked bit for bit against the production-shaped pass (V0) and V0 against the host.
 //   tile_lab [rows=10000000] [tiles=20] [tileShift=19] [meanPerCell=1.55] [tileWidth=2^tileShift columns; any width <= 2^tileShift]
-//   TILE_LAB_QUICK=1: only the 12-byte production pass (for PMC runs)
+//   TILE_LAB_QUICK=1: only the 12-byte production pass (for PMC runs); TILE_LAB_V3=1 / TILE_LAB_V4=1: the row-block-persistent variants;
+//   TILE_LAB_V3_ONE=1: the one V3 variant that did best (for PMC runs)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -259,6 +260,151 @@ __global__ __launch_bounds__(kBlock) void pass_v2(const double* __restrict__ x, 
     }
 }
 
+// ---------------------------------------------------------------- V3: row-block-persistent accumulators
+// The layout is turned around: row BLOCK major (RB rows), column tile major inside a block, row major inside a (block, tile) run.  A
+// workgroup owns a row block for the whole product: its running row sums live in LDS while it walks the block's runs tile by tile -- every
+// workgroup of the chip starts with tile 0, so an XCD's workgroups read the same x window at about the same time -- and y is written ONCE at
+// the end (no read-modify-write of y per (row, tile) segment: 4.3 GB of the 9.7 GB a product moves in the tile-major form; the epilogue of
+// the solver's fused forms could ride on that store).  Rows are still summed tile by tile, columns ascending inside a tile: stored order.
+// packed = local row inside the block (bits >= shift) | column offset inside the tile; seg[b * (T + 1) + t] = first entry of run (b, t).
+// ABL bit1: gathers from an 8 KB window (L1), bit2: no gathers (x = 1)   (timing ablations: wrong results by design)
+template <int RB, int E, int ABL = 0>
+__global__ __launch_bounds__(kBlock) void pass_v3(const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ tVals, const unsigned* __restrict__ tPacked,
+                                                  const int* __restrict__ seg, int nBlocks, int T, int width, int shift, long long rows)
+{
+    constexpr int CH = kBlock * E;                                   // entries per chunk
+    __shared__ double s_acc[RB];
+    __shared__ double s_p[CH];
+    __shared__ int s_r[CH + 1];
+    const unsigned colMask = (1u << shift) - 1u;
+    for (int b = blockIdx.x; b < nBlocks; b += gridDim.x) {
+        for (int i = threadIdx.x; i < RB; i += kBlock) s_acc[i] = 0.0;
+        const int* sg = seg + (long long)b * (T + 1);
+        for (int t = 0; t < T; ++t) {
+            const int kb = sg[t], ke = sg[t + 1];
+            const int col0 = t * width;
+            for (int base = kb; base < ke; base += CH) {
+                const int cnt = (ke - base) < CH ? (ke - base) : CH;
+                double v[E]; unsigned pk[E]; int r[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int j = e * kBlock + (int)threadIdx.x;
+                    const int k = base + (j < cnt ? j : 0);
+                    v[e] = __builtin_nontemporal_load(tVals + k); pk[e] = __builtin_nontemporal_load(tPacked + k);
+                }
+                __syncthreads();                                     // (the leaders of the previous chunk are done with s_p / s_r; s_acc zeroed)
+#pragma unroll
+                for (int e = 0; e < E; ++e) { const int j = e * kBlock + (int)threadIdx.x; r[e] = (int)(pk[e] >> shift); s_r[j + 1] = j < cnt ? r[e] : -2; }
+                if (threadIdx.x == 0) s_r[0] = -1;                   // the first entry of a chunk always leads: the row's sum so far is in s_acc
+                __syncthreads();
+                bool lead[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) { const int j = e * kBlock + (int)threadIdx.x; lead[e] = j < cnt && s_r[j] != r[e]; }
+                double xv[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if (ABL & 4) xv[e] = 1.0;
+                    else if (ABL & 2) xv[e] = x[(pk[e] & colMask) & 1023u];
+                    else xv[e] = x[col0 + (int)(pk[e] & colMask)];
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) { const int j = e * kBlock + (int)threadIdx.x; s_p[j] = v[e] * xv[e]; }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if (!lead[e]) continue;
+                    const int row = r[e];
+                    double acc = s_acc[row];
+                    int j = e * kBlock + (int)threadIdx.x;
+                    while (j < cnt && s_r[j + 1] == row) { acc += s_p[j]; ++j; }
+                    s_acc[row] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        const long long row0 = (long long)b * RB;
+        for (int i = threadIdx.x; i < RB; i += kBlock) if (row0 + i < rows) __builtin_nontemporal_store(s_acc[i], y + row0 + i);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- V4: V3 with TH threads per workgroup and the next chunk's entries prefetched
+// (the loads of chunk n + 1 are issued before the gathers of chunk n: entry streams from HBM and gathers from L2 in flight together)
+template <int RB, int E, int TH, int ABL = 0>
+__global__ __launch_bounds__(TH) void pass_v4(const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ tVals, const unsigned* __restrict__ tPacked,
+                                              const int* __restrict__ seg, int nBlocks, int T, int width, int shift, long long rows)
+{
+    constexpr int CH = TH * E;
+    __shared__ double s_acc[RB];
+    __shared__ double s_p[CH];
+    __shared__ int s_r[CH + 1];
+    const unsigned colMask = (1u << shift) - 1u;
+    const int tid = (int)threadIdx.x;
+    for (int b = blockIdx.x; b < nBlocks; b += gridDim.x) {
+        for (int i = tid; i < RB; i += TH) s_acc[i] = 0.0;
+        const int* sg = seg + (long long)b * (T + 1);
+        // chunk cursor: tile t, entries [base, base + cnt) of run (b, t); advance() steps to the next non-empty chunk
+        int t = 0, base = sg[0], end = sg[1];
+        auto settle = [&]() { while (base >= end && t + 1 < T) { ++t; base = sg[t]; end = sg[t + 1]; } };
+        settle();
+        double v[E]; unsigned pk[E];
+        int cnt = (end - base) < CH ? (end - base) : CH;
+        int col0 = t * width;
+        bool have = base < end;
+        if (have) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) { const int j = e * TH + tid; const int k = base + (j < cnt ? j : 0); v[e] = __builtin_nontemporal_load(tVals + k); pk[e] = __builtin_nontemporal_load(tPacked + k); }
+        }
+        while (have) {
+            // next chunk
+            int t2 = t, base2 = base + cnt, end2 = end;
+            while (base2 >= end2 && t2 + 1 < T) { ++t2; base2 = sg[t2]; end2 = sg[t2 + 1]; }
+            const bool have2 = base2 < end2;
+            const int cnt2 = have2 ? ((end2 - base2) < CH ? (end2 - base2) : CH) : 0;
+            double v2[E]; unsigned pk2[E];
+            if (have2) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) { const int j = e * TH + tid; const int k = base2 + (j < cnt2 ? j : 0); v2[e] = __builtin_nontemporal_load(tVals + k); pk2[e] = __builtin_nontemporal_load(tPacked + k); }
+            }
+            int r[E];
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < E; ++e) { const int j = e * TH + tid; r[e] = (int)(pk[e] >> shift); s_r[j + 1] = j < cnt ? r[e] : -2; }
+            if (tid == 0) s_r[0] = -1;
+            __syncthreads();
+            bool lead[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) { const int j = e * TH + tid; lead[e] = j < cnt && s_r[j] != r[e]; }
+            double xv[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (ABL & 4) xv[e] = 1.0;
+                else if (ABL & 2) xv[e] = x[(pk[e] & colMask) & 1023u];
+                else xv[e] = x[col0 + (int)(pk[e] & colMask)];
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) { const int j = e * TH + tid; s_p[j] = v[e] * xv[e]; }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (!lead[e]) continue;
+                const int row = r[e];
+                double acc = s_acc[row];
+                int j = e * TH + tid;
+                while (j < cnt && s_r[j + 1] == row) { acc += s_p[j]; ++j; }
+                s_acc[row] = acc;
+            }
+            have = have2; t = t2; base = base2; end = end2; cnt = cnt2; col0 = t * width;
+#pragma unroll
+            for (int e = 0; e < E; ++e) { v[e] = v2[e]; pk[e] = pk2[e]; }
+        }
+        __syncthreads();
+        const long long row0 = (long long)b * RB;
+        for (int i = tid; i < RB; i += TH) if (row0 + i < rows) __builtin_nontemporal_store(s_acc[i], y + row0 + i);
+        __syncthreads();
+    }
+}
+
 __global__ void zero_kernel(double* y, long long n) { for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = 0.0; }
 
 template <typename F> static double time_ms(F f, int reps = 5)
@@ -352,6 +498,77 @@ int main(int argc, char** argv)
     auto run = [&](const char* name, auto f, bool exact) { const double ms = time_ms(f); res.push_back({ name, ms }); printf("%-48s %7.3f ms per product\n", name, ms); check(name, exact); fflush(stdout); };
     if (quick) {
         run("V1b production ordering (12 B entries)", PASSES(pass_v1b<<<g, dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t * width, shift, (const int*)nullptr)), true);
+        return 0;
+    }
+    // ---- V3 data: block-major, tile-major inside a block (regenerated from the same hashes in that order)
+    auto build_v3 = [&](int RB, std::vector<double>& v3v, std::vector<unsigned>& v3p, std::vector<int>& v3s) {
+        const int nB = (int)((rows + RB - 1) / RB);
+        v3v.clear(); v3p.clear(); v3s.assign((size_t)nB * (T + 1), 0);
+        v3v.reserve((size_t)nnz); v3p.reserve((size_t)nnz);
+        std::vector<int> cursor((size_t)T);                          // position inside tile t of the tile-major arrays (rows ascend there)
+        for (int t = 0; t < T; ++t) cursor[(size_t)t] = tileStart[(size_t)t];
+        for (int b = 0; b < nB; ++b) {
+            const long long r0 = (long long)b * RB, r1 = std::min(rows, r0 + RB);
+            for (int t = 0; t < T; ++t) {
+                v3s[(size_t)b * (T + 1) + t] = (int)v3v.size();
+                int& k = cursor[(size_t)t];
+                while (k < tileStart[(size_t)t + 1] && hr[(size_t)k] < r1) {
+                    v3v.push_back(hv[(size_t)k]);
+                    v3p.push_back(((unsigned)(hr[(size_t)k] - r0) << shift) | (unsigned)(hc[(size_t)k] - t * width));
+                    ++k;
+                }
+            }
+            v3s[(size_t)b * (T + 1) + T] = (int)v3v.size();
+        }
+        return nB;
+    };
+    auto run_v3 = [&](auto kernel, const char* name, int RB, int wgs, bool exact) {
+        if ((long long)RB << shift > (1LL << 32)) { printf("%s: RB does not fit the packed word\n", name); return; }
+        std::vector<double> v3v; std::vector<unsigned> v3p; std::vector<int> v3s;
+        const int nB = build_v3(RB, v3v, v3p, v3s);
+        double* d3v; unsigned* d3p; int* d3s;
+        CK(hipMalloc(&d3v, nnz * 8)); CK(hipMalloc(&d3p, nnz * 4)); CK(hipMalloc(&d3s, v3s.size() * 4));
+        CK(hipMemcpy(d3v, v3v.data(), nnz * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d3p, v3p.data(), nnz * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d3s, v3s.data(), v3s.size() * 4, hipMemcpyHostToDevice));
+        const int g = wgs < nB ? wgs : nB;
+        run(name, [&] { kernel<<<dim3(g), dim3(kBlock), 0, 0>>>(dx, dy, d3v, d3p, d3s, nB, T, width, shift, rows); }, exact);
+        CK(hipFree(d3v)); CK(hipFree(d3p)); CK(hipFree(d3s));
+    };
+    auto run_v4 = [&](auto kernel, const char* name, int RB, int TH, int wgs, bool exact) {
+        std::vector<double> v3v; std::vector<unsigned> v3p; std::vector<int> v3s;
+        const int nB = build_v3(RB, v3v, v3p, v3s);
+        double* d3v; unsigned* d3p; int* d3s;
+        CK(hipMalloc(&d3v, nnz * 8)); CK(hipMalloc(&d3p, nnz * 4)); CK(hipMalloc(&d3s, v3s.size() * 4));
+        CK(hipMemcpy(d3v, v3v.data(), nnz * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d3p, v3p.data(), nnz * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d3s, v3s.data(), v3s.size() * 4, hipMemcpyHostToDevice));
+        const int g = wgs < nB ? wgs : nB;
+        run(name, [&] { kernel<<<dim3(g), dim3(TH), 0, 0>>>(dx, dy, d3v, d3p, d3s, nB, T, width, shift, rows); }, exact);
+        CK(hipFree(d3v)); CK(hipFree(d3p)); CK(hipFree(d3s));
+    };
+    if (getenv("TILE_LAB_V3_ONE")) {   // the one row-block-persistent variant, for counter passes
+        run_v3(pass_v3<4096, 8>, "V3 row blocks of 4096, 2048-entry chunks, 512 wgs", 4096, 512, true);
+        return 0;
+    }
+    if (getenv("TILE_LAB_V4")) {
+        run("V1b production ordering (12 B entries)", PASSES(pass_v1b<<<g, dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t * width, shift, (const int*)nullptr)), true);
+        run_v4(pass_v4<4096, 8, 256>, "V4 RB 4096, 256 threads x 8, 512 wgs", 4096, 256, 512, true);
+        run_v4(pass_v4<4096, 4, 512>, "V4 RB 4096, 512 threads x 4, 512 wgs", 4096, 512, 512, true);
+        run_v4(pass_v4<8192, 4, 512>, "V4 RB 8192, 512 threads x 4, 256 wgs", 8192, 512, 256, true);
+        run_v4(pass_v4<8192, 4, 1024>, "V4 RB 8192, 1024 threads x 4, 256 wgs", 8192, 1024, 256, true);
+        run_v4(pass_v4<8192, 2, 1024>, "V4 RB 8192, 1024 threads x 2, 256 wgs", 8192, 1024, 256, true);
+        run_v4(pass_v4<4096, 4, 1024>, "V4 RB 4096, 1024 threads x 4, 512 wgs", 4096, 1024, 512, true);
+        run_v4(pass_v4<4096, 8, 256, 4>, "V4 RB 4096, 256 x 8: no gathers (x = 1)", 4096, 256, 512, false);
+        run_v4(pass_v4<8192, 4, 1024, 4>, "V4 RB 8192, 1024 x 4: no gathers (x = 1)", 8192, 1024, 256, false);
+        return 0;
+    }
+    if (getenv("TILE_LAB_V3")) {       // only the row-block-persistent variants (and the production pass next to them)
+        run("V1b production ordering (12 B entries)", PASSES(pass_v1b<<<g, dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t * width, shift, (const int*)nullptr)), true);
+        run_v3(pass_v3<2048, 4>, "V3 row blocks of 2048, 1024-entry chunks, 1280 wgs", 2048, 1280, true);
+        run_v3(pass_v3<2048, 4>, "V3 row blocks of 2048, 1024-entry chunks, 2560 wgs", 2048, 2560, true);
+        run_v3(pass_v3<4096, 4>, "V3 row blocks of 4096, 1024-entry chunks, 768 wgs", 4096, 768, true);
+        run_v3(pass_v3<4096, 8>, "V3 row blocks of 4096, 2048-entry chunks, 512 wgs", 4096, 512, true);
+        run_v3(pass_v3<2048, 8>, "V3 row blocks of 2048, 2048-entry chunks, 1024 wgs", 2048, 1024, true);
+        run_v3(pass_v3<8192, 4>, "V3 row blocks of 8192, 1024-entry chunks, 512 wgs", 8192, 512, true);
+        run_v3(pass_v3<2048, 4, 2>, "V3 2048 / 1024: gathers from an 8 KB window (L1)", 2048, 1280, false);
+        run_v3(pass_v3<2048, 4, 4>, "V3 2048 / 1024: no gathers (x = 1)", 2048, 1280, false);
         return 0;
     }
     run("V0 production pass (16 B entries)", V0(0), true);
