@@ -45,10 +45,6 @@ __device__ __forceinline__ double block_max(double v, double* s_red)
     return a > b ? a : b;
 }
 
-// Lab variants of update_r (round 5, tools/epi_variants.sh; the library is built with 0): bit 0 four pairs per trip, bit 1 four workgroups per CU
-#ifndef MGCG_R_VARIANT
-#define MGCG_R_VARIANT 0
-#endif
 static inline int grid_for(long long n, int perThread)
 {
     const int cap = kMaxGrid;
@@ -412,27 +408,6 @@ __global__ __launch_bounds__(kBlock) void update_r_kernel(CgScalars* __restrict_
             double q0 = rv.x * rv.x; double q1 = rv.y * rv.y; acc += q0; acc += q1;
             if (INF) { double a0 = fabs(rv.x); double a1 = fabs(rv.y); mx = a0 > mx ? a0 : mx; mx = a1 > mx ? a1 : mx; }
         };
-#if MGCG_R_VARIANT & 1
-        {   // lab variant: four pairs per trip (eight 16-byte loads in flight per lane instead of four); the same arithmetic per element, the
-            // same order of a lane's additions (i, i + kBlock, i + 2 kBlock, i + 3 kBlock ascending, as two trips of the form below)
-            const long long n2 = n >> 1;
-            const long long per = ((n2 + gridDim.x - 1) / gridDim.x + (kBlock - 1)) & ~(long long)(kBlock - 1);
-            long long i = per * blockIdx.x + threadIdx.x;
-            long long end = per * (blockIdx.x + 1);
-            end = end < n2 ? end : n2;
-            for (; i < end; i += 4 * kBlock) {
-                const bool h1 = i + kBlock < end, h2 = i + 2 * kBlock < end, h3 = i + 3 * kBlock < end;
-                const long long j1 = h1 ? i + kBlock : i, j2 = h2 ? i + 2 * kBlock : i, j3 = h3 ? i + 3 * kBlock : i;
-                d2 av0 = ldv<NTV>(a2 + i), rv0 = ldv<NTV>(r2 + i), av1 = ldv<NTV>(a2 + j1), rv1 = ldv<NTV>(r2 + j1);
-                d2 av2 = ldv<NTV>(a2 + j2), rv2 = ldv<NTV>(r2 + j2), av3 = ldv<NTV>(a2 + j3), rv3 = ldv<NTV>(r2 + j3);
-                fin(rv0, av0); stv<NTV>(rv0, r2 + i);
-                if (h1) { fin(rv1, av1); stv<NTV>(rv1, r2 + j1); }
-                if (h2) { fin(rv2, av2); stv<NTV>(rv2, r2 + j2); }
-                if (h3) { fin(rv3, av3); stv<NTV>(rv3, r2 + j3); }
-            }
-        }
-        if (false)
-#endif
         chunk_pairs(n >> 1, [&](long long i, bool two) {
             const long long j = two ? i + kBlock : i;
             // streaming hints as in update_xp (measured there: 5.2 -> 6.3 TB/s): Ap is not read again, r not before 2 GB of other traffic
@@ -459,7 +434,7 @@ int launch_update_r(hipStream_t s, CgScalars* sc, double* r, const double* Ap, l
     // two workgroups per CU measured best for this 2-reads-1-write pass (0.565 ms against 0.59-0.61 for 768 / 1024 / 2048 and 0.72 for 256
     // workgroups at 512^3; the 3-reads-2-writes x/p pass keeps 2048)
     DeviceState* d = device_state();
-    const int want = ((MGCG_R_VARIANT & 2) ? 4 : 2) * (d ? d->numCu : kNumCu);
+    const int want = 2 * (d ? d->numCu : kNumCu);
     if (grid > want) grid = want;
     const bool inf = partialsInf != nullptr;
     const bool nt = vec_nt(n);

@@ -48,19 +48,6 @@ constexpr int kTCap = 512;          // nonzeros a wavefront stages per trip
 // (A variant in which the eight XCDs read eight separate runs per trip measured 6 % slower: profiles/r2/spmv_sweep_rows_vs_rowtile_disjoint_runs.log.)
 // (struct TileMap: common.hpp; tile_map_trips / tile_map_tile: spmv_epilogue.hpp; make_tile_map below)
 
-// Lab variants of the epilogue-operand loads (round 5, tools/epi_variants.sh; the library is built with 0):
-//   bit 0: the operands are requested BEFORE the gathers of the trip; bit 1: with the non-temporal hint
-#ifndef MGCG_EPI_VARIANT
-#define MGCG_EPI_VARIANT 0
-#endif
-template <typename T> __device__ __forceinline__ T epi_ld(const T* p)
-{
-#if MGCG_EPI_VARIANT & 2
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
 template <int EPI, int XS>
 __device__ __forceinline__ RowsEpi tile_epi_prefetch(const SpmvArgs& a, int row)
 {
@@ -74,7 +61,7 @@ __device__ __forceinline__ RowsEpi tile_epi_prefetch(const SpmvArgs& a, int row)
     if constexpr (EPI == EPI_DOT) o.w = a.w[row];
     if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_DOT) o.b = a.b[row];
     if constexpr (EPI == EPI_JACOBI || EPI == EPI_JACOBI_DOT) {
-        o.b = epi_ld(a.b + row); o.w = epi_ld(a.w + row);
+        o.b = a.b[row]; o.w = a.w[row];
         const double* dp = a.dinvUniform ? a.b : a.dinv;      // uniform diagonal: the array is not read (a.b stands in, same line as o.b)
         const double dl = dp[row];
         o.dinv = a.dinvUniform ? a.dinvScalar : dl;
@@ -208,10 +195,6 @@ __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, Tile
             }
         }
         __builtin_amdgcn_sched_barrier(0);                         // all LDS reads in flight before the first gather waits for its column id
-#if MGCG_EPI_VARIANT & 1
-        RowsEpi eo = tile_epi_prefetch<EPI, XS>(a, row);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
         for (int j = 0; j < NG; ++j) xg[j] = a.x[cc[j]];
         double eg[XS == 2 ? NG : 1];
@@ -219,9 +202,7 @@ __global__ __launch_bounds__(64 * kTW) void spmv_rowtile_kernel(SpmvArgs a, Tile
 #pragma unroll
             for (int j = 0; j < NG; ++j) eg[j] = a.xCoarse[coarse_of(a, cc[j])];
         }
-#if !(MGCG_EPI_VARIANT & 1)
         RowsEpi eo = tile_epi_prefetch<EPI, XS>(a, row);
-#endif
         // the previous trip's result, then the next trip's raw stream and the row offsets of the trip after it
         __builtin_nontemporal_store(pend, a.y + pendRow);
         load_raw(__builtin_amdgcn_readfirstlane(roB_s));
