@@ -158,7 +158,7 @@ const char* MgcgGetLastError(void);
 void        MgcgClearLastError(void);
 /* Library ABI revision (3 since round 5: exports added, Vector grew, 14 tuning knobs retired, dot_order added). */
 int         MgcgAbiVersion(void);
-/* Tuning knobs (14).  Every MGCG_* environment variable the library honours is read once, at first use; launches never read the
+/* Tuning knobs (15).  Every MGCG_* environment variable the library honours is read once, at first use; launches never read the
  * environment.  No knob changes an element-wise result (SpMV rows, vector updates, the V-cycle: the same doubles under every
  * setting).  What a SCHEDULE knob may change is how a dot product's partial sums are grouped: "overlap" reduces p.Ap from the
  * interior rows' launch and the boundary rows' launch instead of one launch, so with the default overlap = 1 -- a decision taken
@@ -172,6 +172,10 @@ int         MgcgAbiVersion(void);
  *   halo_stream (overlap schedule: 0 [default] the interior rows run on the communicator's side stream and every RCCL call on the
  *     main stream; 1 the halo exchange runs on the side stream and all rows on the main stream -- opt-in until RCCL on two streams of
  *     one communicator has been run on real multi-GPU hardware);
+ *   deep_halo (MGCG_DEEP_HALO, default 1: the row-partitioned V(1,1) cycle takes ONE exchange per level -- a few planes of the level's
+ *     right-hand side, after which everything within reach of the slab's boundaries is recomputed locally, bit for bit what the owner
+ *     computes -- 4 exchanges per MGCG iteration; 0: one exchange per SpMV-shaped pass, 8 per iteration.  Needs slabs at least as thick
+ *     as the halo on every coarse level (2 planes; nu_c on the coarsest), else the library takes the per-pass schedule by itself);
  *   no_fold (MGCG_NO_FOLD: the first Jacobi sweep of a V(1,.) cycle is stored instead of being formed per gather of the residual pass);
  *   fold_up (MGCG_FOLD_UP: -1 [default] the prolongation of a V(1,1) cycle is formed per gather of the post-smoothing sweep on levels of
  *     up to 100 M rows, 0 never, 1 on every level);
