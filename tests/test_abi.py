@@ -142,3 +142,30 @@ def test_comm_init_all_writes_exactly_the_entries_it_was_given(hiplib):
         assert list(buf[:guard]) == [sentinel] * guard and list(buf[guard + room:]) == [sentinel] * guard, ndev
     assert L.MgcgCommInitAll(None, 2) == -1
     L.MgcgClearLastError()
+
+
+def test_the_knob_list_is_the_header_s(hiplib, monkeypatch):
+    """Round 5 retired the knobs whose A/B was settled: the library answers to exactly the 15 names of include/MgcgGpu.h's tuning list, with
+    the defaults written there, and no longer to the retired ones.  No device needed."""
+    from conjugategradient_amd import _lib
+
+    for name in list(os.environ):
+        if name.startswith("MGCG_"):
+            monkeypatch.delenv(name)
+    L = hiplib
+    L.MgcgReloadEnvironment()
+    kept = {"overlap": 1, "halo_stream": 0, "deep_halo": 1, "no_fold": 0, "fold_up": -1, "check_every": 4, "auto_tiles": 1, "tile_shift": 0, "tile_pack": 1,
+            "placement": 3, "dot_order": 0, "verbose": 0, "virtual_devices": 0, "force_multirank": 0, "fail_comm_init": 0}
+    v = C.c_int(-99)
+    for name, default in kept.items():
+        assert L.MgcgGetTuning(name.encode(), C.byref(v)) == 0 and v.value == default, (name, v.value)
+        assert L.MgcgGetTuning(("MGCG_" + name.upper()).encode(), C.byref(v)) == 0 and v.value == default
+    header = open(os.path.join(ROOT, "include", "MgcgGpu.h")).read()
+    assert "Tuning knobs (%d)" % len(kept) in header
+    for name in kept:
+        assert name in header, name
+    for gone in ("no_folded_finalize", "no_uniform_diagonal", "no_zsweep", "rowtile_nt", "vec_nt", "vec_grid", "r_grid", "xp_grid", "pattern_group",
+                 "pattern_waves", "no_indexed_halo", "tile_nt", "vector_vals_nt", "lazy_code_objects"):
+        assert L.MgcgSetTuning(gone.encode(), 1) == -1, gone
+    L.MgcgClearLastError()
+    assert L.MgcgAbiVersion() == 3

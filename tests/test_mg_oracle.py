@@ -178,3 +178,39 @@ def test_linear_transfer_fixture(oracle):
     assert res["iteration"] == int(g["pcg_iteration"]) == 12
     assert np.array_equal(res["x"], g["pcg_x"]) and np.array_equal(M.apply(g["r"]), g["z"])
     assert np.abs(res["x"] - g["x_direct"]).max() < 1e-9
+
+
+def test_pcg_with_partitioned_sums(oracle):
+    """oracle_pcg_parts: the PCG with its dot products cut at the rows of a row partition and the per-device sums added in device order from
+    0 (resultsDot.Sum(), ConjugateGradientParallelGpu.cs:463,499,525) -- what the row-partitioned HIP loop must EQUAL under MGCG_DOT_ORDER=1
+    (tests/test_gpu_dot_order.py).  One part = the plain loop, bit for bit; several parts: the same iteration count, values within the sums'
+    rounding; the sum over parts really is rank-ordered serial sums of the slices."""
+    s = problems.poisson(16, 16, 16)
+    s.b[:] = np.random.default_rng(3).standard_normal(s.Count)
+    M = oracle.Multigrid(s, levels=3)
+    one = M.pcg(rule=oracle.RULE_CSHARP, max_iteration=400, trace=True)
+    same = M.pcg(rule=oracle.RULE_CSHARP, max_iteration=400, trace=True, offsets=[0, s.Count])
+    assert one["iteration"] == same["iteration"] and np.array_equal(one["trace"], same["trace"]) and np.array_equal(one["x"], same["x"])
+    for parts in (2, 3, 8):
+        off = oracle.partition(s.Count, parts)
+        p = M.pcg(rule=oracle.RULE_CSHARP, max_iteration=400, trace=True, offsets=off)
+        assert p["iteration"] == one["iteration"]
+        np.testing.assert_allclose(p["trace"], one["trace"], rtol=1e-9)
+        assert not np.array_equal(p["trace"], one["trace"])          # the association of the sums differs: other bits
+    # the first residual of the partitioned loop, recomputed by hand: r0 = b - A x0 (x0 = 0: r0 = b), z0 = M^-1 r0, p0 = z0, rz = sum over parts
+    off = oracle.partition(s.Count, 3)
+    z0 = M.apply(s.b)
+    rz = 0.0
+    for d in range(3):
+        rz += oracle.dot(s.b[off[d]: off[d + 1]], z0[off[d]: off[d + 1]])
+    Ap = oracle.spmv(s.Elements, s.ColumnIndeces, s.RowOffsets, z0)
+    pAp = 0.0
+    for d in range(3):
+        pAp += oracle.dot(z0[off[d]: off[d + 1]], Ap[off[d]: off[d + 1]])
+    alpha = rz / pAp
+    r1 = oracle.set_added(s.b, Ap, -alpha)
+    rr = 0.0
+    for d in range(3):
+        rr += oracle.dot(r1[off[d]: off[d + 1]], r1[off[d]: off[d + 1]])
+    p3 = M.pcg(rule=oracle.RULE_CSHARP, max_iteration=400, trace=True, offsets=off)
+    assert p3["trace"][0] == np.sqrt(rr)
