@@ -58,7 +58,7 @@ static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // Element-wise grid-stride driver.  V2: f2(i) handles elements i, i+1 with 16-byte accesses and the
 // odd tail goes to f1 on one thread; otherwise f1(i) per element.
 // Streaming hint of the CG vector passes (non-temporal loads and stores).  Measured per size, alternating inside one process
-// (tools/vec_nt_ab.py, profiles/r2/vec_nt_ab.log): with the hint the CG iteration is 2-11 % faster from 4 M rows up (11 % at the 16.8 M rows
+// (profiles/r2/vec_nt_ab.log; the A/B script is in the history): with the hint the CG iteration is 2-11 % faster from 4 M rows up (11 % at the 16.8 M rows
 // of one rank's slab of an 8-GPU run, 2 % at 134 M) and 2.5 % slower at 2 M rows and below, where every vector stays in the caches anyway.
 template <bool NTV, typename T> __device__ __forceinline__ T ldv(const T* p) { if constexpr (NTV) return __builtin_nontemporal_load(p); else return *p; }
 template <bool NTV, typename T> __device__ __forceinline__ void stv(const T& v, T* p) { if constexpr (NTV) __builtin_nontemporal_store(v, p); else *p = v; }

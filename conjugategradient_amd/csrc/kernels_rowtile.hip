@@ -304,7 +304,7 @@ static int launch_rowtile_epi(hipStream_t s, const SpmvArgs& a, int periodRows, 
     tm.gapAt = gapAt; tm.gapSkip = gapSkip;
     // Matrix streams with the non-temporal hint when the vectors of the system are small enough to live in the 256 MB Infinity Cache
     // between the kernels of an iteration (the slab of one rank of an 8-GPU run, the coarse levels of a hierarchy): the matrix, read once
-    // per product, then does not push them out.  CG iteration, alternating inside one process (tools/nt_ab.py): -1 % at 8.4 M rows, -3.5 % at 16.8 M,
+    // per product, then does not push them out.  CG iteration, alternating inside one process (profiles/r2, the A/B script is in the history): -1 % at 8.4 M rows, -3.5 % at 16.8 M,
     // -1.5 % at 33.5 M, +0.2 % at 42 M, +1.5 % at 134 M (there the hint only costs) and +10 % at 2 M (there the matrix itself would have stayed in the cache).  Only the plain CG loop asks for it (SpmvConfig::flags & 8): inside the V-cycle
     // the same hint made the slab's MGCG iteration 1-3 % slower.
     const bool nt = ntWindow && a.rowCount >= 8000000 && a.rowCount <= 36000000;

@@ -426,7 +426,7 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
              (tuning().foldUp.load(std::memory_order_relaxed) < 0 ? L.n <= kFoldUpMaxRows : tuning().foldUp.load(std::memory_order_relaxed) != 0)) {
         // V(1,1) on plain CSR: the prolongation is folded into the one post-smoothing sweep as well -- x1 + P e is formed per gather there
         // (no prolongation kernel, the iterate buffer `cur` is never written: 33 N bytes less on this level).  The second gather per entry
-        // costs the sweep more than the bytes save on the largest levels (tools/foldup_ab.py, profiles/r3/foldup_ab.log: 256^3 as the
+        // costs the sweep more than the bytes save on the largest levels (profiles/r3/foldup_ab.log, the A/B script is in the history: 256^3 as the
         // finest level -4.5 % per MGCG iteration, 512 x 512 x 256 -1.6 %, as level 1 of 512^3 -56 us; on the 512^3 level itself +0.13 ms): by level size.
         if (!mg_jacobi(mg, L, b, cur, other, done, l == 0, e + C.offset)) return false;
         t_lastFolds |= 2;

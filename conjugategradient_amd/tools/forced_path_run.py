@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One rank's slab on the several-ranks code path (MGCG_FORCE_MULTIRANK, a real one-rank RCCL communicator) for a kernel trace:
     rocprofv3 --kernel-trace --output-format csv -d OUT -- python3 conjugategradient_amd/tools/forced_path_run.py --overlap 2 --halo-stream 1
-then tools/trace_timeline.py OUT prints the kernels of one iteration with the gaps between them.  Without the profiler it prints one
+then tools/trace_iteration.py OUT prints the kernels of one steady-state iteration with the gaps between them.  Without the profiler it prints one
 JSON line with the milliseconds per iteration (tools/slab_latency.py runs every schedule in a fresh process through this)."""
 import argparse
 import ctypes as C
