@@ -188,3 +188,39 @@ def test_single_process_ranks_over_rccl_when_the_box_has_two_devices(oracle, tmp
         rec = json.loads(out.stdout.splitlines()[-1])
         assert rec["ranks"] == 2 and rec["transport"] == "rccl" and rec["iteration"] == ref["iteration"]
         _check_x(np.fromfile(xfile), ref["x"], dot_order)
+
+
+@pytest.mark.parametrize("devices,dot_order", [(1, "0"), (3, "0"), (1, "1"), (3, "1")])
+def test_the_reference_driver_in_full_three_ways(oracle, tmp_path, devices, dot_order):
+    """MgcgMain.cs:41-178 in full -- CPU solver, single GPU, every GPU -- with its own element-by-element check (1 % relative against the CPU
+    answer, :129-162).  The product's twin host/MgcgMain.cpp is two-way (the library has no CPU compute path); this harness lives under tests/
+    because its CPU leg is the reference's ConjugateGradientCpu restated on the test oracle (tests/mgcg_main_three_way.cpp links liboracle).
+    On top of the reference's 1 %: the three answers element by element at the north star's 1e-10 (or the oracle's own spread where the forced
+    iterations run into the round-off tail), and with MGCG_DOT_ORDER=1 the single-GPU answer EQUALS the CPU answer bit for bit."""
+    from conjugategradient_amd import _lib
+
+    exe = str(tmp_path / "mgcg_main_three_way")
+    src = os.path.join(ROOT, "tests", "mgcg_main_three_way.cpp")
+    libdir = os.path.join(ROOT, "conjugategradient_amd")
+    oracle.lib()                                                         # (builds oracle/liboracle.so if needed)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", src, "-o", exe, "-L" + libdir, "-lMgcgGpu", "-L" + os.path.join(ROOT, "oracle"), "-l:liboracle.so",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    count, min_it = 20003, 40
+    prefix = str(tmp_path / "x")
+    env = dict(os.environ, MGCG_VIRTUAL_DEVICES=str(devices), MGCG_DOT_ORDER=dot_order)
+    out = subprocess.run([exe, str(count), str(min_it), "write=" + prefix], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["devices"] == devices and rec["mismatches_single"] == 0 and rec["mismatches_parallel"] == 0        # the reference's own check
+    assert rec["iteration_cpu"] == rec["iteration_single"] == rec["iteration_parallel"] == min_it
+    assert rec["us_per_iteration_cpu"] > rec["us_per_iteration_single"] > 0 and rec["us_per_iteration_parallel"] > 0   # the three figures of :165-167
+    s = problems.mgcg_main(count, 160)
+    ref = oracle.cg(s, rule=oracle.RULE_CSHARP, min_iteration=min_it, max_iteration=count)
+    x_cpu, x_single, x_par = (np.fromfile(prefix + "." + k + ".f64") for k in ("cpu", "single", "parallel"))
+    assert _equal_bits(x_cpu, ref["x"])                                  # the harness's CPU leg IS the oracle loop
+    spread = [oracle.cg_parallel(s, w, min_iteration=min_it, max_iteration=count)["x"] for w in (1, 2, 3, 4)]
+    _check_x(x_single, x_cpu, dot_order, spread)
+    refp = oracle.cg_parallel(s, devices, min_iteration=min_it, max_iteration=count)
+    _check_x(x_par, refp["x"], dot_order, spread)
+    if dot_order == "1":
+        assert rec["residual_single"] == rec["residual_cpu"] == ref["residual"]
