@@ -1,13 +1,14 @@
 #!/bin/bash
 # The GPU suite under EVERY knob the library keeps (include/MgcgGpu.h: the tuning list): each must leave every result unchanged.
-#   bash conjugategradient_amd/tools/pytest_env_modes.sh OUT.log [a|b|c|d]
+#   bash conjugategradient_amd/tools/pytest_env_modes.sh OUT.log [a|b|c|d|e]
 # (verbose, virtual_devices, force_multirank and fail_comm_init are set by the tests themselves.)
 OUT=$1
 mkdir -p "$(dirname "$OUT")"
 : > "$OUT"
 run() { echo "== $*" >> "$OUT"; env "$@" timeout -k 10 1100 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -n 3 >> "$OUT"; }
-# (four parts of four runs, so that each fits one gpurun call of 20 minutes; no second argument = everything)
-PART=${2:-abcd}
+# (parts of at most four runs, so that each fits one gpurun call of 20 minutes -- the suite with every sum in the reference's order, part e,
+#  takes a call of its own: its full-size solves run serial sums; no second argument = everything)
+PART=${2:-abcde}
 if [[ $PART == *a* ]]; then
 run MGCG_DEFAULT=1
 run MGCG_COMPRESSION=1
@@ -30,6 +31,8 @@ if [[ $PART == *d* ]]; then
 run MGCG_PLACEMENT=0
 run MGCG_AUTO_TILES=0
 run MGCG_TILE_SHIFT=19
+fi
+if [[ $PART == *e* ]]; then
 run MGCG_DOT_ORDER=1
 fi
 cat "$OUT"
