@@ -1314,7 +1314,7 @@ void MgDestroy(MgcgMg* mg)
         if (L.dinv) (void)hipFree(L.dinv);
         if (L.xa) (void)hipFree(L.xa);
         if (L.xb) (void)hipFree(L.xb);
-        if (L.bFull) { (void)hipFree(L.bFull); L.b = nullptr; }      // (b pointed into it)
+        if (L.bFull) { if (L.b == L.bFull + L.offset) L.b = nullptr; (void)hipFree(L.bFull); }      // (b pointed into it -- unless the set-up failed in between)
         if (L.extElements) (void)hipFree(L.extElements);
         if (L.extColumnIndeces) (void)hipFree(L.extColumnIndeces);
         if (L.extRowOffsets) (void)hipFree(L.extRowOffsets);
