@@ -374,3 +374,37 @@ def test_config2_sixty_cg_iterations_equal_the_oracle_at_full_size(oracle, refer
         assert it == its8 - 1
         assert_equal_bits(tr, ref8["trace"], "8 ranks: trace")
         assert_equal_bits(xs, ref8["x"][off: off + cnt], "8 ranks: x")
+
+
+def test_the_other_two_families_front_ends_equal_the_oracle(oracle, reference_order):
+    """the HandmadeCL family's class (max-norm residual, MIN_ITERATION idiom) and the ViennaCL family's
+    ComputerGpu (relative rule) on the systems their drivers build (MgcgCLMain.cs:52-90, MgcgCL.cs:31-45): Iteration and every entry of x
+    equal to the oracle's loop with the same rule."""
+    from conjugategradient_amd.frontends import ComputerGpu, ConjugateGradientCLGpu
+
+    n, K = 400, 160
+    s = problems.mgcg_main(n, K)
+    cl = ConjugateGradientCLGpu(n, K, 50, n, 1e-4)
+    for i in range(n):
+        lo, hi = int(s.RowOffsets[i]), int(s.RowOffsets[i + 1])
+        for k in range(lo, hi):                                          # (diagonal first, then ascending columns: the builder's own order)
+            cl.A[i, int(s.ColumnIndeces[k])] = float(s.Elements[k])
+    cl.b[:] = s.b
+    cl.x[:] = s.x
+    ref = oracle.cg(s, rule=oracle.RULE_HANDMADECL, allowable_residual=1e-4, min_iteration=50, max_iteration=n)
+    cl.Initialize()
+    cl.Solve()
+    cl.Read()
+    assert cl.Iteration == ref["iteration"] == 50 and cl.Residual == ref["residual"]
+    assert_equal_bits(cl.x, ref["x"], "HandmadeCL family x")
+    cl.Dispose()
+    v = problems.viennacl_main(n, K)
+    ref = oracle.cg(v, rule=oracle.RULE_VIENNACL, allowable_residual=1e-4, min_iteration=0, max_iteration=n, hard_cap=n + 10)
+    gpu = ComputerGpu(n)
+    gpu.Write(v.Elements, v.RowOffsets, v.ColumnIndeces, np.zeros(n), v.b)
+    gpu.Solve(1e-4, 0, n)
+    x = np.zeros(n)
+    gpu.Read(x)
+    assert gpu.Iteration() == ref["iteration"] + 1
+    assert_equal_bits(x, ref["x"], "ViennaCL family x")
+    gpu.Dispose()
