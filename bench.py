@@ -577,23 +577,27 @@ def _mgcg_ms_per_iteration(L, m, k_short, k_long, sync):
     return ms, res
 
 
-def _mgcg_schedule(L, dist, build, rank, world, comm, sch, k_short, k_long):
-    """ms per MGCG iteration of a freshly set-up hierarchy under one halo schedule (collective)."""
+def _mgcg_schedule(L, dist, build, rank, world, comm, sch, k_short, k_long, deep_halo=None):
+    """ms per MGCG iteration of a freshly set-up hierarchy under one halo schedule (collective).  deep_halo = 0: round 4's cycle (one exchange
+    per SpMV-shaped pass) instead of the deep-halo cycle (one per level)."""
     key, ov, hs = sch
-    saved = (_tuning_get(L, b"overlap"), _tuning_get(L, b"halo_stream"))
+    saved = (_tuning_get(L, b"overlap"), _tuning_get(L, b"halo_stream"), _tuning_get(L, b"deep_halo"))
     try:
         L.MgcgSetTuning(b"overlap", ov)
         L.MgcgSetTuning(b"halo_stream", hs)
+        if deep_halo is not None:
+            L.MgcgSetTuning(b"deep_halo", deep_halo)
         m2 = build(rank, world, comm)
         try:
             _mgcg_fixed(L, m2, k_short)
             ms2, _ = _mgcg_ms_per_iteration(L, m2, k_short, k_long, dist.barrier)
-            return {"ms_per_iteration": _max_over_ranks(dist, [ms2])[0]}
+            return {"ms_per_iteration": _max_over_ranks(dist, [ms2])[0], "folds_rank0": int(L.MgcgLastVcycleFolds())}
         finally:
             m2.Dispose()
     finally:
         L.MgcgSetTuning(b"overlap", saved[0])
         L.MgcgSetTuning(b"halo_stream", saved[1])
+        L.MgcgSetTuning(b"deep_halo", saved[2])
 
 
 def mgcg_multirank_extra(L, _lib, dist, a, rank, world, local_rank, comm, n: int, stage):
@@ -682,7 +686,10 @@ def mgcg_multirank_extra(L, _lib, dist, a, rank, world, local_rank, comm, n: int
     sched = {}
     for sch in SCHEDULES:
         sched[sch[0]] = _mgcg_schedule(L, dist, build, rank, world, comm, sch, k_short, k_long)
-    sched["library_default"] = {"ms_per_iteration": ms, "overlap_knob": _tuning_get(L, b"overlap"), "halo_stream_knob": _tuning_get(L, b"halo_stream")}
+    # the library's default schedule with round 4's cycle (an exchange before every SpMV-shaped pass: 8 per iteration) next to the deep-halo cycle (4)
+    sched["per_pass_exchanges"] = _mgcg_schedule(L, dist, build, rank, world, comm, ("per_pass_exchanges", _tuning_get(L, b"overlap"), _tuning_get(L, b"halo_stream")), k_short, k_long, deep_halo=0)
+    sched["library_default"] = {"ms_per_iteration": ms, "overlap_knob": _tuning_get(L, b"overlap"), "halo_stream_knob": _tuning_get(L, b"halo_stream"),
+                                "deep_halo_knob": _tuning_get(L, b"deep_halo"), "folds_rank0": out.get("folds_rank0")}
     out["schedules"] = sched
     out["_k"] = (k_short, k_long)
     out["_build"] = build

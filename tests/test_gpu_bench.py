@@ -78,8 +78,12 @@ def _check_multirank_extras(rec, world):
     assert par["within_1e-10"] is True and par["same_iterations_to_1e-8"] is True, par
     assert mg["single_rank"]["iterations_to_1e-8"] == mg["iterations_to_1e-8"]
     assert mg["speedup_vs_single_rank"]["solver_time"] > 0 and mg["speedup_vs_single_rank"]["per_iteration"] > 0
-    for k in ("exchange_in_line", "interior_rows_on_side_stream", "exchange_on_side_stream", "library_default"):
+    for k in ("exchange_in_line", "interior_rows_on_side_stream", "exchange_on_side_stream", "library_default", "per_pass_exchanges"):
         assert mg["schedules"][k]["ms_per_iteration"] > 0, (k, mg["schedules"])
+    # the deep-halo cycle (bit 2 of the folds) is the default wherever the slabs are thick enough; the per-pass schedule never has it
+    assert not mg["schedules"]["per_pass_exchanges"]["folds_rank0"] & 4
+    planes = round(rec["config"]["rows"] ** (1 / 3)) // world
+    assert bool(mg["folds_rank0"] & 4) == (planes // 2 >= 2 and planes // 4 >= 4 and os.environ.get("MGCG_DEEP_HALO", "1") != "0"), (mg["folds_rank0"], planes)
 
 
 @pytest.mark.parametrize("solver", ["cg", "mgcg"])
