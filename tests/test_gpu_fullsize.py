@@ -159,6 +159,7 @@ def test_config3_first_iterations_against_the_oracle_at_full_size(oracle, mgcg_e
         return mg.trace, x, folds
 
     # (1) default mode: the same algorithm with exactly summed dot products
+    mgcg_env.setenv("MGCG_DOT_ORDER", "0")             # (also when the whole suite runs under MGCG_DOT_ORDER=1)
     trace, x, folds = solve_single()
     if "MGCG_NO_FOLD" not in os.environ and os.environ.get("MGCG_FOLD_UP", "-1") != "0":
         assert folds == 3                                  # the schedule of record: first sweep and (on the 256^3 level) prolongation folded
