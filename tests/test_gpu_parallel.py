@@ -201,7 +201,9 @@ def test_measured_overlap_rule_is_one_collective_decision_of_all_ranks(mgcg_env)
     assert out[0][0] == out[1][0] and out[0][5] == out[1][5]
     single = ConjugateGradientRankGpu(n**3, 7, 0, 10**6, 1e-8, rank=0, world=1)
     single.InitializePoisson(n, n, n)
-    assert abs(single.Steps(10, restart=True) - out[0][0]) <= 1e-12 * out[0][0]
+    # (tree sums: 1e-12; with the whole suite under MGCG_DOT_ORDER=1 the serial sums of one and of two ranks differ by the reference order's own
+    #  rounding at 2 M rows, as oracle.cg and oracle.cg_parallel do)
+    assert abs(single.Steps(10, restart=True) - out[0][0]) <= (1e-10 if os.environ.get("MGCG_DOT_ORDER", "0") == "1" else 1e-12) * out[0][0]
     single.Dispose()
 
 
