@@ -43,46 +43,6 @@ __global__ __launch_bounds__(256) void gather_kernel(const double* __restrict__ 
     }
     if (acc == 1.2345e300) out[0] = acc;
 }
-// Round 5: can the SCALAR data path carry gathers next to the vector path?  The tile pass of config 5 is bound by the L1 (TCP) miss path --
-// 0.22 L1->L2 requests per cycle per CU at a 316-cycle L2 hit latency (profiles/r5/config5_tiles/pmc_summary_T27.json); scalar loads go through
-// the scalar cache, which has a miss path of its own.  Per wave and trip: V vector gathers per lane (64 V entries) and S x 64 scalar gathers --
-// lane indices broadcast one by one (v_readlane) into s_load_dwordx2, results written back lane by lane.  V = 4, S = 0 is the plain kernel.
-template <int V, int S>
-__global__ __launch_bounds__(256) void gather_mixed_kernel(const double* __restrict__ x, const int* __restrict__ idx, long long n, double* __restrict__ out)
-{
-    double acc = 0.0;
-    const long long stride = (long long)gridDim.x * 256;
-    const int lane = threadIdx.x & 63;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i + (V + S - 1) * stride < n; i += (V + S) * stride) {
-        int c[V + S];
-#pragma unroll
-        for (int u = 0; u < V + S; ++u) c[u] = __builtin_nontemporal_load(idx + i + u * stride);
-        double v[V > 0 ? V : 1];
-#pragma unroll
-        for (int u = 0; u < V; ++u) v[u] = x[c[u]];
-#pragma unroll
-        for (int u = 0; u < S; ++u) {
-            double mine = 0.0;
-            // 64 scalar loads, issued in groups of 8 so that several are in flight
-            for (int l0 = 0; l0 < 64; l0 += 8) {
-                double sv[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int ci = __builtin_amdgcn_readlane(c[V + u], l0 + k);
-                    const double* p = x + ci;
-                    asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(sv[k]) : "s"(p));
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int k = 0; k < 8; ++k) mine = (lane == l0 + k) ? sv[k] : mine;
-            }
-            acc += mine;
-        }
-#pragma unroll
-        for (int u = 0; u < V; ++u) acc += v[u];
-    }
-    if (acc == 1.2345e300) out[0] = acc;
-}
 template <typename F> static double time_ms(F f, int reps = 5)
 {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -105,10 +65,6 @@ int main(int argc, char** argv)
         printf("window %8d doubles (%6.1f MB): ", window, window * 8 / 1048576.0);
 #define RUN(M, U, name) { double ms = time_ms([&] { hipLaunchKernelGGL((gather_kernel<M, U>), dim3(8192), dim3(256), 0, 0, x, idx, n, out, window); }); printf(" %s %6.1f G/s", name, n / ms / 1e6); }
         RUN(0, 4, "plain") RUN(0, 8, "plainU8") RUN(1, 4, "nt") RUN(6, 4, "buf") RUN(2, 4, "buf.sc0") RUN(3, 4, "buf.sc1") RUN(4, 4, "buf.sc0sc1") RUN(5, 4, "buf.nt") RUN(7, 4, "f32")
-        printf("\n"); fflush(stdout);
-#define RUNM(V, S, name) { double ms = time_ms([&] { hipLaunchKernelGGL((gather_mixed_kernel<V, S>), dim3(8192), dim3(256), 0, 0, x, idx, n, out); }); printf(" %s %6.1f G/s", name, n / ms / 1e6); }
-        printf("   scalar path next to the vector path: ");
-        RUNM(4, 0, "v4") RUNM(3, 1, "v3+s1") RUNM(6, 2, "v6+s2") RUNM(7, 1, "v7+s1") RUNM(0, 1, "s1 only")
         printf("\n"); fflush(stdout);
         if (argc > 1 && atoi(argv[1]) > 0) break;
     }
