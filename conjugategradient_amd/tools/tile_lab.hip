@@ -328,6 +328,84 @@ __global__ __launch_bounds__(kBlock) void pass_v3(const double* __restrict__ x, 
     }
 }
 
+// ---------------------------------------------------------------- V5: V3 with a SOFT lockstep of an XCD's workgroups over the tiles
+// V3 loses because nothing keeps the workgroups of an XCD on one x window (counters: L2 hit rate 51 %).  Here a workgroup that is about to start
+// step k = (round, tile) first looks at how many workgroups of ITS XCD (blockIdx.x & 7: round-robin dispatch) have finished step k - 1 - SLACK
+// and sleeps while fewer than `need` have -- at most kMaxNaps short naps, then it goes on regardless: a best-effort pacing that can never
+// deadlock (no workgroup ever depends on another one being resident).  progress[xcd * steps + k] counts finished workgroups (zeroed per launch).
+constexpr int kMaxNaps = 4000;
+template <int RB, int E, int SLACK>
+__global__ __launch_bounds__(kBlock) void pass_v5(const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ tVals, const unsigned* __restrict__ tPacked,
+                                                  const int* __restrict__ seg, int nBlocks, int T, int width, int shift, long long rows, unsigned* __restrict__ progress, int needPerMille)
+{
+    constexpr int CH = kBlock * E;
+    __shared__ double s_acc[RB];
+    __shared__ double s_p[CH];
+    __shared__ int s_r[CH + 1];
+    const unsigned colMask = (1u << shift) - 1u;
+    const int xcd = blockIdx.x & 7;
+    const int rounds = (nBlocks + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int steps = rounds * T;
+    unsigned* prog = progress + (long long)xcd * steps;
+    int round = 0;
+    for (int b = blockIdx.x; b < nBlocks; b += gridDim.x, ++round) {
+        for (int i = threadIdx.x; i < RB; i += kBlock) s_acc[i] = 0.0;
+        const int* sg = seg + (long long)b * (T + 1);
+        // workgroups of my XCD that take part in this round
+        const int lastFull = nBlocks - round * (int)gridDim.x;                         // blocks left at the start of this round
+        const int active = lastFull >= (int)gridDim.x ? (int)gridDim.x / 8 : (lastFull - xcd + 7) / 8;
+        const unsigned need = (unsigned)((long long)active * needPerMille / 1000);
+        for (int t = 0; t < T; ++t) {
+            const int k = round * T + t;
+            if (k - 1 - SLACK >= 0 && threadIdx.x == 0) {
+                int naps = 0;
+                while (__hip_atomic_load(prog + (k - 1 - SLACK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && naps < kMaxNaps) { __builtin_amdgcn_s_sleep(8); ++naps; }
+            }
+            __syncthreads();
+            const int kb = sg[t], ke = sg[t + 1];
+            const int col0 = t * width;
+            for (int base = kb; base < ke; base += CH) {
+                const int cnt = (ke - base) < CH ? (ke - base) : CH;
+                double v[E]; unsigned pk[E]; int r[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int j = e * kBlock + (int)threadIdx.x;
+                    const int kk = base + (j < cnt ? j : 0);
+                    v[e] = __builtin_nontemporal_load(tVals + kk); pk[e] = __builtin_nontemporal_load(tPacked + kk);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) { const int j = e * kBlock + (int)threadIdx.x; r[e] = (int)(pk[e] >> shift); s_r[j + 1] = j < cnt ? r[e] : -2; }
+                if (threadIdx.x == 0) s_r[0] = -1;
+                __syncthreads();
+                bool lead[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) { const int j = e * kBlock + (int)threadIdx.x; lead[e] = j < cnt && s_r[j] != r[e]; }
+                double xv[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) xv[e] = x[col0 + (int)(pk[e] & colMask)];
+#pragma unroll
+                for (int e = 0; e < E; ++e) { const int j = e * kBlock + (int)threadIdx.x; s_p[j] = v[e] * xv[e]; }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if (!lead[e]) continue;
+                    const int row = r[e];
+                    double acc = s_acc[row];
+                    int j = e * kBlock + (int)threadIdx.x;
+                    while (j < cnt && s_r[j + 1] == row) { acc += s_p[j]; ++j; }
+                    s_acc[row] = acc;
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) atomicAdd(prog + k, 1u);                             // (a pacing hint, not a synchronisation: no data depends on it)
+        }
+        const long long row0 = (long long)b * RB;
+        for (int i = threadIdx.x; i < RB; i += kBlock) if (row0 + i < rows) __builtin_nontemporal_store(s_acc[i], y + row0 + i);
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- V4: V3 with TH threads per workgroup and the next chunk's entries prefetched
 // (the loads of chunk n + 1 are issued before the gathers of chunk n: entry streams from HBM and gathers from L2 in flight together)
 template <int RB, int E, int TH, int ABL = 0>
@@ -543,6 +621,28 @@ int main(int argc, char** argv)
         run(name, [&] { kernel<<<dim3(g), dim3(TH), 0, 0>>>(dx, dy, d3v, d3p, d3s, nB, T, width, shift, rows); }, exact);
         CK(hipFree(d3v)); CK(hipFree(d3p)); CK(hipFree(d3s));
     };
+    if (getenv("TILE_LAB_V5")) {       // V3 with the soft lockstep of an XCD's workgroups
+        run("V1b production ordering (12 B entries)", PASSES(pass_v1b<<<g, dim3(kBlock), 0, 0>>>(dx, dy, dv, dp, dh, hdrBase[(size_t)t], kb, ke, t * width, shift, (const int*)nullptr)), true);
+        auto run_v5 = [&](auto kernel, const char* name, int RB, int wgs, int perMille) {
+            std::vector<double> v3v; std::vector<unsigned> v3p; std::vector<int> v3s;
+            const int nB = build_v3(RB, v3v, v3p, v3s);
+            double* d3v; unsigned* d3p; int* d3s; unsigned* dprog;
+            const int g = (wgs < nB ? wgs : nB) & ~7;
+            const int rounds = (nB + g - 1) / g;
+            const size_t progN = (size_t)8 * rounds * T;
+            CK(hipMalloc(&d3v, nnz * 8)); CK(hipMalloc(&d3p, nnz * 4)); CK(hipMalloc(&d3s, v3s.size() * 4)); CK(hipMalloc(&dprog, progN * 4));
+            CK(hipMemcpy(d3v, v3v.data(), nnz * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d3p, v3p.data(), nnz * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d3s, v3s.data(), v3s.size() * 4, hipMemcpyHostToDevice));
+            run(name, [&] { CK(hipMemsetAsync(dprog, 0, progN * 4, 0)); kernel<<<dim3(g), dim3(kBlock), 0, 0>>>(dx, dy, d3v, d3p, d3s, nB, T, width, shift, rows, dprog, perMille); }, true);
+            CK(hipFree(d3v)); CK(hipFree(d3p)); CK(hipFree(d3s)); CK(hipFree(dprog));
+        };
+        run_v5(pass_v5<4096, 8, 0>, "V5 RB 4096 / 2048, 512 wgs, same tile, all of the XCD", 4096, 512, 1000);
+        run_v5(pass_v5<4096, 8, 0>, "V5 RB 4096 / 2048, 512 wgs, same tile, 3/4 of the XCD", 4096, 512, 750);
+        run_v5(pass_v5<4096, 8, 1>, "V5 RB 4096 / 2048, 512 wgs, one tile of slack, all", 4096, 512, 1000);
+        run_v5(pass_v5<4096, 8, 0>, "V5 RB 4096 / 2048, 768 wgs, same tile, all", 4096, 768, 1000);
+        run_v5(pass_v5<2048, 4, 0>, "V5 RB 2048 / 1024, 1280 wgs, same tile, all", 2048, 1280, 1000);
+        run_v5(pass_v5<8192, 4, 0>, "V5 RB 8192 / 1024, 512 wgs, same tile, all", 8192, 512, 1000);
+        return 0;
+    }
     if (getenv("TILE_LAB_V3_ONE")) {   // the one row-block-persistent variant, for counter passes
         run_v3(pass_v3<4096, 8>, "V3 row blocks of 4096, 2048-entry chunks, 512 wgs", 4096, 512, true);
         return 0;
