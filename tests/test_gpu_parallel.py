@@ -677,3 +677,54 @@ def test_ranks_without_rows(oracle, mgcg_env):
         assert it == ref["iteration"] and resid == res[0][4]
     assert [r[1] for r in res] == [0, 0, 0, 3]
     assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
+
+
+@pytest.mark.parametrize("world,dims,nu_coarse", [(2, (8, 8, 32), 4), (3, (8, 4, 48), 2), (2, (16, 8, 32), 1), (4, (8, 8, 64), 3)])
+def test_deep_halo_cycle_on_variable_coefficients(oracle, mgcg_env, world, dims, nu_coarse):
+    """The deep-halo cycle away from its comfortable case: a matrix with varying values (D A D: no uniform diagonal, so every level keeps
+    STORED iterates on the extended planes, multiplies with its D^-1 array and uses the neighbours' matrix rows, copied at set-up, for what they
+    really hold) and coarse-sweep counts 1-4 (the depth of the coarsest level's halo).  z = M^-1 r must equal the single-domain oracle's bit
+    for bit, the PCG its iteration count and -- with the sums in the reference's order -- its trace and x."""
+    import scipy.sparse as sp
+    from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu
+
+    mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    mgcg_env.setenv("MGCG_DOT_ORDER", "1")
+    s0 = problems.poisson(*dims)
+    rng = np.random.default_rng(8)
+    d = sp.diags(1.0 + rng.random(s0.Count))
+    A = (d @ s0.to_scipy() @ d).tocsr()
+    A.sort_indices()
+    s = problems.LinearSystem(A.data.copy(), A.indices.astype(np.int32), A.indptr.astype(np.int32), np.zeros(s0.Count), rng.standard_normal(s0.Count), "scaled", grid=s0.grid)
+    M = oracle.Multigrid(s, levels=3, nu_coarse=nu_coarse)
+    off = oracle.partition(s.Count, world)
+    ref = M.pcg(rule=oracle.RULE_CSHARP, max_iteration=400, trace=True, offsets=off)
+    rvec = rng.standard_normal(s.Count)
+    zref = M.apply(rvec)
+
+    def make_rank(rank, comm):
+        cg = ConjugateGradientMgRankGpu(s.Count, 7, 0, 400, 1e-8, s.grid, rank=rank, world=world, comm=comm, device=rank, levels=3, nuCoarse=nu_coarse).load(s)
+        cg.Initialize()
+        cg.Setup()
+        o, c = cg.part.offset, cg.part.count
+        z = cg.Apply(rvec[o: o + c])
+        folds_apply = _lib.lib().MgcgLastVcycleFolds()
+        cg.Solve(trace=True)
+        folds_solve = _lib.lib().MgcgLastVcycleFolds()
+        cg.Read()
+        out = (o, c, z, cg.x[o: o + c].copy(), cg.Iteration, cg.trace, folds_apply, folds_solve)
+        cg.Dispose()
+        return out
+
+    res = _run_ranks_in_threads(world, make_rank)
+    x, z = np.zeros(s.Count), np.zeros(s.Count)
+    deep_on = os.environ.get("MGCG_DEEP_HALO", "1") != "0"
+    for o, c, zs, xs, it, tr, fa, fs in res:
+        z[o: o + c] = zs
+        x[o: o + c] = xs
+        assert it == ref["iteration"]
+        assert np.array_equal(tr, ref["trace"])
+        assert bool(fa & 4) == deep_on and bool(fs & 4) == deep_on, (fa, fs)      # the deep-halo cycle ran ...
+        assert not (fs & 8)                                                      # ... on stored iterates: no uniform diagonal to fold with
+    assert np.array_equal(z, zref)
+    assert np.array_equal(x, ref["x"])
