@@ -1086,6 +1086,32 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     int* dErr = nullptr;
     int* dmm = nullptr;
     bool ok = MGCG_HIP(hipMalloc((void**)&dErr, sizeof(int))) && MGCG_HIP(hipMemsetAsync(dErr, 0, sizeof(int), s)) && MGCG_HIP(hipMalloc((void**)&dmm, 2 * sizeof(int)));
+    // Galerkin matrix of a level from its finer one (two passes: row lengths, then entries).  Whatever it allocated stays in L for MgDestroy.
+    auto coarse_matrix = [&](MgLevel& L, const MgLevel& F) -> bool {
+        L.ownsMatrix = true;
+        int* counts = nullptr;
+        bool good = MGCG_HIP(hipMalloc((void**)&L.rowOffsets, sizeof(int) * (size_t)(L.n + 1))) && MGCG_HIP(hipMalloc((void**)&counts, sizeof(int) * (size_t)(L.n > 0 ? L.n : 1)));
+        std::vector<int> h((size_t)L.n + 1);
+        int err = 0;
+        if (good) {
+            launch_galerkin(s, F.nx, F.ny, F.nz, F.z0, F.z1, F.elements, F.rowOffsets, F.columnIndeces, sigma, nullptr, counts, nullptr, nullptr, dErr);
+            good = MGCG_HIP(hipMemcpyAsync(h.data() + 1, counts, sizeof(int) * (size_t)L.n, hipMemcpyDeviceToHost, s)) &&
+                   MGCG_HIP(hipMemcpyAsync(&err, dErr, sizeof(int), hipMemcpyDeviceToHost, s)) && MGCG_HIP(hipStreamSynchronize(s));
+        }
+        if (counts) (void)hipFree(counts);
+        if (!good) return false;
+        if (err) { set_error("MgSetup: matrix is not a 27-point-neighbourhood operator on the %dx%dx%d grid", F.nx, F.ny, F.nz); return false; }
+        h[0] = 0;
+        long long run = 0;
+        for (long long i = 1; i <= L.n; ++i) { run += h[(size_t)i]; h[(size_t)i] = (int)run; }   // exclusive scan on the host (set-up only)
+        L.nnz = run;
+        good = MGCG_HIP(hipMemcpyAsync(L.rowOffsets, h.data(), sizeof(int) * (size_t)(L.n + 1), hipMemcpyHostToDevice, s)) &&
+               MGCG_HIP(hipMalloc((void**)&L.elements, sizeof(double) * (size_t)(L.nnz > 0 ? L.nnz : 1))) &&
+               MGCG_HIP(hipMalloc((void**)&L.columnIndeces, sizeof(int) * (size_t)(L.nnz > 0 ? L.nnz : 1)));
+        if (good) launch_galerkin(s, F.nx, F.ny, F.nz, F.z0, F.z1, F.elements, F.rowOffsets, F.columnIndeces, sigma, L.rowOffsets, nullptr, L.elements, L.columnIndeces, dErr);
+        return MGCG_HIP(hipStreamSynchronize(s)) && good;   // (h must outlive the copy)
+    };
+    bool agreedToLeave = false;
     for (int l = 0; ok && l < levels; ++l) {
         MgLevel L;
         if (l == 0) {
@@ -1104,33 +1130,7 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
         L.nGlobal = (long long)L.nx * L.ny * L.nz;
         L.n = (long long)L.nx * L.ny * (L.z1 - L.z0);
         L.offset = (long long)L.nx * L.ny * L.z0;
-        if (l > 0) {
-            const MgLevel& F = mg->lv[l - 1];
-            L.ownsMatrix = true;
-            int* counts = nullptr;
-            ok = ok && MGCG_HIP(hipMalloc((void**)&L.rowOffsets, sizeof(int) * (size_t)(L.n + 1)));
-            ok = ok && MGCG_HIP(hipMalloc((void**)&counts, sizeof(int) * (size_t)L.n));
-            if (!ok) break;
-            launch_galerkin(s, F.nx, F.ny, F.nz, F.z0, F.z1, F.elements, F.rowOffsets, F.columnIndeces, sigma, nullptr, counts, nullptr, nullptr, dErr);
-            std::vector<int> h((size_t)L.n + 1);
-            ok = ok && MGCG_HIP(hipMemcpyAsync(h.data() + 1, counts, sizeof(int) * (size_t)L.n, hipMemcpyDeviceToHost, s));
-            int err = 0;
-            ok = ok && MGCG_HIP(hipMemcpyAsync(&err, dErr, sizeof(int), hipMemcpyDeviceToHost, s));
-            ok = ok && MGCG_HIP(hipStreamSynchronize(s));
-            (void)hipFree(counts);
-            if (!ok) break;
-            if (err) { set_error("MgSetup: matrix is not a 27-point-neighbourhood operator on the %dx%dx%d grid", F.nx, F.ny, F.nz); ok = false; (void)hipFree(L.rowOffsets); break; }
-            h[0] = 0;
-            long long run = 0;
-            for (long long i = 1; i <= L.n; ++i) { run += h[(size_t)i]; h[(size_t)i] = (int)run; }   // exclusive scan on the host (set-up only)
-            L.nnz = run;
-            ok = ok && MGCG_HIP(hipMemcpyAsync(L.rowOffsets, h.data(), sizeof(int) * (size_t)(L.n + 1), hipMemcpyHostToDevice, s));
-            ok = ok && MGCG_HIP(hipMalloc((void**)&L.elements, sizeof(double) * (size_t)(L.nnz > 0 ? L.nnz : 1)));
-            ok = ok && MGCG_HIP(hipMalloc((void**)&L.columnIndeces, sizeof(int) * (size_t)(L.nnz > 0 ? L.nnz : 1)));
-            if (!ok) break;
-            launch_galerkin(s, F.nx, F.ny, F.nz, F.z0, F.z1, F.elements, F.rowOffsets, F.columnIndeces, sigma, L.rowOffsets, nullptr, L.elements, L.columnIndeces, dErr);
-            ok = ok && MGCG_HIP(hipStreamSynchronize(s));   // h must outlive the copy
-        }
+        if (l > 0) ok = ok && coarse_matrix(L, mg->lv[l - 1]);
         ok = ok && MGCG_HIP(hipMalloc((void**)&L.dinv, sizeof(double) * (size_t)L.n));
         ok = ok && MGCG_HIP(hipMalloc((void**)&L.xa, sizeof(double) * (size_t)L.nGlobal));
         ok = ok && MGCG_HIP(hipMalloc((void**)&L.r, sizeof(double) * (size_t)L.n));
@@ -1159,10 +1159,17 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
             ok = ok && MGCG_HIP(hipMemcpyAsync(out, dmm, sizeof(out), hipMemcpyDeviceToHost, s));
             ok = ok && MGCG_HIP(hipStreamSynchronize(s));
             L.minJ = out[0]; L.maxJ = out[1];
-            if (ok) { L.halo = halo_plan_create(comm, L.nGlobal, L.offset, L.n, L.minJ, L.maxJ); ok = L.halo != nullptr; }
+        }
+        if (multi) {
+            // the plan and the overlap rule are collective: a rank whose level failed (its slab's matrix is not a stencil operator, an allocation)
+            // says so first, and every rank leaves the set-up in the same place
+            ok = comm_agree(comm, ok, "MgSetup");
+            if (ok) { L.halo = halo_plan_create(comm, L.nGlobal, L.offset, L.n, L.minJ, L.maxJ); ok = comm_agree(comm, L.halo != nullptr, "MgSetup"); }
+            agreedToLeave = !ok;                                // (every rank holds the same verdict: no second agreement behind the loop)
             ok = ok && plan_overlap(s, comm, mg->multi, L.rowOffsets, L.columnIndeces, L.n, L.offset, &L.overlap, &L.interior0, &L.interior1, cublas->ws.devInts + 6, L.halo, L.xa, L.nGlobal);
         }
-        mg->lv.push_back(L);
+        mg->lv.push_back(L);                                    // (also a level that failed: MgDestroy frees what it had allocated)
+        if (!ok) break;
         mg->levels = (int)mg->lv.size();
     }
     ok = ok && MGCG_HIP(hipStreamSynchronize(s));
@@ -1179,7 +1186,9 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
         const int d = (l == mg->levels - 1) ? nuCoarse : 2;
         if (L.nz <= 1 || (L.z1 - L.z0) < d || (L.z0 & 1) || ((L.z1 - L.z0) & 1)) wantDeep = false;
     }
-    if (multi && !comm_agree(comm, ok, "MgSetup")) { MgDestroy(mg); return nullptr; }
+    // (a rank that failed outside the agreements above -- before the loop, or in the local tail of a level -- says so here; its peers hear it in
+    //  their next agreement, which is this one or the next level's first)
+    if (multi && (agreedToLeave || !comm_agree(comm, ok, "MgSetup"))) { MgDestroy(mg); return nullptr; }
     for (int l = 1; ok && wantDeep && l < mg->levels; ++l) {
         MgLevel& L = mg->lv[(size_t)l];
         const long long plane = (long long)L.nx * L.ny;
@@ -1275,7 +1284,7 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
         // the plan that brings the `deep` planes of b (collective; every rank reaches it with the same verdict)
         if (!comm_agree(comm, ok, "MgSetup")) { ok = false; break; }
         L.bHalo = halo_plan_create(comm, L.nGlobal, L.offset, L.n, (int)L.extBase, (int)(L.extBase + L.extRows - 1));
-        if (!L.bHalo) { ok = false; break; }
+        if (!comm_agree(comm, L.bHalo != nullptr, "MgSetup")) { ok = false; break; }
     }
     mg->deep = ok && wantDeep;
     mg->deepFolds = mg->deep && foldsEverywhere;

@@ -258,6 +258,58 @@ def test_a_rank_with_unusable_arguments_leaves_together_with_its_peers(oracle, m
         assert it == ref["iteration"]
 
 
+def test_a_rank_whose_slab_is_not_a_stencil_leaves_the_multigrid_set_up_together_with_its_peers(mgcg_env):
+    """The multigrid set-up is collective level by level (halo plans, the overlap rule, the deep-halo rows): a rank whose own slab fails
+    INSIDE it -- here rank 1's matrix has one entry three columns from the diagonal, which the Galerkin product refuses -- tells its peers in
+    the level's agreement; every rank comes back with NULL (the healthy one names the reason as another rank's), nobody stays blocked in a
+    halo plan, and the same communicator then sets up and solves the intact system."""
+    import threading
+
+    from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu
+
+    world, n = 2, 16
+    mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    L = _lib.lib()
+    group = L.MgcgLoopbackCreate(world)
+    out = [None] * world
+
+    def body(rank):
+        L.SetDevice(rank)
+        comm = L.MgcgCommInitLoopback(group, rank)
+        cg = ConjugateGradientMgRankGpu(n**3, 7, 0, 200, 1e-8, (n, n, n), rank=rank, world=world, comm=comm, device=rank, rule=_lib.RULE_NATIVE, levels=3)
+        cg.InitializePoisson(n, n, n)
+        cols = cg.vectorColumnIndeces.to_numpy()
+        good = cols.copy()
+        if rank == 1:
+            ro = cg.vectorRowOffsets.to_numpy(cg.part.count + 1)
+            row = 5 * n * n + 5 * n + 5                             # an inner row of the slab: its last entry is the +z neighbour
+            k = ro[row + 1] - 1
+            cols[k] = cg.part.offset + row + 3                      # ... now a point three cells along x
+            cg.vectorColumnIndeces.CopyFrom(cols, cols.size)
+        try:
+            cg.Setup()
+            msg = "no error"
+        except Exception as ex:     # noqa: BLE001
+            msg = str(ex)
+        L.MgcgClearLastError()
+        cg.vectorColumnIndeces.CopyFrom(good, good.size)
+        cg.Setup()
+        cg.Solve()
+        out[rank] = (msg, cg.Iteration, cg.Residual)
+        cg.Dispose()
+        L.MgcgCommDestroy(comm)
+
+    ts = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ts), "a rank is still blocked in a collective of the set-up"
+    L.MgcgLoopbackDestroy(group)
+    assert "27-point" in out[1][0] and "another rank failed" in out[0][0], out
+    assert out[0][1] == out[1][1] > 0 and out[0][2] == out[1][2], out
+
+
 def test_comm_probe_prices_the_steps_of_the_several_ranks_path():
     """MgcgCommProbe (tools/slab_latency.py): every kind of step returns a finite, positive time on a one-rank RCCL communicator and on
     a communicator without a transport; bad arguments are refused."""
