@@ -335,6 +335,22 @@ bool comm_agree(MgcgComm* c, bool localOk, const char* who)
     return true;
 }
 
+// Do all ranks say yes?  One all-reduce like comm_agree, but a "no" is an answer, not a failure: nobody's error text is touched.
+// false: the all-reduce itself failed (*all is then false).
+bool comm_all(MgcgComm* c, bool mine, bool* all)
+{
+    *all = mine;
+    if (!c || c->nranks <= 1) return true;
+    *all = false;
+    double no = mine ? 0.0 : 1.0;
+    bool ok = MGCG_HIP(hipMemcpyAsync(c->scratch, &no, sizeof(double), hipMemcpyHostToDevice, c->stream)) && MGCG_HIP(hipStreamSynchronize(c->stream));
+    ok = comm_allreduce_sum(c, c->scratch, 1, c->stream) && ok;
+    ok = ok && MGCG_HIP(hipMemcpyAsync(&no, c->scratch, sizeof(double), hipMemcpyDeviceToHost, c->stream)) && MGCG_HIP(hipStreamSynchronize(c->stream));
+    if (!ok) return false;
+    *all = (no == 0.0);
+    return true;
+}
+
 HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long long countLocal, int minJ, int maxJ,
                            const int* columnIndeces, long long nnz, bool reuse, bool localOk)
 {

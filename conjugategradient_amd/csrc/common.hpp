@@ -449,6 +449,7 @@ HaloPlan* halo_plan_create(MgcgComm* c, long long count, long long offset, long 
 // localOk (reuse plans only, several ranks): this rank's verdict on its own arguments, folded into the plan's one all-reduce -- when any
 // rank says false, every rank gets nullptr and nobody enters the solve's collectives.
 bool comm_agree(MgcgComm* c, bool localOk, const char* who);
+bool comm_all(MgcgComm* c, bool mine, bool* all);                 // do all ranks say yes?  (a "no" is not an error)
 // set-up only (collective): host vectors to and from ranks rank - 1 and rank + 1
 bool comm_neighbour_exchange_host(MgcgComm* c, const std::vector<double>& toLower, const std::vector<double>& toUpper,
                                   std::vector<double>& fromLower, std::vector<double>& fromUpper, bool localOk = true);   // the same agreement as a call of its own (set-up paths)

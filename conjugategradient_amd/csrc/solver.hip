@@ -67,6 +67,8 @@ struct MgcgMg {
     double* finalOut = nullptr;
     bool finalWritten = false;
     bool deep = false;                     // every level >= 1 has its deep halo (decided at set-up, the same on every rank)
+    bool deep0 = false;                    // ... and the finest level may form its first iterate per gather from the EXCHANGED right-hand side: every rank's
+                                           // rows have one and the same diagonal and take the row-tile kernel (agreed at set-up: it decides WHAT the level exchanges)
     // deep-halo cycle, finest level: the PCG loop keeps its residual r (the cycle's right-hand side) in this buffer -- the slab's rows with
     // room for one grid plane either side -- so that ONE exchange brings r's halo planes and every sweep of the level can form its iterate
     // per gather, exactly as the single-rank cycle does (no stored first sweep, no boundary zones, no separate boundary launches)
@@ -355,7 +357,7 @@ static bool mg_vcycle(MgcgMg* mg, int l, const double* b, double* x0, double* x1
     // Deep-halo cycle with the right-hand side in the loop's extended buffer (b = rExt + plane: one grid plane of room either side): ONE
     // exchange brings b's halo planes, after which every row of the rank -- boundary rows included -- forms x_1 per gather of the residual
     // pass and x_1 + P e per gather of the post-smoothing sweep: the single-rank cycle's kernels, one launch each, no zones.
-    if (l == 0 && mg->deep && mg->rExt != nullptr && b == mg->rExt + (long long)L.nx * L.ny && mayFold && (L.dcsr == nullptr || !L.dcsr->usable) &&
+    if (l == 0 && mg->deep && mg->deep0 && mg->rExt != nullptr && b == mg->rExt + (long long)L.nx * L.ny && mayFold && (L.dcsr == nullptr || !L.dcsr->usable) &&
         L.nx >= 2 && log2_exact(L.nx) >= 1 && log2_exact(L.ny) >= 0 && L.nGlobal < 0x7fffffffLL && tuning().foldUp.load(std::memory_order_relaxed) != 0) {
         SpmvArgs a{};
         a.elements = L.elements; a.rowOffsets = L.rowOffsets; a.columnIndeces = L.columnIndeces; a.x = b - L.offset; a.y = L.r;
@@ -1291,10 +1293,24 @@ MgcgMg* MgSetupParallel(MgcgComm* comm, MgcgBlas* cublas, MgcgSparse* cusparse,
     if (mg->deep) {       // the loop's residual with room for one grid plane either side (SolveMgParallel keeps r there)
         const MgLevel& L0 = mg->lv[0];
         const size_t len = (size_t)(L0.n + 2LL * L0.nx * L0.ny);
-        if (!MGCG_HIP(hipMalloc((void**)&mg->rExt, sizeof(double) * len)) || !MGCG_HIP(hipMemsetAsync(mg->rExt, 0, sizeof(double) * len, s)) || !MGCG_HIP(hipStreamSynchronize(s))) {
-            if (mg->rExt) { (void)hipFree(mg->rExt); mg->rExt = nullptr; }      // (not fatal: the cycle then keeps its boundary zones on the finest level)
-            (void)hipGetLastError();
-        }
+        ok = MGCG_HIP(hipMalloc((void**)&mg->rExt, sizeof(double) * len)) && MGCG_HIP(hipMemsetAsync(mg->rExt, 0, sizeof(double) * len, s)) && MGCG_HIP(hipStreamSynchronize(s));
+    }
+    // (whether the loop keeps r there decides which exchanges the cycle makes: every rank has the buffer, or the set-up fails on every rank)
+    if (multi && wantDeep && !comm_agree(comm, ok, "MgSetup")) ok = false;
+    // The finest level of the cycle exchanges its right-hand side and forms x_1 = omega d b per gather -- for the neighbours' columns with the
+    // rank's OWN d -- or it exchanges the stored x_1: a decision every rank must take alike, and only when all of them hold the same diagonal.
+    if (ok && multi && wantDeep) {
+        const MgLevel& L0 = mg->lv[0];
+        SpmvArgs probe{}; probe.elements = L0.elements; probe.columnIndeces = L0.columnIndeces; probe.elementsCount = (int)L0.nnz; probe.rowCount = (int)L0.n;
+        bool mine = L0.dinvUniform && (L0.dcsr == nullptr || !L0.dcsr->usable) && spmv_takes_rowtile(probe, L0.cfg);
+        const std::vector<double> say{ mine ? 1.0 : 0.0, L0.dinvScalar };
+        std::vector<double> fromLower, fromUpper;
+        ok = comm_neighbour_exchange_host(comm, say, say, fromLower, fromUpper, true);
+        for (const std::vector<double>* v : { &fromLower, &fromUpper })
+            if (!v->empty()) mine = mine && v->size() == 2 && (*v)[0] == 1.0 && (*v)[1] == L0.dinvScalar;
+        bool all = false;
+        ok = ok && comm_all(comm, mine, &all);
+        mg->deep0 = ok && all;
     }
     if (!ok || mg->levels == 0) { MgDestroy(mg); return nullptr; }
     return mg;

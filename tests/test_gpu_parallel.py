@@ -781,3 +781,58 @@ def test_deep_halo_cycle_on_variable_coefficients(oracle, mgcg_env, world, dims,
         assert not (fs & 8)                                                      # ... on stored iterates: no uniform diagonal to fold with
     assert np.array_equal(z, zref)
     assert np.array_equal(x, ref["x"])
+
+
+@pytest.mark.parametrize("which", ["shifted_upper_half", "scaled_upper_half"])
+def test_deep_halo_cycle_when_the_ranks_hold_different_diagonals(oracle, mgcg_env, which):
+    """What the finest level of the deep-halo cycle exchanges -- its right-hand side, from which x_1 = omega d b is formed per gather with the
+    rank's OWN d, or the stored x_1 -- is decided by all ranks together at set-up, and the per-gather form is taken only when every rank's rows
+    hold one and the same diagonal.  Two ranks; the upper half of the grid (= rank 1's slab) carries A + 3 I (both slabs have a uniform diagonal,
+    but not the same one), or D A D with a random D there (rank 0's diagonal is uniform, rank 1's is not): z = M^-1 r, trace and x must
+    still equal the single-domain oracle's bit for bit, on the stored-iterate form of the finest level (fold bit 8 clear)."""
+    import scipy.sparse as sp
+    from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu
+
+    world, dims = 2, (8, 8, 32)
+    mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    mgcg_env.setenv("MGCG_DOT_ORDER", "1")
+    s0 = problems.poisson(*dims)
+    rng = np.random.default_rng(11)
+    upper = np.arange(s0.Count) >= s0.Count // 2
+    if which == "shifted_upper_half":
+        A = (s0.to_scipy() + sp.diags(np.where(upper, 3.0, 0.0))).tocsr()
+    else:
+        d = sp.diags(np.where(upper, 1.0 + rng.random(s0.Count), 1.0))
+        A = (d @ s0.to_scipy() @ d).tocsr()
+    A.sort_indices()
+    s = problems.LinearSystem(A.data.copy(), A.indices.astype(np.int32), A.indptr.astype(np.int32), np.zeros(s0.Count), rng.standard_normal(s0.Count), which, grid=s0.grid)
+    M = oracle.Multigrid(s, levels=3)
+    off = oracle.partition(s.Count, world)
+    ref = M.pcg(rule=oracle.RULE_CSHARP, max_iteration=400, trace=True, offsets=off)
+    rvec = rng.standard_normal(s.Count)
+    zref = M.apply(rvec)
+
+    def make_rank(rank, comm):
+        cg = ConjugateGradientMgRankGpu(s.Count, 7, 0, 400, 1e-8, s.grid, rank=rank, world=world, comm=comm, device=rank, levels=3).load(s)
+        cg.Initialize()
+        cg.Setup()
+        o, c = cg.part.offset, cg.part.count
+        z = cg.Apply(rvec[o: o + c])
+        cg.Solve(trace=True)
+        folds = _lib.lib().MgcgLastVcycleFolds()
+        cg.Read()
+        out = (o, c, z, cg.x[o: o + c].copy(), cg.Iteration, cg.trace, folds)
+        cg.Dispose()
+        return out
+
+    res = _run_ranks_in_threads(world, make_rank)
+    x, z = np.zeros(s.Count), np.zeros(s.Count)
+    deep_on = os.environ.get("MGCG_DEEP_HALO", "1") != "0"
+    for o, c, zs, xs, it, tr, folds in res:
+        z[o: o + c] = zs
+        x[o: o + c] = xs
+        assert bool(folds & 4) == deep_on and not (folds & 8), folds
+        assert it == ref["iteration"]
+        assert np.array_equal(tr, ref["trace"])
+    assert np.array_equal(z, zref)
+    assert np.array_equal(x, ref["x"])
