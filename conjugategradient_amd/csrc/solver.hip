@@ -258,8 +258,10 @@ static bool mg_smooth(MgcgMg* mg, MgLevel& L, const double* b, double* cur, doub
 //     x_1 = omega D^-1 b on +-nu_c planes, sweep k on +-(nu_c + 1 - k), x_{nu_c} on +-1          -> deep = nu_c
 //   a middle level: x_1 = omega D^-1 b on +-2, residual on the slab, y = x_1 + P e on +-2 (e from below on +-1 of ITS planes = +-2 of these),
 //     post-smoothing sweep on +-1                                                              -> deep = 2
-//   the finest level keeps its one exchange of x_1 before the residual pass (its right-hand side is the caller's local vector); its
-//     post-smoothing sweep finds x_1 in the halo planes from that exchange and adds P e there itself   -> no second exchange.
+//   the finest level has one exchange too: of its right-hand side when that is the loop's r in MgcgMg::rExt and every rank holds the same
+//     uniform diagonal (MgcgMg::deep0, agreed at set-up: x_1 and x_1 + P e are then formed per gather on all rows), else of the stored x_1
+//     before the residual pass -- the post-smoothing sweep then finds x_1 in the halo planes and P e is added there (mg_deep_prolong_halo);
+//     either way                                                                                       -> no second exchange.
 // Per MGCG iteration: SyncP of p + 3 exchanges in the cycle instead of SyncP + 7.  The redundant rows are deep planes on slabs of 32 / 16
 // planes of levels that hold 1/8 and 1/64 of the work.
 static bool mg_deep_level(MgcgMg* mg, int l, const int* done, double** result)
