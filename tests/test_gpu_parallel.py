@@ -607,6 +607,7 @@ def test_partition_of_equal_nonzero_counts_over_loopback(oracle, mgcg_env, world
                                                             (8, (16, 16, 64), 3, 0), (8, (16, 16, 64), 3, 1),    # config 4's shape: 8 z-slabs, 3 levels
                                                             # slabs thick enough for the deep-halo cycle (16 / 8 / 4 planes per rank; 4 coarse sweeps reach 4 planes):
                                                             (2, (8, 8, 32), 3, 0), (3, (16, 8, 48), 3, 0), (4, (16, 16, 64), 3, 0), (2, (8, 8, 16), 2, 0), (3, (8, 12, 24), 2, 0),
+                                                            (2, (16, 16, 64), 4, 0), (3, (16, 8, 96), 4, 0),      # four levels: TWO middle levels hand their halo planes down and up
                                                             (2, (8, 8, 32), 3, 1)])   # (thick slabs with the linear transfer: the deep halo is set up, the cycle must not take it)
 def test_distributed_multigrid_over_loopback(oracle, mgcg_env, world, dims, levels, interpolation):
     """Row-partitioned MGCG (config 4 in miniature): slab-local Galerkin set-up, per-level halo planes, V-cycle
