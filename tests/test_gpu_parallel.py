@@ -784,8 +784,9 @@ def test_deep_halo_cycle_on_variable_coefficients(oracle, mgcg_env, world, dims,
     assert np.array_equal(x, ref["x"])
 
 
+@pytest.mark.parametrize("overlap", [None, "2"])          # "2": rank 0's interior rows fold (uniform diagonal, zones stored), rank 1's may not
 @pytest.mark.parametrize("which", ["shifted_upper_half", "scaled_upper_half"])
-def test_deep_halo_cycle_when_the_ranks_hold_different_diagonals(oracle, mgcg_env, which):
+def test_deep_halo_cycle_when_the_ranks_hold_different_diagonals(oracle, mgcg_env, which, overlap):
     """What the finest level of the deep-halo cycle exchanges -- its right-hand side, from which x_1 = omega d b is formed per gather with the
     rank's OWN d, or the stored x_1 -- is decided by all ranks together at set-up, and the per-gather form is taken only when every rank's rows
     hold one and the same diagonal.  Two ranks; the upper half of the grid (= rank 1's slab) carries A + 3 I (both slabs have a uniform diagonal,
@@ -797,6 +798,8 @@ def test_deep_halo_cycle_when_the_ranks_hold_different_diagonals(oracle, mgcg_en
     world, dims = 2, (8, 8, 32)
     mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
     mgcg_env.setenv("MGCG_DOT_ORDER", "1")
+    if overlap is not None:
+        mgcg_env.setenv("MGCG_OVERLAP", overlap)
     s0 = problems.poisson(*dims)
     rng = np.random.default_rng(11)
     upper = np.arange(s0.Count) >= s0.Count // 2
