@@ -461,7 +461,8 @@ int MgcgLastOverlapTimes(double microseconds[2]);
  * of the post-smoothing sweep as well (V(1,1), plain CSR, uniform diagonal, power-of-two nx and ny), bit 2 (4) = several ranks: the
  * deep-halo cycle ran (one exchange per coarse level instead of one per pass; knob deep_halo), bit 3 (8) = ... and the finest level's
  * right-hand side carried its halo planes, so every level ran the single-rank folded kernels (SolveMgParallel keeps r in the hierarchy's
- * buffer; MgApply on a caller's vector cannot).  Schedules only: the results are bit-identical either way (MGCG_NO_FOLD=1 /
+ * buffer; MgApply on a caller's vector cannot; taken only when ALL ranks agreed at set-up that their rows hold one and the same uniform
+ * diagonal -- the form decides what the level exchanges, r or the stored first sweep).  Schedules only: the results are bit-identical either way (MGCG_NO_FOLD=1 /
  * MGCG_FOLD_UP=0 switch the folds off; MGCG_FOLD_UP=1 takes the second one on levels of any size, by default it is taken up to 100 M rows). */
 int MgcgLastVcycleFolds(void);
 /* The calling thread's last halo exchange: returns 1 if it moved per-peer index lists (unstructured slices: only the entries
