@@ -608,6 +608,7 @@ def test_partition_of_equal_nonzero_counts_over_loopback(oracle, mgcg_env, world
                                                             # slabs thick enough for the deep-halo cycle (16 / 8 / 4 planes per rank; 4 coarse sweeps reach 4 planes):
                                                             (2, (8, 8, 32), 3, 0), (3, (16, 8, 48), 3, 0), (4, (16, 16, 64), 3, 0), (2, (8, 8, 16), 2, 0), (3, (8, 12, 24), 2, 0),
                                                             (2, (16, 16, 64), 4, 0), (3, (16, 8, 96), 4, 0),      # four levels: TWO middle levels hand their halo planes down and up
+                                                            (8, (8, 8, 256), 3, 0),                               # eight ranks with slabs thick enough (config 4's rank count on the deep-halo cycle)
                                                             (2, (8, 8, 32), 3, 1)])   # (thick slabs with the linear transfer: the deep halo is set up, the cycle must not take it)
 def test_distributed_multigrid_over_loopback(oracle, mgcg_env, world, dims, levels, interpolation):
     """Row-partitioned MGCG (config 4 in miniature): slab-local Galerkin set-up, per-level halo planes, V-cycle
@@ -733,7 +734,8 @@ def test_ranks_without_rows(oracle, mgcg_env):
     assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
 
 
-@pytest.mark.parametrize("world,dims,nu_coarse", [(2, (8, 8, 32), 4), (3, (8, 4, 48), 2), (2, (16, 8, 32), 1), (4, (8, 8, 64), 3)])
+@pytest.mark.parametrize("world,dims,nu_coarse", [(2, (8, 8, 32), 4), (3, (8, 4, 48), 2), (2, (16, 8, 32), 1), (4, (8, 8, 64), 3),
+                                                  (2, (8, 8, 16), 2)])       # the coarsest slab exactly as thick as its halo (2 planes)
 def test_deep_halo_cycle_on_variable_coefficients(oracle, mgcg_env, world, dims, nu_coarse):
     """The deep-halo cycle away from its comfortable case: a matrix with varying values (D A D: no uniform diagonal, so every level keeps
     STORED iterates on the extended planes, multiplies with its D^-1 array and uses the neighbours' matrix rows, copied at set-up, for what they
