@@ -1,11 +1,12 @@
 #!/bin/bash
 # The GPU suite under EVERY knob the library keeps (include/MgcgGpu.h: the tuning list): each must leave every result unchanged.
-#   bash conjugategradient_amd/tools/pytest_env_modes.sh OUT.log [a|b|c|d|e]
+#   bash conjugategradient_amd/tools/pytest_env_modes.sh OUT.log [a|b|c|d|e] ["FILES"]
+# FILES: the test files to run instead of the whole suite (e.g. "tests/test_gpu_parallel.py tests/test_gpu_mg.py": all sixteen settings then fit one call).
 # (verbose, virtual_devices, force_multirank and fail_comm_init are set by the tests themselves.)
 OUT=$1
 mkdir -p "$(dirname "$OUT")"
 : > "$OUT"
-SELECT="tests"
+SELECT=${3:-tests}
 run() { echo "== $* ($SELECT)" >> "$OUT"; env "$@" timeout -k 10 1100 python -m pytest $SELECT -m gpu -q -p no:cacheprovider 2>&1 | tail -n 3 >> "$OUT"; }
 # (parts of at most four runs, so that each fits one gpurun call of 20 minutes -- the suite with every sum in the reference's order, part e,
 #  takes a call of its own: its full-size solves run serial sums; no second argument = everything)
@@ -36,7 +37,7 @@ fi
 if [[ $PART == *e* ]]; then
 # every sum in the reference's order: one serial sum of 1.3e8 terms takes half a second, so the full-size SOLVES (hundreds of iterations at
 # 512^3: tests/test_gpu_fullsize.py, which has its own legs in this mode) are left out of this pass
-SELECT="tests --ignore=tests/test_gpu_fullsize.py"
+if [[ -z "$3" ]]; then SELECT="tests --ignore=tests/test_gpu_fullsize.py"; fi
 run MGCG_DOT_ORDER=1
 fi
 cat "$OUT"
