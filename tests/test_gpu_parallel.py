@@ -787,24 +787,26 @@ def test_deep_halo_cycle_on_variable_coefficients(oracle, mgcg_env, world, dims,
 
 
 @pytest.mark.parametrize("overlap", [None, "2"])          # "2": rank 0's interior rows fold (uniform diagonal, zones stored), rank 1's may not
-@pytest.mark.parametrize("which", ["shifted_upper_half", "scaled_upper_half"])
-def test_deep_halo_cycle_when_the_ranks_hold_different_diagonals(oracle, mgcg_env, which, overlap):
+@pytest.mark.parametrize("world,which", [(2, "shifted_upper_half"), (2, "scaled_upper_half"),
+                                         (3, "shifted_upper_half")])      # three ranks, the last one differs: rank 0's MIDDLE level folds (its own and its
+                                                                          # neighbour's planes hold one diagonal), rank 1's and rank 2's keep stored iterates
+def test_deep_halo_cycle_when_the_ranks_hold_different_diagonals(oracle, mgcg_env, world, which, overlap):
     """What the finest level of the deep-halo cycle exchanges -- its right-hand side, from which x_1 = omega d b is formed per gather with the
     rank's OWN d, or the stored x_1 -- is decided by all ranks together at set-up, and the per-gather form is taken only when every rank's rows
-    hold one and the same diagonal.  Two ranks; the upper half of the grid (= rank 1's slab) carries A + 3 I (both slabs have a uniform diagonal,
+    hold one and the same diagonal.  The last rank's slab carries A + 3 I (both slabs have a uniform diagonal,
     but not the same one), or D A D with a random D there (rank 0's diagonal is uniform, rank 1's is not): z = M^-1 r, trace and x must
     still equal the single-domain oracle's bit for bit, on the stored-iterate form of the finest level (fold bit 8 clear)."""
     import scipy.sparse as sp
     from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu
 
-    world, dims = 2, (8, 8, 32)
+    dims = (8, 8, 16 * world)
     mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
     mgcg_env.setenv("MGCG_DOT_ORDER", "1")
     if overlap is not None:
         mgcg_env.setenv("MGCG_OVERLAP", overlap)
     s0 = problems.poisson(*dims)
     rng = np.random.default_rng(11)
-    upper = np.arange(s0.Count) >= s0.Count // 2
+    upper = np.arange(s0.Count) >= s0.Count * (world - 1) // world          # the last rank's slab
     if which == "shifted_upper_half":
         A = (s0.to_scipy() + sp.diags(np.where(upper, 3.0, 0.0))).tocsr()
     else:
