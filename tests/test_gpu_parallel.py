@@ -844,3 +844,59 @@ def test_deep_halo_cycle_when_the_ranks_hold_different_diagonals(oracle, mgcg_en
         assert np.array_equal(tr, ref["trace"])
     assert np.array_equal(z, zref)
     assert np.array_equal(x, ref["x"])
+
+
+@pytest.mark.parametrize("dot_order", ["0", "1"])
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_multigrid_on_a_27_point_finest_operator(oracle, mgcg_env, world, dot_order):
+    """The hierarchy's contract is "a 27-point-neighbourhood operator on the grid", not "a 7-point one": a finest level with 27 entries per
+    row (27 I - K, K = every neighbour of the 3 x 3 x 3 cube) takes none of the short-row forms -- no row-tile kernel, so no per-gather
+    iterates on any level of any rank, rows summed by several lanes in the default mode -- and its Galerkin levels have 27 entries too.  One,
+    two (deep-halo cycle) and four ranks (slabs too thin for it: one exchange per pass) against the single-domain oracle: bit for bit with
+    the sums in the reference's order, to the documented tolerances otherwise."""
+    import scipy.sparse as sp
+    from conjugategradient_amd.parallel import ConjugateGradientMgRankGpu
+
+    nx, ny, nz = 8, 8, 32
+    mgcg_env.setenv("MGCG_VIRTUAL_DEVICES", str(world))
+    mgcg_env.setenv("MGCG_DOT_ORDER", dot_order)
+    ones = lambda n: sp.diags([np.ones(n - 1), np.ones(n), np.ones(n - 1)], [-1, 0, 1])      # noqa: E731
+    A = (27.0 * sp.identity(nx * ny * nz) - sp.kron(ones(nz), sp.kron(ones(ny), ones(nx)))).tocsr()
+    A.sort_indices()
+    assert np.diff(A.indptr).max() == 27
+    rng = np.random.default_rng(5)
+    s = problems.LinearSystem(A.data.copy(), A.indices.astype(np.int32), A.indptr.astype(np.int32), np.zeros(A.shape[0]), rng.standard_normal(A.shape[0]), "op27", grid=(nx, ny, nz))
+    M = oracle.Multigrid(s, levels=3)
+    ref = M.pcg(rule=oracle.RULE_CSHARP, max_iteration=400, trace=True, offsets=oracle.partition(s.Count, world))
+    rvec = rng.standard_normal(s.Count)
+    zref = M.apply(rvec)
+
+    def make_rank(rank, comm):
+        cg = ConjugateGradientMgRankGpu(s.Count, 27, 0, 400, 1e-8, s.grid, rank=rank, world=world, comm=comm if world > 1 else None, device=rank, levels=3).load(s)
+        cg.Initialize()
+        cg.Setup()
+        assert cg.levels == M.levels
+        o, c = cg.part.offset, cg.part.count
+        z = cg.Apply(rvec[o: o + c])
+        cg.Solve(trace=True)
+        folds = _lib.lib().MgcgLastVcycleFolds()
+        cg.Read()
+        out = (o, c, z, cg.x[o: o + c].copy(), cg.Iteration, cg.trace, folds)
+        cg.Dispose()
+        return out
+
+    res = _run_ranks_in_threads(world, make_rank)
+    x, z = np.zeros(s.Count), np.zeros(s.Count)
+    for o, c, zs, xs, it, tr, folds in res:
+        z[o: o + c] = zs
+        x[o: o + c] = xs
+        assert not (folds & (1 | 2 | 8)), folds                       # nothing formed per gather: the rows are too long for the row-tile kernel
+        assert bool(folds & 4) == (world == 2 and os.environ.get("MGCG_DEEP_HALO", "1") != "0"), folds
+        assert it == ref["iteration"]
+        if dot_order == "1":
+            assert np.array_equal(tr, ref["trace"])
+    if dot_order == "1":
+        assert np.array_equal(z, zref) and np.array_equal(x, ref["x"])
+    else:
+        assert np.abs(z - zref).max() <= 1e-12 * np.abs(zref).max()
+        assert np.abs(x - ref["x"]).max() <= 1e-10 * np.abs(ref["x"]).max()
