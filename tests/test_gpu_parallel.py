@@ -608,6 +608,7 @@ def test_partition_of_equal_nonzero_counts_over_loopback(oracle, mgcg_env, world
                                                             # slabs thick enough for the deep-halo cycle (16 / 8 / 4 planes per rank; 4 coarse sweeps reach 4 planes):
                                                             (2, (8, 8, 32), 3, 0), (3, (16, 8, 48), 3, 0), (4, (16, 16, 64), 3, 0), (2, (8, 8, 16), 2, 0), (3, (8, 12, 24), 2, 0),
                                                             (2, (16, 16, 64), 4, 0), (3, (16, 8, 96), 4, 0),      # four levels: TWO middle levels hand their halo planes down and up
+                                                            (2, (1, 8, 32), 3, 0), (2, (6, 2, 32), 3, 0), (2, (2, 1, 32), 3, 0),   # degenerate / non-power-of-two planes under the deep-halo cycle (stored iterates)
                                                             (8, (8, 8, 256), 3, 0),                               # eight ranks with slabs thick enough (config 4's rank count on the deep-halo cycle)
                                                             (2, (8, 8, 32), 3, 1)])   # (thick slabs with the linear transfer: the deep halo is set up, the cycle must not take it)
 def test_distributed_multigrid_over_loopback(oracle, mgcg_env, world, dims, levels, interpolation):
@@ -644,7 +645,7 @@ def test_distributed_multigrid_over_loopback(oracle, mgcg_env, world, dims, leve
     res = _run_ranks_in_threads(world, make_rank)
     x, z = np.zeros(s.Count), np.zeros(s.Count)
     plain = os.environ.get("MGCG_COMPRESSION", "0") == "0" and "MGCG_NO_FOLD" not in os.environ and os.environ.get("MGCG_FOLD_UP", "-1") != "0"
-    if interpolation == 0 and dims[2] // world >= 8 and plain and (dims[0] & (dims[0] - 1)) == 0 and (dims[1] & (dims[1] - 1)) == 0:       # (tools/pytest_env_modes.sh runs the suite with these switches too)
+    if interpolation == 0 and dims[2] // world >= 8 and plain and dims[0] >= 2 and (dims[0] & (dims[0] - 1)) == 0 and (dims[1] & (dims[1] - 1)) == 0:       # (tools/pytest_env_modes.sh runs the suite with these switches too)
         # slabs of eight planes, power-of-two nx and ny: on the finest level the interior rows form the first sweep AND x1 + P e per gather
         # (bits 0 and 1); the boundary rows multiply what is stored within two planes of the rank's boundaries
         assert all(r[6] & 3 == 3 for r in res), [r[6] for r in res]
