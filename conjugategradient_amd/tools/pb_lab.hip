@@ -1,0 +1,610 @@
+// pb_lab: propagation blocking for a matrix of BASELINE config 5's shape (10 M rows, ~31 entries per row, columns uniform over the whole
+// range) -- the layout DESIGN.md section 7 had priced and never built: the gathers of x come from LDS instead of through the L1 miss path
+// that bounds the column-tile pass (profiles/r5/config5_tiles/pmc_summary_T27.json), at the price of the products travelling through memory.
+//   pass 1 (column-tile major): a workgroup holds the x window of ONE tile of 16384 columns in LDS (128 KB), streams the tile's entries
+//           (value + 16-bit column offset, row major inside the tile) and stores every rounded product value * x[col];
+//   pass 2 (row-block major):   a workgroup owns a block of RB rows, collects the block's products, drops them into LDS at their position in
+//           the block's CSR order (16-bit, stored in the order the products arrive) and every row adds its products left to right -- the
+//           stored order of Mgcg/cuBlas/Mgcg/SparseMatrix.cs:68-88, so y is the CSR kernels' y bit for bit (checked for every variant).
+// Who pays for the transposition between the two orders (profiles/r5/config5_pb/):
+//   "runs"   pass 1 SCATTERS: the products of a (block, tile) pair -- 13 entries at 256 rows -- are stored side by side, block major; pass 2 reads
+//            one contiguous stream.  Pass 1 2.3-3.4 ms (0.58 without its stores): short partial-line writes are what the memory likes least.
+//            Dealing adjacent tiles to one XCD so that the pieces meet in its L2 helps 10-20 %, not more.
+//   "direct" the same with every product at its own CSR index (8-byte stores, a line each): 9.6 ms.
+//   "gather" pass 1 STREAMS its products out in its own order (no destination array: 18 B per entry, 1.11-1.17 ms = 4.9-5.2 TB/s) and pass 2
+//            fetches the block's short piece of every tile (piece table: one 32-bit start per block and tile; 16 lanes per piece, all of a
+//            lane's pieces in flight at once): 1.12-1.16 ms.  PRODUCT 2.22-2.33 ms by box against 2.62-2.71 for the production tile pass
+//            (same box: 2.331 against 2.705); PMC: 3.30 GB read + 2.48 GB written in pass 1, 3.40 GB read in pass 2 = 9.27 GB, each
+//            line of the product stream fetched from memory once (the neighbouring blocks' share of a line hits in L2).
+//            Pass 2 as a persistent loop over consecutive blocks (table rows requested a block ahead) and with the shared line of two
+//            consecutive pieces carried in registers: 1.26 and 3.0 ms -- slower, kept for the record.
+// Measurement tool, not part of the library.  tools/pb_pmc.sh: the counter passes.
+//   pb_lab [rows=10000000] [partsPerTile=2]     PB_LAB_SKIP_RUNS=1 PB_LAB_GATHER_ONLY=1: only the "gather" form; PB_LAB_DIRECT=1: also "direct";
+//   PB_LAB_ONE=1: the two kernels of the best form five times (counter passes); PB_LAB_HOST_ONLY=1: the layouts replayed on the host, no device
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+constexpr int kW = 16384;           // columns per tile = doubles of x in LDS
+constexpr int kWShift = 14;
+constexpr int kMaxRow = 48;         // the generator's rows have 16..46 entries
+
+static int g_mismatch = 0;
+static inline unsigned long long mix(unsigned long long h) { h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 27; h *= 0x94D049BB133111EBull; h ^= h >> 31; return h; }
+
+// MODE bit0: products stored with the non-temporal hint; bit1: no stores (timing ablation); bit2: no LDS gather (x = 1, timing ablation);
+// bit3: every product is stored at its entry's own index (tile major: one contiguous stream per workgroup, no destination array)
+// MAP 1: the tiles are dealt to the XCDs in contiguous chunks (workgroup w runs on XCD w % 8: cdna guide), so that the workgroups an XCD runs at
+// the same time hold ADJACENT tiles; all of them walk the row blocks in the same order at about the same pace, so the short runs they store for
+// one block -- side by side in memory -- meet in that XCD's L2 and leave it as whole lines.
+template <int TH, int U, int MODE, int MAP = 0>
+__global__ __launch_bounds__(TH) void pb_pass1(const double* __restrict__ x, long long cols, const double* __restrict__ av, const unsigned short* __restrict__ ac,
+                                               const unsigned* __restrict__ adest, const int* __restrict__ tileStart, int parts, double* __restrict__ prod, int nTiles = 1 << 30)
+{
+    __shared__ double xs[kW];
+    int t, part;
+    if (MAP == 1) {
+        const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, perXcd = (int)gridDim.x / (8 * parts);      // (grid = 8 * perXcd * parts)
+        t = xcd * perXcd + slot / parts; part = slot % parts;
+        if (t >= nTiles) return;                                     // (workgroup-uniform, before any barrier)
+    } else { t = (int)blockIdx.x / parts; part = (int)blockIdx.x - t * parts; }
+    const long long c0 = (long long)t * kW;
+    for (int i = threadIdx.x; i < kW; i += TH) { const long long c = c0 + i; xs[i] = c < cols ? x[c] : 0.0; }
+    __syncthreads();
+    const int kb = tileStart[t], ke = tileStart[t + 1];
+    const long long len = ke - kb;
+    const int a = kb + (int)(len * part / parts), b = kb + (int)(len * (part + 1) / parts);
+    double sink = 0.0;
+    for (int k0 = a; k0 < b; k0 += TH * U) {
+        double v[U]; unsigned c[U], d[U]; bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * TH + (int)threadIdx.x;
+            ok[u] = k < b;
+            const int kk = ok[u] ? k : a;                            // (a < b here: a valid entry)
+            v[u] = __builtin_nontemporal_load(av + kk); c[u] = __builtin_nontemporal_load(ac + kk); d[u] = (MODE & 8) ? (unsigned)kk : __builtin_nontemporal_load(adest + kk);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double xv = (MODE & 4) ? 1.0 : xs[c[u] & (kW - 1)];
+            const double p = v[u] * xv;
+            if (MODE & 2) sink += p;
+            else if (ok[u]) { if (MODE & 1) __builtin_nontemporal_store(p, prod + d[u]); else prod[d[u]] = p; }
+        }
+    }
+    if ((MODE & 2) && sink == 1.2345e300) prod[0] = sink;
+}
+
+template <int RB, int TH, bool DIRECT>
+__global__ __launch_bounds__(TH) void pb_pass2(const double* __restrict__ prod, const unsigned short* __restrict__ bpos, const int* __restrict__ rowOff, long long rows, double* __restrict__ y)
+{
+    constexpr int CAP = RB * kMaxRow;
+    __shared__ double s[CAP];
+    const long long r0 = (long long)blockIdx.x * RB;
+    const long long r1 = r0 + RB < rows ? r0 + RB : rows;
+    const int base = rowOff[r0];
+    int n = rowOff[r1] - base;
+    n = n < CAP ? n : CAP;                                           // (the host has checked n <= CAP)
+    constexpr int U = 8;
+    for (int k0 = 0; k0 < n; k0 += TH * U) {                         // (n >= 1: every row has entries)
+        double p[U]; int at[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * TH + (int)threadIdx.x, kk = k < n ? k : 0;
+            p[u] = __builtin_nontemporal_load(prod + base + kk);
+            at[u] = DIRECT ? kk : ((int)__builtin_nontemporal_load(bpos + base + kk) % CAP);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (k0 + u * TH + (int)threadIdx.x < n) s[at[u]] = p[u];
+    }
+    __syncthreads();
+    if ((long long)threadIdx.x < r1 - r0) {
+        const long long row = r0 + threadIdx.x;
+        int a = rowOff[row] - base, e = rowOff[row + 1] - base;
+        e = e < n ? e : n;
+        double acc = 0.0;
+        for (int j = a; j < e; ++j) acc += s[j];
+        y[row] = acc;
+    }
+}
+
+// The other way round ("gather"): pass 1 stores its products where its entries are (tile major, one stream), and pass 2 fetches, for its
+// row block, the block's short piece of every tile: pieceStart[b * Tpad + t] = first entry of block b inside tile t (the next block's entry
+// ends it), pieceOff[b * Tpad + t] = where that piece begins in the block's own (tile major) order, in which bposB is stored contiguously.
+// LP lanes per piece.  Blocks are dealt to the XCDs in contiguous chunks: neighbouring blocks' pieces share lines.
+template <int RB, int TH, int CAP, int TMAX, int LP, int U>
+__global__ __launch_bounds__(TH) void pb_pass2_gather(const double* __restrict__ prodA, const unsigned short* __restrict__ bposB, const unsigned* __restrict__ pieceStart,
+                                                      const unsigned short* __restrict__ pieceOff, int Tpad, int T, const int* __restrict__ rowOff, long long rows, int nB,
+                                                      long long nnz, double* __restrict__ y)
+{
+    __shared__ double s[CAP];
+    __shared__ unsigned sStart[TMAX];
+    __shared__ unsigned short sLen[TMAX], sOff[TMAX];
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, per = (int)gridDim.x >> 3;
+    const int b = xcd * per + slot;
+    if (b >= nB) return;                                             // (workgroup-uniform)
+    const int tid = (int)threadIdx.x;
+    const long long r0 = (long long)b * RB;
+    const long long r1 = r0 + RB < rows ? r0 + RB : rows;
+    const int base = rowOff[r0];
+    int n = rowOff[r1] - base;
+    n = n < CAP ? n : CAP;                                           // (the host has checked n <= CAP)
+    for (int t = tid; t < T; t += TH) {
+        const unsigned st = pieceStart[(long long)b * Tpad + t], en = pieceStart[(long long)(b + 1) * Tpad + t];
+        sStart[t] = st; sLen[t] = (unsigned short)(en - st); sOff[t] = pieceOff[(long long)b * Tpad + t];
+    }
+    __syncthreads();
+    constexpr int G = TH / LP;                                      // LP lanes per piece, U pieces per lane in flight
+    const int grp = tid / LP, l = tid % LP;
+    for (int t0 = grp; t0 < T; t0 += G * U) {
+        double p[U]; int at[U]; bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u * G;
+            const int tt = t < T ? t : 0;
+            const int len = t < T ? (int)sLen[tt] : 0;
+            ok[u] = l < len;
+            long long src = ok[u] ? (long long)sStart[tt] + l : 0;
+            src = src < nnz ? src : 0;
+            int pos = ok[u] ? (int)sOff[tt] + l : 0;
+            pos = pos < n ? pos : 0;
+            p[u] = prodA[src];
+            at[u] = (int)bposB[base + pos] % CAP;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (ok[u]) s[at[u]] = p[u];
+        for (int u = 0; u < U; ++u) {                                // pieces of more than LP entries
+            const int t = t0 + u * G;
+            if (t >= T) break;
+            const int len = (int)sLen[t];
+            for (int i = l + LP; i < len; i += LP) {
+                long long src = (long long)sStart[t] + i; src = src < nnz ? src : 0;
+                int pos = (int)sOff[t] + i; pos = pos < n ? pos : 0;
+                s[(int)bposB[base + pos] % CAP] = prodA[src];
+            }
+        }
+    }
+    __syncthreads();
+    if ((long long)tid < r1 - r0) {
+        const long long row = r0 + tid;
+        int a = rowOff[row] - base, e = rowOff[row + 1] - base;
+        e = e < n ? e : n;
+        double acc = 0.0;
+        for (int j = a; j < e; ++j) acc += s[j];
+        y[row] = acc;
+    }
+}
+
+// The same as a persistent loop: a workgroup takes a run of CONSECUTIVE blocks.  The table row that ends block b's pieces is the row that starts
+// block b + 1's, so one new row per block is enough, and it is requested one block ahead (thread t keeps tile t's entries in registers): the
+// table's round trip leaves the block's critical path, which is then one round of piece loads, the LDS hand-over and the row sums.
+template <int RB, int TH, int CAP, int TMAX, int LP, int U>
+__global__ __launch_bounds__(TH) void pb_pass2_persist(const double* __restrict__ prodA, const unsigned short* __restrict__ bposB, const unsigned* __restrict__ pieceStart,
+                                                       const unsigned short* __restrict__ pieceOff, int Tpad, int T, const int* __restrict__ rowOff, long long rows, int nB,
+                                                       long long nnz, double* __restrict__ y)
+{
+    static_assert(TMAX <= TH, "one tile per thread");
+    __shared__ double s[CAP];
+    __shared__ unsigned sStart[TMAX];
+    __shared__ unsigned short sLen[TMAX], sOff[TMAX];
+    const int tid = (int)threadIdx.x;
+    const int per = (nB + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int b0 = (int)blockIdx.x * per, b1 = b0 + per < nB ? b0 + per : nB;
+    if (b0 >= b1) return;                                            // (workgroup-uniform)
+    const int tt = tid < T ? tid : 0;
+    unsigned cur = pieceStart[(long long)b0 * Tpad + tt], nxt = pieceStart[(long long)(b0 + 1) * Tpad + tt];
+    unsigned short off = pieceOff[(long long)b0 * Tpad + tt];
+    constexpr int G = TH / LP;
+    const int grp = tid / LP, l = tid % LP;
+    auto row_end = [&](int b) -> long long { const long long e = (long long)(b + 1) * RB; return e < rows ? e : rows; };
+    int base = rowOff[(long long)b0 * RB], end = rowOff[row_end(b0)];
+    for (int b = b0; b < b1; ++b) {
+        if (tid < T) { sStart[tid] = cur; sLen[tid] = (unsigned short)(nxt - cur); sOff[tid] = off; }
+        __syncthreads();                                             // (nothing of this thread is in flight here: the barrier's wait is free)
+        // requests for the NEXT block ride along with this block's piece loads (everything in flight ends at the next barrier)
+        const int bn = b + 2 <= nB ? b + 2 : nB, bo = b + 1 < nB ? b + 1 : nB - 1;
+        const unsigned nn = pieceStart[(long long)bn * Tpad + tt];
+        const unsigned short offn = pieceOff[(long long)bo * Tpad + tt];
+        const int baseN = rowOff[(long long)bo * RB], endN = rowOff[row_end(bo)];
+        const long long r0 = (long long)b * RB;
+        const long long r1 = row_end(b);
+        int n = end - base;
+        n = n < CAP ? n : CAP;
+        int ra = 0, re = 0;
+        if ((long long)tid < r1 - r0) { ra = rowOff[r0 + tid] - base; re = rowOff[r0 + tid + 1] - base; re = re < n ? re : n; }
+        for (int t0 = grp; t0 < T; t0 += G * U) {
+            double p[U]; int at[U]; bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * G;
+                const int tq = t < T ? t : 0;
+                const int len = t < T ? (int)sLen[tq] : 0;
+                ok[u] = l < len;
+                long long src = ok[u] ? (long long)sStart[tq] + l : 0;
+                src = src < nnz ? src : 0;
+                int pos = ok[u] ? (int)sOff[tq] + l : 0;
+                pos = pos < n ? pos : 0;
+                p[u] = prodA[src];
+                at[u] = (int)bposB[base + pos] % CAP;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) if (ok[u]) s[at[u]] = p[u];
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * G;
+                if (t >= T) break;
+                const int len = (int)sLen[t];
+                for (int i = l + LP; i < len; i += LP) {
+                    long long src = (long long)sStart[t] + i; src = src < nnz ? src : 0;
+                    int pos = (int)sOff[t] + i; pos = pos < n ? pos : 0;
+                    s[(int)bposB[base + pos] % CAP] = prodA[src];
+                }
+            }
+        }
+        __syncthreads();
+        if ((long long)tid < r1 - r0) {
+            double acc = 0.0;
+            for (int j = ra; j < re; ++j) acc += s[j];
+            y[r0 + tid] = acc;
+        }
+        __syncthreads();                                             // s and the piece tables are rewritten by the next block
+        cur = nxt; nxt = nn; off = offn; base = baseN; end = endN;
+    }
+}
+
+// Persistent pass 2 that fetches every line of the product stream ONCE: a piece is read as aligned 16-entry (128-byte) segments by the same
+// 16 lanes block after block, and the last segment of a piece -- which also holds the beginning of the next block's piece of that tile -- stays
+// in those lanes' registers for the next block (cv / cseg).  Without it every piece costs its two partly used lines: 2.2 x the bytes at 256 rows.
+template <int RB, int TH, int CAP, int TMAX, int U>
+__global__ __launch_bounds__(TH) void pb_pass2_carry(const double* __restrict__ prodA, const unsigned short* __restrict__ bposB, const unsigned* __restrict__ pieceStart,
+                                                     const unsigned short* __restrict__ pieceOff, int Tpad, int T, const int* __restrict__ rowOff, long long rows, int nB,
+                                                     long long nnzPad, double* __restrict__ y)
+{
+    static_assert(TMAX <= TH, "one tile per thread");
+    constexpr int LP = 16, G = TH / LP;
+    __shared__ double s[CAP];
+    __shared__ unsigned sStart[TMAX];
+    __shared__ unsigned short sLen[TMAX], sOff[TMAX];
+    const int tid = (int)threadIdx.x;
+    const int per = (nB + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int b0 = (int)blockIdx.x * per, b1 = b0 + per < nB ? b0 + per : nB;
+    if (b0 >= b1) return;                                            // (workgroup-uniform)
+    const int tt = tid < T ? tid : 0;
+    unsigned cur = pieceStart[(long long)b0 * Tpad + tt], nxt = pieceStart[(long long)(b0 + 1) * Tpad + tt];
+    unsigned short off = pieceOff[(long long)b0 * Tpad + tt];
+    const int grp = tid / LP, l = tid % LP;
+    auto row_end = [&](int b) -> long long { const long long e = (long long)(b + 1) * RB; return e < rows ? e : rows; };
+    int base = rowOff[(long long)b0 * RB], end = rowOff[row_end(b0)];
+    double cv[U]; unsigned cseg[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { cv[u] = 0.0; cseg[u] = 0xffffffffu; }
+    for (int b = b0; b < b1; ++b) {
+        if (tid < T) { sStart[tid] = cur; sLen[tid] = (unsigned short)(nxt - cur); sOff[tid] = off; }
+        __syncthreads();
+        const int bn = b + 2 <= nB ? b + 2 : nB, bo = b + 1 < nB ? b + 1 : nB - 1;
+        const unsigned nn = pieceStart[(long long)bn * Tpad + tt];
+        const unsigned short offn = pieceOff[(long long)bo * Tpad + tt];
+        const int baseN = rowOff[(long long)bo * RB], endN = rowOff[row_end(bo)];
+        const long long r0 = (long long)b * RB;
+        const long long r1 = row_end(b);
+        int n = end - base;
+        n = n < CAP ? n : CAP;
+        int ra = 0, re = 0;
+        if ((long long)tid < r1 - r0) { ra = rowOff[r0 + tid] - base; re = rowOff[r0 + tid + 1] - base; re = re < n ? re : n; }
+        constexpr int UH = U / 2;                                    // two half rounds: the registers of one hold 2 * UH loads per lane in flight
+        static_assert(U % 2 == 0, "U even");
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+        double v0[UH], v1[UH]; unsigned short a0[UH], a1[UH];
+#pragma unroll
+        for (int uu = 0; uu < UH; ++uu) {
+            const int u = h * UH + uu;
+            const int t = grp + u * G;
+            const int tq = t < T ? t : 0;
+            const unsigned st = sStart[tq];
+            const unsigned len = t < T ? (unsigned)sLen[tq] : 0u;
+            const unsigned en = st + len, of = sOff[tq];
+            const unsigned seg0 = st >> 4, seg1 = len ? (en - 1) >> 4 : seg0;
+            const bool any = len > 0;
+            const unsigned e0 = seg0 * 16 + (unsigned)l, e1 = e0 + 16;
+            const bool k0 = any && e0 >= st && e0 < en;            // does my lane's entry of the segment belong to the piece?
+            const bool k1 = any && e1 < en;                        // (e1 >= st always)
+            const bool need0 = any && seg0 != cseg[u], need1 = any && seg1 > seg0;
+            long long i0 = e0, i1 = e1;
+            i0 = i0 < nnzPad ? i0 : 0; i1 = i1 < nnzPad ? i1 : 0;
+            v0[uu] = need0 ? prodA[i0] : cv[u];
+            v1[uu] = need1 ? prodA[i1] : 0.0;
+            int p0 = k0 ? (int)(of + (e0 - st)) : 0, p1 = k1 ? (int)(of + (e1 - st)) : 0;
+            p0 = p0 < n ? p0 : 0; p1 = p1 < n ? p1 : 0;
+            a0[uu] = k0 ? bposB[base + p0] : (unsigned short)0;
+            a1[uu] = k1 ? bposB[base + p1] : (unsigned short)0;
+        }
+#pragma unroll
+        for (int uu = 0; uu < UH; ++uu) {
+            const int u = h * UH + uu;
+            const int t = grp + u * G;
+            const int tq = t < T ? t : 0;
+            const unsigned st = sStart[tq];
+            const unsigned len = t < T ? (unsigned)sLen[tq] : 0u;
+            const unsigned en = st + len, of = sOff[tq];
+            const unsigned seg0 = st >> 4, seg1 = len ? (en - 1) >> 4 : seg0;
+            const unsigned e0 = seg0 * 16 + (unsigned)l, e1 = e0 + 16;
+            if (len > 0 && e0 >= st && e0 < en) s[(int)a0[uu] % CAP] = v0[uu];
+            if (len > 0 && e1 < en) s[(int)a1[uu] % CAP] = v1[uu];
+            if (len > 0) {
+                double last = seg1 == seg0 ? v0[uu] : v1[uu];
+                for (unsigned sg = seg0 + 2; sg <= seg1; ++sg) {     // pieces of more than two segments (rare)
+                    const unsigned e = sg * 16 + (unsigned)l;
+                    long long i = e; i = i < nnzPad ? i : 0;
+                    last = prodA[i];
+                    if (e < en) { int pp = (int)(of + (e - st)); pp = pp < n ? pp : 0; s[(int)bposB[base + pp] % CAP] = last; }
+                }
+                cv[u] = last; cseg[u] = seg1;
+            }
+        }
+        }
+        __syncthreads();
+        if ((long long)tid < r1 - r0) {
+            double acc = 0.0;
+            for (int j = ra; j < re; ++j) acc += s[j];
+            y[r0 + tid] = acc;
+        }
+        __syncthreads();
+        cur = nxt; nxt = nn; off = offn; base = baseN; end = endN;
+    }
+}
+
+template <typename F> static double time_ms(F f, int reps = 5)
+{
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f(); CK(hipDeviceSynchronize());
+    std::vector<float> t;
+    for (int r = 0; r < reps; ++r) { CK(hipEventRecord(a)); f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); t.push_back(ms); }
+    std::sort(t.begin(), t.end());
+    CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
+    return t[t.size() / 2];
+}
+
+int main(int argc, char** argv)
+{
+    const long long rows = argc > 1 ? atoll(argv[1]) : 10000000LL;
+    const int parts = argc > 2 ? atoi(argv[2]) : 2;
+    if (rows < 1024 || rows > 40000000LL || parts < 1 || parts > 64) { printf("bad arguments\n"); return 1; }
+    const long long cols = rows;
+    const int T = (int)((cols + kW - 1) / kW);
+    printf("pb_lab: %lld rows and columns, %d tiles of %d columns (%d KB of x in LDS each), %d workgroup(s) per tile in pass 1\n", rows, T, kW, kW * 8 / 1024, parts);
+    // ---- host CSR: 16..46 entries per row, columns uniform, ascending inside a row, values in (-1, 0]
+    std::vector<int> rowOff((size_t)rows + 1, 0), col; std::vector<double> val;
+    col.reserve((size_t)rows * 32); val.reserve((size_t)rows * 32);
+    for (long long i = 0; i < rows; ++i) {
+        unsigned long long h = mix((unsigned long long)i * 0x9E3779B97F4A7C15ull + 12345ull);
+        const int n = 16 + (int)((h >> 40) % 31ull);
+        long long cs[kMaxRow];
+        for (int q = 0; q < n; ++q) { h = mix(h + 0x632BE59BD9B4E019ull); cs[q] = (long long)(h % (unsigned long long)cols); }
+        std::sort(cs, cs + n);
+        for (int q = 0; q < n; ++q) {
+            if (q > 0 && cs[q] == cs[q - 1]) continue;
+            h = mix(h + 1);
+            col.push_back((int)cs[q]); val.push_back(-((double)(h >> 11) * (1.0 / 9007199254740992.0)));
+        }
+        if (col.size() > 2000000000ull) { printf("too many entries\n"); return 1; }
+        rowOff[(size_t)i + 1] = (int)col.size();
+    }
+    const long long nnz = (long long)col.size();
+    printf("nnz %lld (%.2f per row)\n", nnz, (double)nnz / rows); fflush(stdout);
+    std::vector<double> hx((size_t)cols), yref((size_t)rows);
+    for (long long i = 0; i < cols; ++i) hx[(size_t)i] = cos((double)i * 0.01);
+    for (long long i = 0; i < rows; ++i) { double acc = 0.0; for (int k = rowOff[(size_t)i]; k < rowOff[(size_t)i + 1]; ++k) { const double p = val[(size_t)k] * hx[(size_t)col[(size_t)k]]; acc += p; } yref[(size_t)i] = acc; }
+    // ---- pass 1's input: tile major, inside a tile in CSR order (= row major, columns ascending)
+    std::vector<int> tileStart((size_t)T + 1, 0);
+    for (long long e = 0; e < nnz; ++e) ++tileStart[(size_t)(col[(size_t)e] >> kWShift) + 1];
+    for (int t = 0; t < T; ++t) tileStart[(size_t)t + 1] += tileStart[(size_t)t];
+    std::vector<double> av((size_t)nnz); std::vector<unsigned short> ac((size_t)nnz); std::vector<unsigned> adest((size_t)nnz);
+    {
+        std::vector<int> cur(tileStart.begin(), tileStart.end() - 1);
+        for (long long e = 0; e < nnz; ++e) { const int t = col[(size_t)e] >> kWShift; const int k = cur[(size_t)t]++; av[(size_t)k] = val[(size_t)e]; ac[(size_t)k] = (unsigned short)(col[(size_t)e] - t * kW); }
+    }
+    // destination of every entry (by CSR index) for the "runs" order of row blocks of RB rows, and the position pass 2 sorts it back to
+    std::vector<unsigned> kB((size_t)nnz); std::vector<unsigned short> bpos((size_t)nnz);
+    auto build_runs = [&](int RB) -> bool {
+        std::vector<int> cnt((size_t)T + 1);
+        const long long nB = (rows + RB - 1) / RB;
+        for (long long b = 0; b < nB; ++b) {
+            const long long r0 = b * RB, r1 = std::min(rows, r0 + RB);
+            const int e0 = rowOff[(size_t)r0], e1 = rowOff[(size_t)r1];
+            if (e1 - e0 > RB * kMaxRow || e1 - e0 > 65536) { printf("block %lld has %d entries: too many\n", b, e1 - e0); return false; }
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (int e = e0; e < e1; ++e) ++cnt[(size_t)(col[(size_t)e] >> kWShift) + 1];
+            for (int t = 0; t < T; ++t) cnt[(size_t)t + 1] += cnt[(size_t)t];
+            for (int e = e0; e < e1; ++e) { const int t = col[(size_t)e] >> kWShift; const int k = e0 + cnt[(size_t)t]++; kB[(size_t)e] = (unsigned)k; bpos[(size_t)k] = (unsigned short)(e - e0); }
+        }
+        return true;
+    };
+    auto build_adest = [&](bool direct) {
+        std::vector<int> cur(tileStart.begin(), tileStart.end() - 1);
+        for (long long e = 0; e < nnz; ++e) { const int t = col[(size_t)e] >> kWShift; adest[(size_t)cur[(size_t)t]++] = direct ? (unsigned)e : kB[(size_t)e]; }
+    };
+    // host checks of everything the kernels index with
+    for (long long k = 0; k < nnz; ++k) if (ac[(size_t)k] >= kW) { printf("column offset out of range\n"); return 1; }
+    if (tileStart[(size_t)T] != nnz) { printf("tile starts do not add up\n"); return 1; }
+
+    if (getenv("PB_LAB_HOST_ONLY")) {       // the two passes replayed on the host (no device needed): checks the layouts before any kernel runs
+        std::vector<double> prodH((size_t)nnz), s;
+        for (int v = 0; v < 3; ++v) {
+            const int RB = v == 1 ? 256 : 128; const bool direct = v == 2;
+            if (!direct && !build_runs(RB)) return 1;
+            build_adest(direct);
+            std::fill(prodH.begin(), prodH.end(), 0.0);
+            for (int t = 0; t < T; ++t) for (int k = tileStart[(size_t)t]; k < tileStart[(size_t)t + 1]; ++k) { const double p = av[(size_t)k] * hx[(size_t)t * kW + ac[(size_t)k]]; prodH[(size_t)adest[(size_t)k]] = p; }
+            long long bad = 0;
+            for (long long r0 = 0; r0 < rows; r0 += RB) {
+                const long long r1 = std::min(rows, r0 + RB);
+                const int base = rowOff[(size_t)r0], n = rowOff[(size_t)r1] - base;
+                s.assign((size_t)n, 0.0);
+                for (int k = 0; k < n; ++k) s[(size_t)(direct ? k : bpos[(size_t)base + k])] = prodH[(size_t)base + k];
+                for (long long row = r0; row < r1; ++row) { double acc = 0.0; for (int j = rowOff[(size_t)row] - base; j < rowOff[(size_t)row + 1] - base; ++j) acc += s[(size_t)j]; if (memcmp(&acc, &yref[(size_t)row], 8) != 0) ++bad; }
+            }
+            printf("host replay, %s: %lld rows differ\n", v == 0 ? "runs / 128" : (v == 1 ? "runs / 256" : "direct"), bad);
+        }
+        return 0;
+    }
+    double *dav, *dx, *dy, *dprod; unsigned short *dac, *dbpos; unsigned* dadest; int *drowOff, *dtileStart;
+    CK(hipMalloc(&dav, nnz * 8)); CK(hipMalloc(&dac, nnz * 2)); CK(hipMalloc(&dadest, nnz * 4)); CK(hipMalloc(&dprod, (nnz + 16) * 8)); CK(hipMalloc(&dbpos, nnz * 2));
+    CK(hipMalloc(&drowOff, (rows + 1) * 4)); CK(hipMalloc(&dtileStart, (T + 1) * 4)); CK(hipMalloc(&dx, cols * 8)); CK(hipMalloc(&dy, rows * 8));
+    CK(hipMemcpy(dav, av.data(), nnz * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dac, ac.data(), nnz * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(drowOff, rowOff.data(), (rows + 1) * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dtileStart, tileStart.data(), (T + 1) * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dx, hx.data(), cols * 8, hipMemcpyHostToDevice));
+    std::vector<double> got((size_t)rows);
+    auto check = [&](const char* name) {
+        CK(hipMemcpy(got.data(), dy, rows * 8, hipMemcpyDeviceToHost));
+        long long bad = 0;
+        for (long long i = 0; i < rows; ++i) if (memcmp(&got[(size_t)i], &yref[(size_t)i], 8) != 0) ++bad;
+        if (bad) g_mismatch = 1;
+        printf("   %-58s %s (%lld rows differ)\n", name, bad == 0 ? "bit-identical to the host's CSR row sums" : "MISMATCH", bad); fflush(stdout);
+    };
+    const dim3 g1((unsigned)(T * parts));
+    const int perXcd = (T + 7) / 8;
+    const dim3 g1x((unsigned)(8 * perXcd * parts));
+    auto variant = [&](const char* name, int RB, bool direct, auto pass2) {
+        if (!direct && !build_runs(RB)) return;
+        build_adest(direct);
+        for (long long k = 0; k < nnz; ++k) if (adest[(size_t)k] >= (unsigned long long)nnz) { printf("destination out of range\n"); exit(1); }
+        CK(hipMemcpy(dadest, adest.data(), nnz * 4, hipMemcpyHostToDevice));
+        if (!direct) CK(hipMemcpy(dbpos, bpos.data(), nnz * 2, hipMemcpyHostToDevice));
+        CK(hipMemset(dprod, 0, nnz * 8)); CK(hipMemset(dy, 0, rows * 8));
+        const dim3 g2((unsigned)((rows + RB - 1) / RB));
+        auto p1 = [&] { pb_pass1<1024, 4, 0><<<g1, dim3(1024), 0, 0>>>(dx, cols, dav, dac, dadest, dtileStart, parts, dprod); };
+        auto p1nt = [&] { pb_pass1<1024, 4, 1><<<g1, dim3(1024), 0, 0>>>(dx, cols, dav, dac, dadest, dtileStart, parts, dprod); };
+        auto p2 = [&] { pass2(g2); };
+        const double both = time_ms([&] { p1(); p2(); });
+        CK(hipGetLastError());
+        check(name);
+        const double t1 = time_ms(p1), t2 = time_ms(p2), t1nt = time_ms(p1nt), bothNt = time_ms([&] { p1nt(); p2(); });
+        check("   (after the non-temporal stores)");
+        {
+            auto p1x = [&] { pb_pass1<1024, 4, 0, 1><<<g1x, dim3(1024), 0, 0>>>(dx, cols, dav, dac, dadest, dtileStart, parts, dprod, T); };
+            auto p1x2 = [&] { pb_pass1<1024, 2, 0, 1><<<g1x, dim3(1024), 0, 0>>>(dx, cols, dav, dac, dadest, dtileStart, parts, dprod, T); };
+            CK(hipMemset(dprod, 0, nnz * 8)); CK(hipMemset(dy, 0, rows * 8));
+            const double bx = time_ms([&] { p1x(); p2(); });
+            CK(hipGetLastError());
+            check("   (adjacent tiles per XCD)");
+            const double t1x = time_ms(p1x), t1x2 = time_ms(p1x2), bx2 = time_ms([&] { p1x2(); p2(); });
+            printf("%-46s adjacent tiles per XCD: product %.3f ms | pass 1 %.3f ms = %.2f TB/s | with 2 entries per thread: product %.3f, pass 1 %.3f\n", name, bx, t1x, (nnz * 22.0 + cols * 8.0 * parts) / t1x / 1e9, bx2, t1x2);
+        }
+        const double bytes1 = nnz * 22.0 + cols * 8.0 * parts, bytes2 = nnz * (direct ? 8.0 : 10.0) + rows * 12.0;
+        printf("%-46s product %.3f ms (non-temporal product stores: %.3f) | pass 1 %.3f ms = %.2f TB/s (nt %.3f) | pass 2 %.3f ms = %.2f TB/s\n",
+               name, both, bothNt, t1, bytes1 / t1 / 1e9, t1nt, t2, bytes2 / t2 / 1e9);
+        fflush(stdout);
+    };
+    if (!getenv("PB_LAB_SKIP_RUNS")) {
+    variant("runs, row blocks of 128", 128, false, [&](dim3 g2) { pb_pass2<128, 256, false><<<g2, dim3(256), 0, 0>>>(dprod, dbpos, drowOff, rows, dy); });
+    variant("runs, row blocks of 256", 256, false, [&](dim3 g2) { pb_pass2<256, 512, false><<<g2, dim3(512), 0, 0>>>(dprod, dbpos, drowOff, rows, dy); });
+    variant("runs, row blocks of 64", 64, false, [&](dim3 g2) { pb_pass2<64, 256, false><<<g2, dim3(256), 0, 0>>>(dprod, dbpos, drowOff, rows, dy); });
+    if (getenv("PB_LAB_DIRECT")) variant("direct (products at their CSR index), blocks of 128", 128, true, [&](dim3 g2) { pb_pass2<128, 256, true><<<g2, dim3(256), 0, 0>>>(dprod, dbpos, drowOff, rows, dy); });
+    }
+    // ---- the "gather" form
+    auto gather_variant = [&](const char* name, auto RBc, auto THc, auto CAPc, auto LPc, auto Uc) {
+        constexpr int RB = decltype(RBc)::value, TH = decltype(THc)::value, CAP = decltype(CAPc)::value, TMAX = 1024, LP = decltype(LPc)::value, U = decltype(Uc)::value;
+        if (T > TMAX) { printf("%s: more than %d tiles\n", name, TMAX); return; }
+        const int nB = (int)((rows + RB - 1) / RB), Tpad = (T + 7) & ~7;
+        std::vector<unsigned> pieceStart((size_t)(nB + 1) * Tpad, 0); std::vector<unsigned short> pieceOff((size_t)(nB + 1) * Tpad, 0);
+        {
+            std::vector<int> cur(tileStart.begin(), tileStart.end() - 1);
+            for (int b = 0; b <= nB; ++b) {
+                const long long r0 = std::min(rows, (long long)b * RB), r1 = std::min(rows, r0 + RB);
+                for (int t = 0; t < T; ++t) pieceStart[(size_t)b * Tpad + t] = (unsigned)cur[(size_t)t];
+                for (int e = rowOff[(size_t)r0]; e < rowOff[(size_t)r1]; ++e) ++cur[(size_t)(col[(size_t)e] >> kWShift)];
+            }
+            for (int t = 0; t < T; ++t) if (pieceStart[(size_t)nB * Tpad + t] != (unsigned)tileStart[(size_t)t + 1]) { printf("piece table does not end at the tile ends\n"); exit(1); }
+            for (int b = 0; b < nB; ++b) {
+                unsigned off = 0;
+                for (int t = 0; t < T; ++t) { pieceOff[(size_t)b * Tpad + t] = (unsigned short)off; off += pieceStart[(size_t)(b + 1) * Tpad + t] - pieceStart[(size_t)b * Tpad + t]; }
+                const long long r0 = (long long)b * RB, r1 = std::min(rows, r0 + RB);
+                if ((int)off != rowOff[(size_t)r1] - rowOff[(size_t)r0] || off > (unsigned)CAP || off > 65535u) { printf("block %d: %u entries do not fit (capacity %d)\n", b, off, CAP); return; }
+            }
+        }
+        if (!build_runs(RB)) return;                                 // bpos in the block's tile-major order = the order the pieces arrive in
+        unsigned* dps; unsigned short* dpo;
+        CK(hipMalloc(&dps, pieceStart.size() * 4)); CK(hipMalloc(&dpo, pieceOff.size() * 2));
+        CK(hipMemcpy(dps, pieceStart.data(), pieceStart.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dpo, pieceOff.data(), pieceOff.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dbpos, bpos.data(), nnz * 2, hipMemcpyHostToDevice));
+        CK(hipMemset(dprod, 0, (nnz + 16) * 8)); CK(hipMemset(dy, 0, rows * 8));
+        const dim3 g2((unsigned)(8 * ((nB + 7) / 8)));
+        auto p1 = [&] { pb_pass1<1024, 2, 8><<<g1, dim3(1024), 0, 0>>>(dx, cols, dav, dac, dadest, dtileStart, parts, dprod); };
+        auto p1b = [&] { pb_pass1<1024, 1, 8><<<g1, dim3(1024), 0, 0>>>(dx, cols, dav, dac, dadest, dtileStart, parts, dprod); };
+        auto p1nt = [&] { pb_pass1<1024, 2, 9><<<g1, dim3(1024), 0, 0>>>(dx, cols, dav, dac, dadest, dtileStart, parts, dprod); };
+        auto p2 = [&] { pb_pass2_gather<RB, TH, CAP, TMAX, LP, U><<<g2, dim3(TH), 0, 0>>>(dprod, dbpos, dps, dpo, Tpad, T, drowOff, rows, nB, nnz, dy); };
+        if (getenv("PB_LAB_ONE")) {                                  // counter passes: the two kernels of the product, five times, nothing else
+            for (int r = 0; r < 5; ++r) { p1(); p2(); }
+            CK(hipDeviceSynchronize());
+            check(name);
+            CK(hipFree(dps)); CK(hipFree(dpo));
+            exit(g_mismatch ? 3 : 0);
+        }
+        if constexpr (TH >= 1024) {
+            for (int wgs : { 256, 512, 1024 }) {
+                if (wgs * (size_t)(CAP * 8 + 8192) > 256 * (size_t)163840 * 8) continue;
+                auto p2p = [&] { pb_pass2_persist<RB, TH, CAP, 1024, LP, U><<<dim3((unsigned)wgs), dim3(TH), 0, 0>>>(dprod, dbpos, dps, dpo, Tpad, T, drowOff, rows, nB, nnz, dy); };
+                CK(hipMemset(dy, 0, rows * 8));
+                const double bp = time_ms([&] { p1(); p2p(); });
+                CK(hipGetLastError());
+                check("   (persistent pass 2)");
+                const double t2p = time_ms(p2p);
+                printf("%-46s persistent pass 2, %d workgroups: product %.3f ms | pass 2 %.3f ms\n", name, wgs, bp, t2p); fflush(stdout);
+            }
+            if constexpr (LP == 16) {
+                for (int wgs : { 512, 1024 }) {
+                    auto p2c = [&] { pb_pass2_carry<RB, TH, CAP, 1024, U><<<dim3((unsigned)wgs), dim3(TH), 0, 0>>>(dprod, dbpos, dps, dpo, Tpad, T, drowOff, rows, nB, nnz + 16, dy); };
+                    CK(hipMemset(dy, 0, rows * 8));
+                    const double bc = time_ms([&] { p1(); p2c(); });
+                    CK(hipGetLastError());
+                    check("   (persistent pass 2, every line once)");
+                    const double t2c = time_ms(p2c);
+                    printf("%-46s persistent pass 2 with carried segments, %d workgroups: product %.3f ms | pass 2 %.3f ms\n", name, wgs, bc, t2c); fflush(stdout);
+                }
+            }
+            CK(hipMemset(dy, 0, rows * 8));
+        }
+        const double both = time_ms([&] { p1(); p2(); });
+        CK(hipGetLastError());
+        check(name);
+        const double t1 = time_ms(p1), t1b = time_ms(p1b), t1nt = time_ms(p1nt), t2 = time_ms(p2), bothNt = time_ms([&] { p1nt(); p2(); });
+        check("   (after the non-temporal stores)");
+        const double bytes1 = nnz * 18.0 + cols * 8.0 * parts, bytes2 = nnz * 10.0 + rows * 12.0 + (double)nB * Tpad * 10.0;
+        printf("%-46s product %.3f ms (non-temporal product stores: %.3f) | pass 1 %.3f ms = %.2f TB/s (1 entry per thread %.3f, nt %.3f) | pass 2 %.3f ms = %.2f TB/s of %.2f GB\n",
+               name, both, bothNt, t1, bytes1 / t1 / 1e9, t1b, t1nt, t2, bytes2 / t2 / 1e9, bytes2 / 1e9);
+        fflush(stdout);
+        CK(hipFree(dps)); CK(hipFree(dpo));
+    };
+    gather_variant("gather, blocks of 256, 1024 threads, 16 lanes x 10", std::integral_constant<int, 256>{}, std::integral_constant<int, 1024>{}, std::integral_constant<int, 9216>{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 10>{});
+    gather_variant("gather, blocks of 128, 1024 threads, 16 lanes x 10", std::integral_constant<int, 128>{}, std::integral_constant<int, 1024>{}, std::integral_constant<int, 4864>{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 10>{});
+    gather_variant("gather, blocks of 512, 1024 threads, 16 lanes x 10", std::integral_constant<int, 512>{}, std::integral_constant<int, 1024>{}, std::integral_constant<int, 17408>{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 10>{});
+    if (getenv("PB_LAB_GATHER_ONLY")) return g_mismatch ? 3 : 0;
+    // launch shapes of pass 1 on the last destinations (timing only: the products land where they did before)
+    {
+        for (int pp : { 1, 2, 4, 8 }) {
+            const dim3 g((unsigned)(T * pp));
+            const double u2 = time_ms([&] { pb_pass1<1024, 2, 0><<<g, dim3(1024), 0, 0>>>(dx, cols, dav, dac, dadest, dtileStart, pp, dprod); });
+            const double u4 = time_ms([&] { pb_pass1<1024, 4, 0><<<g, dim3(1024), 0, 0>>>(dx, cols, dav, dac, dadest, dtileStart, pp, dprod); });
+            const double u8 = time_ms([&] { pb_pass1<1024, 8, 0><<<g, dim3(1024), 0, 0>>>(dx, cols, dav, dac, dadest, dtileStart, pp, dprod); });
+            const double h4 = time_ms([&] { pb_pass1<512, 4, 0><<<g, dim3(512), 0, 0>>>(dx, cols, dav, dac, dadest, dtileStart, pp, dprod); });
+            const dim3 gx((unsigned)(8 * perXcd * pp));
+            const double x2 = time_ms([&] { pb_pass1<1024, 2, 0, 1><<<gx, dim3(1024), 0, 0>>>(dx, cols, dav, dac, dadest, dtileStart, pp, dprod, T); });
+            const double x4 = time_ms([&] { pb_pass1<1024, 4, 0, 1><<<gx, dim3(1024), 0, 0>>>(dx, cols, dav, dac, dadest, dtileStart, pp, dprod, T); });
+            printf("pass 1, %d workgroup(s) per tile: 1024 threads x 2 / 4 / 8 entries %.3f / %.3f / %.3f ms, 512 threads x 4 %.3f ms | adjacent tiles per XCD, x 2 / 4: %.3f / %.3f ms\n", pp, u2, u4, u8, h4, x2, x4);
+        }
+    }
+    // timing ablations of pass 1 on the last destinations
+    {
+        const double noStore = time_ms([&] { pb_pass1<1024, 4, 2><<<g1, dim3(1024), 0, 0>>>(dx, cols, dav, dac, dadest, dtileStart, parts, dprod); });
+        const double noGather = time_ms([&] { pb_pass1<1024, 4, 4><<<g1, dim3(1024), 0, 0>>>(dx, cols, dav, dac, dadest, dtileStart, parts, dprod); });
+        printf("pass 1 ablations (last destinations): no product stores %.3f ms (%.2f TB/s read), x = 1 instead of the LDS gather %.3f ms\n", noStore, nnz * 14.0 / noStore / 1e9, noGather);
+    }
+    printf("algorithmic bytes of the product (12 B per entry + 4 B per row offset + 16 B per row): %.2f GB\n", (nnz * 12.0 + rows * 20.0) / 1e9);
+    return g_mismatch ? 3 : 0;
+}
