@@ -17,9 +17,13 @@
 //            (same box: 2.331 against 2.705); PMC: 3.30 GB read + 2.48 GB written in pass 1, 3.40 GB read in pass 2 = 9.27 GB, each
 //            line of the product stream fetched from memory once (the neighbouring blocks' share of a line hits in L2).
 //            Pass 2 as a persistent loop over consecutive blocks (table rows requested a block ahead) and with the shared line of two
-//            consecutive pieces carried in registers: 1.26 and 3.0 ms -- slower, kept for the record.
+//            consecutive pieces carried in registers: 1.26 and 3.0 ms -- slower, kept for the record.  Where pass 2's 1.13 ms go
+//            (PB_LAB_ABLATE=1, run9 / run10): without any piece load it still takes 0.98, without the piece table 0.78, with neither 0.40 --
+//            the block's fixed steps (row bounds, table, LDS hand-over, row sums: dependent round trips at two workgroups per CU), not its
+//            bytes; reading the table by the lane groups themselves instead of through LDS: 1.30 (run11).
 // Measurement tool, not part of the library.  tools/pb_pmc.sh: the counter passes.
 //   pb_lab [rows=10000000] [partsPerTile=2]     PB_LAB_SKIP_RUNS=1 PB_LAB_GATHER_ONLY=1: only the "gather" form; PB_LAB_DIRECT=1: also "direct";
+//   PB_LAB_ABLATE=1: timing ablations of pass 2; PB_LAB_CARRY=1: also the carried-segment form;
 //   PB_LAB_ONE=1: the two kernels of the best form five times (counter passes); PB_LAB_HOST_ONLY=1: the layouts replayed on the host, no device
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -118,7 +122,8 @@ __global__ __launch_bounds__(TH) void pb_pass2(const double* __restrict__ prod, 
 // row block, the block's short piece of every tile: pieceStart[b * Tpad + t] = first entry of block b inside tile t (the next block's entry
 // ends it), pieceOff[b * Tpad + t] = where that piece begins in the block's own (tile major) order, in which bposB is stored contiguously.
 // LP lanes per piece.  Blocks are dealt to the XCDs in contiguous chunks: neighbouring blocks' pieces share lines.
-template <int RB, int TH, int CAP, int TMAX, int LP, int U>
+// ABL (timing ablations, wrong results by design): bit0 no position loads (the product lands at its arrival index), bit1 no product loads, bit2 no piece table (fixed pieces)
+template <int RB, int TH, int CAP, int TMAX, int LP, int U, int ABL = 0>
 __global__ __launch_bounds__(TH) void pb_pass2_gather(const double* __restrict__ prodA, const unsigned short* __restrict__ bposB, const unsigned* __restrict__ pieceStart,
                                                       const unsigned short* __restrict__ pieceOff, int Tpad, int T, const int* __restrict__ rowOff, long long rows, int nB,
                                                       long long nnz, double* __restrict__ y)
@@ -135,7 +140,12 @@ __global__ __launch_bounds__(TH) void pb_pass2_gather(const double* __restrict__
     const int base = rowOff[r0];
     int n = rowOff[r1] - base;
     n = n < CAP ? n : CAP;                                           // (the host has checked n <= CAP)
+    // my row's bounds are requested here, with the piece table: asked for behind the scatter they were a third dependent round trip per block
+    // (profiles/r5/config5_pb/run9_pass2_ablations.log: the kernel without any piece load still took 0.99 of its 1.17 ms)
+    int ra = 0, re = 0;
+    if ((long long)tid < r1 - r0) { ra = rowOff[r0 + tid] - base; re = rowOff[r0 + tid + 1] - base; re = re < n ? re : n; }
     for (int t = tid; t < T; t += TH) {
+        if (ABL & 4) { sStart[t] = (unsigned)(((long long)t * nB + b) * 13 % (nnz - 64)); sLen[t] = 13; sOff[t] = (unsigned short)(t * 13 % 7000); continue; }
         const unsigned st = pieceStart[(long long)b * Tpad + t], en = pieceStart[(long long)(b + 1) * Tpad + t];
         sStart[t] = st; sLen[t] = (unsigned short)(en - st); sOff[t] = pieceOff[(long long)b * Tpad + t];
     }
@@ -154,8 +164,8 @@ __global__ __launch_bounds__(TH) void pb_pass2_gather(const double* __restrict__
             src = src < nnz ? src : 0;
             int pos = ok[u] ? (int)sOff[tt] + l : 0;
             pos = pos < n ? pos : 0;
-            p[u] = prodA[src];
-            at[u] = (int)bposB[base + pos] % CAP;
+            p[u] = (ABL & 2) ? 1.0 : prodA[src];
+            at[u] = (ABL & 1) ? pos % CAP : (int)bposB[base + pos] % CAP;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) if (ok[u]) s[at[u]] = p[u];
@@ -172,12 +182,9 @@ __global__ __launch_bounds__(TH) void pb_pass2_gather(const double* __restrict__
     }
     __syncthreads();
     if ((long long)tid < r1 - r0) {
-        const long long row = r0 + tid;
-        int a = rowOff[row] - base, e = rowOff[row + 1] - base;
-        e = e < n ? e : n;
         double acc = 0.0;
-        for (int j = a; j < e; ++j) acc += s[j];
-        y[row] = acc;
+        for (int j = ra; j < re; ++j) acc += s[j];
+        y[r0 + tid] = acc;
     }
 }
 
@@ -356,6 +363,65 @@ __global__ __launch_bounds__(TH) void pb_pass2_carry(const double* __restrict__ 
         }
         __syncthreads();
         cur = nxt; nxt = nn; off = offn; base = baseN; end = endN;
+    }
+}
+
+// Pass 2 without the LDS copy of the piece table: every 16-lane group loads the table entries of its own pieces (one address per group) and goes
+// straight on to the pieces -- no barrier between the table and the piece loads.
+template <int RB, int TH, int CAP, int U>
+__global__ __launch_bounds__(TH) void pb_pass2_direct_table(const double* __restrict__ prodA, const unsigned short* __restrict__ bposB, const unsigned* __restrict__ pieceStart,
+                                                            const unsigned short* __restrict__ pieceOff, int Tpad, int T, const int* __restrict__ rowOff, long long rows, int nB,
+                                                            long long nnz, double* __restrict__ y)
+{
+    constexpr int LP = 16, G = TH / LP;
+    __shared__ double s[CAP];
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, per = (int)gridDim.x >> 3;
+    const int b = xcd * per + slot;
+    if (b >= nB) return;
+    const int tid = (int)threadIdx.x;
+    const long long r0 = (long long)b * RB;
+    const long long r1 = r0 + RB < rows ? r0 + RB : rows;
+    const int base = rowOff[r0];
+    int n = rowOff[r1] - base;
+    n = n < CAP ? n : CAP;
+    int ra = 0, re = 0;
+    if ((long long)tid < r1 - r0) { ra = rowOff[r0 + tid] - base; re = rowOff[r0 + tid + 1] - base; re = re < n ? re : n; }
+    const int grp = tid / LP, l = tid % LP;
+    unsigned st[U]; int ln[U], of[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int t = grp + u * G;
+        const int tq = t < T ? t : 0;
+        st[u] = pieceStart[(long long)b * Tpad + tq];
+        const unsigned en = pieceStart[(long long)(b + 1) * Tpad + tq];
+        of[u] = (int)pieceOff[(long long)b * Tpad + tq];
+        ln[u] = t < T ? (int)(en - st[u]) : 0;
+    }
+    double p[U]; int at[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool ok = l < ln[u];
+        long long src = ok ? (long long)st[u] + l : 0;
+        src = src < nnz ? src : 0;
+        int pos = ok ? of[u] + l : 0;
+        pos = pos < n ? pos : 0;
+        p[u] = prodA[src];
+        at[u] = (int)bposB[base + pos] % CAP;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (l < ln[u]) s[at[u]] = p[u];
+        for (int i = l + LP; i < ln[u]; i += LP) {                   // pieces of more than 16 entries
+            long long src = (long long)st[u] + i; src = src < nnz ? src : 0;
+            int pos = of[u] + i; pos = pos < n ? pos : 0;
+            s[(int)bposB[base + pos] % CAP] = prodA[src];
+        }
+    }
+    __syncthreads();
+    if ((long long)tid < r1 - r0) {
+        double acc = 0.0;
+        for (int j = ra; j < re; ++j) acc += s[j];
+        y[r0 + tid] = acc;
     }
 }
 
@@ -548,6 +614,7 @@ int main(int argc, char** argv)
         }
         if constexpr (TH >= 1024) {
             for (int wgs : { 256, 512, 1024 }) {
+                if (getenv("PB_LAB_ABLATE")) break;
                 if (wgs * (size_t)(CAP * 8 + 8192) > 256 * (size_t)163840 * 8) continue;
                 auto p2p = [&] { pb_pass2_persist<RB, TH, CAP, 1024, LP, U><<<dim3((unsigned)wgs), dim3(TH), 0, 0>>>(dprod, dbpos, dps, dpo, Tpad, T, drowOff, rows, nB, nnz, dy); };
                 CK(hipMemset(dy, 0, rows * 8));
@@ -559,6 +626,7 @@ int main(int argc, char** argv)
             }
             if constexpr (LP == 16) {
                 for (int wgs : { 512, 1024 }) {
+                    if (!getenv("PB_LAB_CARRY")) break;
                     auto p2c = [&] { pb_pass2_carry<RB, TH, CAP, 1024, U><<<dim3((unsigned)wgs), dim3(TH), 0, 0>>>(dprod, dbpos, dps, dpo, Tpad, T, drowOff, rows, nB, nnz + 16, dy); };
                     CK(hipMemset(dy, 0, rows * 8));
                     const double bc = time_ms([&] { p1(); p2c(); });
@@ -569,6 +637,25 @@ int main(int argc, char** argv)
                 }
             }
             CK(hipMemset(dy, 0, rows * 8));
+        }
+        if constexpr (LP == 16 && TH / 16 * U >= 611) {
+            auto p2d = [&] { pb_pass2_direct_table<RB, TH, CAP, U><<<g2, dim3(TH), 0, 0>>>(dprod, dbpos, dps, dpo, Tpad, T, drowOff, rows, nB, nnz, dy); };
+            if (T <= TH / 16 * U) {
+                CK(hipMemset(dy, 0, rows * 8));
+                const double bd = time_ms([&] { p1(); p2d(); });
+                CK(hipGetLastError());
+                check("   (pass 2 with the piece table read by the lane groups)");
+                const double t2d = time_ms(p2d);
+                printf("%-46s piece table read by the lane groups themselves (no LDS copy, one barrier): product %.3f ms | pass 2 %.3f ms\n", name, bd, t2d); fflush(stdout);
+                CK(hipMemset(dy, 0, rows * 8));
+            }
+        }
+        if (getenv("PB_LAB_ABLATE")) {
+            auto ab = [&](auto ablc) { constexpr int A = decltype(ablc)::value; return time_ms([&] { pb_pass2_gather<RB, TH, CAP, TMAX, LP, U, A><<<g2, dim3(TH), 0, 0>>>(dprod, dbpos, dps, dpo, Tpad, T, drowOff, rows, nB, nnz, dy); }); };
+            const double a0 = ab(std::integral_constant<int, 0>{}), a1 = ab(std::integral_constant<int, 1>{}), a2 = ab(std::integral_constant<int, 2>{}), a3 = ab(std::integral_constant<int, 3>{}),
+                         a4 = ab(std::integral_constant<int, 4>{}), a7 = ab(std::integral_constant<int, 7>{});
+            printf("%-46s pass 2 ablations: as is %.3f | no position loads %.3f | no product loads %.3f | neither %.3f | no piece table (fixed 13-entry pieces) %.3f | nothing but the row sums and y %.3f ms\n", name, a0, a1, a2, a3, a4, a7);
+            fflush(stdout);
         }
         const double both = time_ms([&] { p1(); p2(); });
         CK(hipGetLastError());
@@ -582,8 +669,9 @@ int main(int argc, char** argv)
         CK(hipFree(dps)); CK(hipFree(dpo));
     };
     gather_variant("gather, blocks of 256, 1024 threads, 16 lanes x 10", std::integral_constant<int, 256>{}, std::integral_constant<int, 1024>{}, std::integral_constant<int, 9216>{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 10>{});
+    gather_variant("gather, blocks of 128, 512 threads, 16 lanes x 20", std::integral_constant<int, 128>{}, std::integral_constant<int, 512>{}, std::integral_constant<int, 4864>{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 20>{});
     gather_variant("gather, blocks of 128, 1024 threads, 16 lanes x 10", std::integral_constant<int, 128>{}, std::integral_constant<int, 1024>{}, std::integral_constant<int, 4864>{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 10>{});
-    gather_variant("gather, blocks of 512, 1024 threads, 16 lanes x 10", std::integral_constant<int, 512>{}, std::integral_constant<int, 1024>{}, std::integral_constant<int, 17408>{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 10>{});
+    gather_variant("gather, blocks of 256, 512 threads, 16 lanes x 20", std::integral_constant<int, 256>{}, std::integral_constant<int, 512>{}, std::integral_constant<int, 9216>{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 20>{});
     if (getenv("PB_LAB_GATHER_ONLY")) return g_mismatch ? 3 : 0;
     // launch shapes of pass 1 on the last destinations (timing only: the products land where they did before)
     {
