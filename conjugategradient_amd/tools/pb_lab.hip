@@ -21,8 +21,11 @@
 //            (PB_LAB_ABLATE=1, run9 / run10): without any piece load it still takes 0.98, without the piece table 0.78, with neither 0.40 --
 //            the block's fixed steps (row bounds, table, LDS hand-over, row sums: dependent round trips at two workgroups per CU), not its
 //            bytes; reading the table by the lane groups themselves instead of through LDS: 1.30 (run11).
+//   "rounds" the gather form with blocks of 1024 rows whose pieces are taken in 4 rounds of tiles, LDS holding one round at a time and every row
+//            carrying its sum from round to round: the fixed steps once per 1024 rows -- pass 2 0.75 ms, PRODUCT 1.97 ms against 2.70 for the
+//            production tile pass on the same box (run12, same_box2_*.log); PMC 9.11 GB (pmc_summary_rounds.json).
 // Measurement tool, not part of the library.  tools/pb_pmc.sh: the counter passes.
-//   pb_lab [rows=10000000] [partsPerTile=2]     PB_LAB_SKIP_RUNS=1 PB_LAB_GATHER_ONLY=1: only the "gather" form; PB_LAB_DIRECT=1: also "direct";
+//   pb_lab [rows=10000000] [partsPerTile=2]     PB_LAB_SKIP_RUNS=1 PB_LAB_GATHER_ONLY=1: only the "gather" and "rounds" forms (PB_LAB_ROUNDS_ONLY=1: only "rounds"); PB_LAB_DIRECT=1: also "direct";
 //   PB_LAB_ABLATE=1: timing ablations of pass 2; PB_LAB_CARRY=1: also the carried-segment form;
 //   PB_LAB_ONE=1: the two kernels of the best form five times (counter passes); PB_LAB_HOST_ONLY=1: the layouts replayed on the host, no device
 #include <hip/hip_runtime.h>
@@ -425,6 +428,76 @@ __global__ __launch_bounds__(TH) void pb_pass2_direct_table(const double* __rest
     }
 }
 
+// Pass 2 in ROUNDS over the tiles: a block of RBIG rows (one row per thread) takes its pieces in K rounds of T / K tiles; a round's products go to
+// LDS at their place in (row, column) order among the ROUND's entries, every row adds its share and carries the sum into the next round -- tiles
+// ascend along a row, so the additions are still in stored order.  LDS holds a K-th of the block, so the block can be K times taller at the same
+// two workgroups per CU: fewer fixed steps (row bounds, piece table) per row, longer pieces (52 entries at 1024 rows: a wavefront per piece).
+template <int RBIG, int K, int CAPK, int TMAX, int U>
+__global__ __launch_bounds__(RBIG) void pb_pass2_rounds(const double* __restrict__ prodA, const unsigned short* __restrict__ bposR, const unsigned* __restrict__ pieceStart,
+                                                        const unsigned short* __restrict__ pieceOff, const unsigned short* __restrict__ rr, int Tpad, int T, int TK,
+                                                        const int* __restrict__ rowOff, long long rows, int nB, long long nnz, double* __restrict__ y)
+{
+    constexpr int TH = RBIG, LP = 64, G = TH / LP;
+    __shared__ double s[CAPK];
+    __shared__ unsigned sStart[TMAX];
+    __shared__ unsigned short sLen[TMAX], sOff[TMAX];
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, per = (int)gridDim.x >> 3;
+    const int b = xcd * per + slot;
+    if (b >= nB) return;                                             // (workgroup-uniform)
+    const int tid = (int)threadIdx.x;
+    const long long r0 = (long long)b * RBIG;
+    const long long r1 = r0 + RBIG < rows ? r0 + RBIG : rows;
+    const int base = rowOff[r0];
+    const int nBlk = rowOff[r1] - base;
+    unsigned short ra[K], re[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { const long long at = ((long long)b * K + k) * (RBIG + 1) + tid; ra[k] = rr[at]; re[k] = rr[at + 1]; }
+    for (int t = tid; t < T; t += TH) {
+        const unsigned st = pieceStart[(long long)b * Tpad + t], en = pieceStart[(long long)(b + 1) * Tpad + t];
+        sStart[t] = st; sLen[t] = (unsigned short)(en - st); sOff[t] = pieceOff[(long long)b * Tpad + t];
+    }
+    __syncthreads();
+    const int grp = tid / LP, l = tid % LP;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int tLo = k * TK, tHi = (tLo + TK) < T ? (tLo + TK) : T;
+        double p[U]; int at[U]; bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = tLo + grp + u * G;
+            const int tq = t < tHi ? t : 0;
+            const int len = t < tHi ? (int)sLen[tq] : 0;
+            ok[u] = l < len;
+            long long src = ok[u] ? (long long)sStart[tq] + l : 0;
+            src = src < nnz ? src : 0;
+            int pos = ok[u] ? (int)sOff[tq] + l : 0;
+            pos = pos < nBlk ? pos : 0;
+            p[u] = prodA[src];
+            at[u] = (int)bposR[base + pos] % CAPK;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (ok[u]) s[at[u]] = p[u];
+        for (int u = 0; u < U; ++u) {                                // pieces of more than 64 entries
+            const int t = tLo + grp + u * G;
+            if (t >= tHi) break;
+            const int len = (int)sLen[t];
+            for (int i = l + LP; i < len; i += LP) {
+                long long src = (long long)sStart[t] + i; src = src < nnz ? src : 0;
+                int pos = (int)sOff[t] + i; pos = pos < nBlk ? pos : 0;
+                s[(int)bposR[base + pos] % CAPK] = prodA[src];
+            }
+        }
+        __syncthreads();
+        if ((long long)tid < r1 - r0) {
+            const int e = (int)re[k] < CAPK ? (int)re[k] : CAPK;
+            for (int j = (int)ra[k]; j < e; ++j) acc += s[j];
+        }
+        __syncthreads();
+    }
+    if ((long long)tid < r1 - r0) y[r0 + tid] = acc;
+}
+
 template <typename F> static double time_ms(F f, int reps = 5)
 {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -668,10 +741,69 @@ int main(int argc, char** argv)
         fflush(stdout);
         CK(hipFree(dps)); CK(hipFree(dpo));
     };
+    if (!getenv("PB_LAB_ROUNDS_ONLY"))
     gather_variant("gather, blocks of 256, 1024 threads, 16 lanes x 10", std::integral_constant<int, 256>{}, std::integral_constant<int, 1024>{}, std::integral_constant<int, 9216>{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 10>{});
+    if (!getenv("PB_LAB_BEST") && !getenv("PB_LAB_ROUNDS_ONLY")) {
     gather_variant("gather, blocks of 128, 512 threads, 16 lanes x 20", std::integral_constant<int, 128>{}, std::integral_constant<int, 512>{}, std::integral_constant<int, 4864>{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 20>{});
     gather_variant("gather, blocks of 128, 1024 threads, 16 lanes x 10", std::integral_constant<int, 128>{}, std::integral_constant<int, 1024>{}, std::integral_constant<int, 4864>{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 10>{});
     gather_variant("gather, blocks of 256, 512 threads, 16 lanes x 20", std::integral_constant<int, 256>{}, std::integral_constant<int, 512>{}, std::integral_constant<int, 9216>{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 20>{});
+    }
+    auto rounds_variant = [&](const char* name, auto RBc, auto Kc, auto CAPc) {
+        constexpr int RBIG = decltype(RBc)::value, K = decltype(Kc)::value, CAPK = decltype(CAPc)::value, TMAX = 1024, U = 10;
+        const int TK = (T + K - 1) / K;
+        if (T > TMAX || TK > (RBIG / 64) * U) { printf("%s: too many tiles per round\n", name); return; }
+        const int nB = (int)((rows + RBIG - 1) / RBIG), Tpad = (T + 7) & ~7;
+        std::vector<unsigned> pieceStart((size_t)(nB + 1) * Tpad, 0); std::vector<unsigned short> pieceOff((size_t)(nB + 1) * Tpad, 0);
+        std::vector<unsigned short> rr((size_t)nB * K * (RBIG + 1), 0);
+        {
+            std::vector<int> cur(tileStart.begin(), tileStart.end() - 1);
+            for (int b = 0; b <= nB; ++b) {
+                const long long r0 = std::min(rows, (long long)b * RBIG), r1 = std::min(rows, r0 + RBIG);
+                for (int t = 0; t < T; ++t) pieceStart[(size_t)b * Tpad + t] = (unsigned)cur[(size_t)t];
+                for (int e = rowOff[(size_t)r0]; e < rowOff[(size_t)r1]; ++e) ++cur[(size_t)(col[(size_t)e] >> kWShift)];
+            }
+            for (int b = 0; b < nB; ++b) {
+                unsigned off = 0;
+                for (int t = 0; t < T; ++t) { pieceOff[(size_t)b * Tpad + t] = (unsigned short)off; off += pieceStart[(size_t)(b + 1) * Tpad + t] - pieceStart[(size_t)b * Tpad + t]; }
+                if (off > 65535u) { printf("block %d: %u entries: too many for 16-bit offsets\n", b, off); return; }
+            }
+        }
+        if (!build_runs(RBIG)) return;                               // kB: every entry's place in its block's arrival (tile major) order
+        for (int b = 0; b < nB; ++b) {                               // bpos (by arrival index): the place among the ROUND's entries of the block, in CSR order
+            const long long r0 = (long long)b * RBIG, r1 = std::min(rows, r0 + RBIG);
+            int cnt[K]; for (int k = 0; k < K; ++k) cnt[k] = 0;
+            for (long long r = r0; r < r0 + RBIG + 1; ++r) {
+                for (int k = 0; k < K; ++k) rr[((size_t)b * K + k) * (RBIG + 1) + (size_t)(r - r0)] = (unsigned short)cnt[k];
+                if (r >= r1) continue;
+                for (int e = rowOff[(size_t)r]; e < rowOff[(size_t)r + 1]; ++e) { const int k = (col[(size_t)e] >> kWShift) / TK; bpos[(size_t)kB[(size_t)e]] = (unsigned short)cnt[k]++; }
+            }
+            for (int k = 0; k < K; ++k) if (cnt[k] > CAPK) { printf("block %d round %d: %d entries, capacity %d\n", b, k, cnt[k], CAPK); return; }
+        }
+        unsigned* dps; unsigned short *dpo, *drr;
+        CK(hipMalloc(&dps, pieceStart.size() * 4)); CK(hipMalloc(&dpo, pieceOff.size() * 2)); CK(hipMalloc(&drr, rr.size() * 2));
+        CK(hipMemcpy(dps, pieceStart.data(), pieceStart.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dpo, pieceOff.data(), pieceOff.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(drr, rr.data(), rr.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dbpos, bpos.data(), nnz * 2, hipMemcpyHostToDevice));
+        CK(hipMemset(dprod, 0, (nnz + 16) * 8)); CK(hipMemset(dy, 0, rows * 8));
+        const dim3 g2((unsigned)(8 * ((nB + 7) / 8)));
+        auto p1 = [&] { pb_pass1<1024, 2, 8><<<g1, dim3(1024), 0, 0>>>(dx, cols, dav, dac, dadest, dtileStart, parts, dprod); };
+        auto p2 = [&] { pb_pass2_rounds<RBIG, K, CAPK, TMAX, U><<<g2, dim3(RBIG), 0, 0>>>(dprod, dbpos, dps, dpo, drr, Tpad, T, TK, drowOff, rows, nB, nnz, dy); };
+        if (getenv("PB_LAB_ONE")) {                                  // counter passes
+            for (int r = 0; r < 5; ++r) { p1(); p2(); }
+            CK(hipDeviceSynchronize());
+            check(name);
+            exit(g_mismatch ? 3 : 0);
+        }
+        const double both = time_ms([&] { p1(); p2(); });
+        CK(hipGetLastError());
+        check(name);
+        const double t1 = time_ms(p1), t2 = time_ms(p2);
+        const double bytes2 = nnz * 10.0 + rows * 12.0 + (double)nB * Tpad * 10.0 + (double)rr.size() * 2.0;
+        printf("%-46s product %.3f ms | pass 1 %.3f ms | pass 2 %.3f ms = %.2f TB/s of %.2f GB\n", name, both, t1, t2, bytes2 / t2 / 1e9, bytes2 / 1e9);
+        fflush(stdout);
+        CK(hipFree(dps)); CK(hipFree(dpo)); CK(hipFree(drr));
+    };
+    rounds_variant("rounds, blocks of 1024 rows, 4 rounds of tiles", std::integral_constant<int, 1024>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 8704>{});
+    rounds_variant("rounds, blocks of 1024 rows, 5 rounds of tiles", std::integral_constant<int, 1024>{}, std::integral_constant<int, 5>{}, std::integral_constant<int, 7168>{});
     if (getenv("PB_LAB_GATHER_ONLY")) return g_mismatch ? 3 : 0;
     // launch shapes of pass 1 on the last destinations (timing only: the products land where they did before)
     {

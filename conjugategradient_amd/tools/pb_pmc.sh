@@ -1,10 +1,11 @@
 #!/bin/bash
 # HBM-side traffic of the two kernels of the propagation-blocking product (tools/pb_lab, PB_LAB_ONE=1): two rocprofv3 --pmc passes
 # (read requests by size; write requests), run on the GPU box from the repo root:   bash conjugategradient_amd/tools/pb_pmc.sh OUTDIR
+# (PB_LAB_ROUNDS_ONLY=1, the default: pass 2 in rounds over the tiles; PB_LAB_ROUNDS_ONLY= : the one-round gather form of 256-row blocks)
 set -u
 OUT=$1
 mkdir -p "$OUT"
-export TMPDIR=/tmp PB_LAB_ONE=1 PB_LAB_SKIP_RUNS=1 PB_LAB_GATHER_ONLY=1
+export TMPDIR=/tmp PB_LAB_ONE=1 PB_LAB_SKIP_RUNS=1 PB_LAB_GATHER_ONLY=1 PB_LAB_ROUNDS_ONLY=${PB_LAB_ROUNDS_ONLY:-1}
 LAB=$GRAFT_REPO_ROOT/conjugategradient_amd/tools/pb_lab
 (cd /tmp && timeout -k 10 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/pmc_rd" -- $LAB 10000000 2) > "$OUT/pmc_rd.log" 2>&1
 echo "pmc_rd rc=$?"
